@@ -1,0 +1,198 @@
+/* ============================================================================
+ * sbx_depth.h -- C ABI of libsbx_depth.so, the MI355X (gfx950) engine behind
+ *                `sambamba depth base|region|window`.
+ *
+ * The reference (biod/sambamba, D) has no plugin API.  Its only FFI precedent is
+ * the zlib binding (BioD/bio/core/utils/zlib.d:6,139-163: extern(C) prototypes,
+ * caller-owned buffers, int return codes turned into exceptions).  This header
+ * follows the same conventions and plugs into the two seams SURVEY.md 8(b) names:
+ *
+ *   codec seam   decompressBgzfBlock(BgzfBlock)            BioD/bio/core/bgzf/block.d:127
+ *                (called from BgzfInputStream.fillNextBlock, inputstream.d:414-417)
+ *                -> sbx_inflate_blocks()
+ *
+ *   engine seam  everything between "bam opened, filter/regions/mode known"
+ *                (sambamba/depth.d:1163-1217) and "printer.push / printer.close"
+ *                (depth.d:1218-1234)   -> sbx_open ... sbx_depth_* ... sbx_close
+ *
+ * Conventions: every function returns 0 on success or a negative SBX_E* code;
+ * the message is available from sbx_last_error() (the D shim turns it into the
+ * `sambamba-depth: <msg>` line of depth.d:1237-1244).  The caller owns every
+ * output buffer; the library owns device memory and file mappings.  One sbx_ctx
+ * is used from one host thread at a time; calls are blocking.  The library never
+ * falls back to a CPU implementation: without a usable HIP device every compute
+ * entry point fails with SBX_ENODEVICE.
+ * ========================================================================== */
+#ifndef SBX_DEPTH_H
+#define SBX_DEPTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBX_OK            0
+#define SBX_EINVAL       -1   /* bad argument */
+#define SBX_EIO          -2   /* file missing / unreadable / truncated */
+#define SBX_EFORMAT      -3   /* not BGZF / BAM / BAI, or corrupt deflate stream */
+#define SBX_ENODEVICE    -4   /* no HIP device or HIP runtime failure */
+#define SBX_EUNSUPPORTED -5   /* valid request outside the device path (e.g. regex -F filter) */
+#define SBX_ENOTSORTED   -6   /* "All files must be coordinate-sorted" (depth.d:1164-1165) */
+#define SBX_ENOINDEX     -7   /* "All files must be indexed"           (depth.d:1166)      */
+#define SBX_ENOMEM       -8
+#define SBX_ERG          -9   /* read group of a read is not in the header (depth.d:246-248) */
+
+typedef struct sbx_ctx sbx_ctx;
+
+/* Counter layout of one reference position of one sample, `depth base`
+ * (PerBasePrinter.writeColumn, depth.d:495-556): A, C, G, T, other (N/IUPAC/'='),
+ * DEL, REFSKIP.  COV = sum of all seven (code 4 counts towards COV but has no column). */
+#define SBX_NCOUNTERS 7
+
+enum { SBX_MODE_BASE = 0, SBX_MODE_REGION = 1, SBX_MODE_WINDOW = 2 };   /* depth.d:101-105 */
+
+typedef struct {
+    uint32_t ref_id;   /* BamRegion (BioD/bio/std/hts/bam/region.d:28-31) */
+    uint32_t start;    /* 0-based, inclusive */
+    uint32_t end;      /* 0-based, exclusive */
+} sbx_region;
+
+typedef struct {
+    int32_t n_ref;             /* reference_sequences.length (reader.d:580-598)            */
+    int32_t n_samples;         /* sample_names.length, >= 1 ("*" when there is no @RG)      */
+    int32_t n_read_groups;
+    int32_t sorted_by_coordinate;  /* header.sorting_order == coordinate (depth.d:1164)     */
+    int32_t has_index;         /* bam.has_index (depth.d:1166)                             */
+    int32_t reserved;
+    uint64_t n_bgzf_blocks;
+    uint64_t compressed_bytes;
+    uint64_t uncompressed_bytes;
+} sbx_header_info;
+
+/* Per region (or window) x sample statistics: PerSampleRegionData (depth.d:609-635).
+ * The reference keeps these as 32-bit `uint` (wrap-around is reference behaviour). */
+typedef struct {
+    uint32_t n_reads;
+    uint32_t n_bases;
+} sbx_region_stats;
+
+/* The compiled subset of the -F filter language (sambamba/utils/common/filtering.d:86-214,
+ * queryparser.d:232-483): a postfix program over flag tests, integer-field comparisons,
+ * and / or / not.  Built by sbx_compile_filter() from the query string. */
+#define SBX_FILTER_MAX_OPS 64
+typedef struct {
+    uint8_t  kind;     /* 0 FLAG_ANY(mask)  1 CHIMERIC  2 INTCMP  3 AND  4 OR  5 NOT  6 TRUE */
+    uint8_t  field;    /* INTCMP: 0 ref_id 1 position 2 mapping_quality 3 sequence_length
+                                  4 mate_ref_id 5 mate_position 6 template_length            */
+    uint8_t  cmp;      /* INTCMP: 0 >  1 <  2 >=  3 <=  4 ==  5 !=                           */
+    uint8_t  pad;
+    uint32_t mask;
+    int64_t  value;
+} sbx_filter_op;
+typedef struct {
+    int32_t n_ops;
+    int32_t reserved;
+    sbx_filter_op ops[SBX_FILTER_MAX_OPS];
+} sbx_filter;
+
+/* ---- codec seam -------------------------------------------------------------
+ * Batched replacement of decompressBgzfBlock (block.d:127-216): raw-deflate (RFC 1951,
+ * zlib windowBits = -15) payloads comp[comp_off[i] .. +comp_len[i]) are inflated on the
+ * device into out[out_off[i] .. +isize[i]).  All pointers are host memory.  As in the
+ * reference's release build the CRC32 is not verified (block.d:187).  Returns
+ * SBX_EFORMAT if any payload is not a valid deflate stream of exactly isize[i] bytes. */
+int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
+                       const uint32_t* isize, uint32_t n_blocks, uint8_t* out, const uint64_t* out_off,
+                       char* err, size_t errlen);
+
+/* ---- engine seam ------------------------------------------------------------ */
+
+/* new MultiBamReader(filenames) (multireader.d:244) + BamReader header parse
+ * (reader.d:101-125).  n_bams must be 1 in this version (multi-BAM merge is SURVEY 8(f)-2).
+ * device = HIP device ordinal (or -1: use LOCAL_RANK / 0). */
+sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* err, size_t errlen);
+void sbx_close(sbx_ctx*);
+const char* sbx_last_error(sbx_ctx*);
+
+int sbx_header(sbx_ctx*, sbx_header_info* out);
+/* reference_sequences[i].name / .length (depth.d:455,576,1041,1223) */
+const char* sbx_ref_name(sbx_ctx*, int ref_id);
+int64_t sbx_ref_length(sbx_ctx*, int ref_id);
+int sbx_ref_id(sbx_ctx*, const char* name);           /* bam.hasReference / bam[name].id; -1 if absent */
+/* printer.sample_names (depth.d:1170-1181) */
+const char* sbx_sample_name(sbx_ctx*, int sample_id);
+/* raw SAM header text (for the D shim's SamHeader) */
+const char* sbx_header_text(sbx_ctx*, size_t* len);
+
+/* createFilterFromQuery (filtering.d:40-51).  query == NULL compiles the default
+ * "mapping_quality > 0 and not duplicate and not failed_quality_control" (depth.d:1159).
+ * Returns SBX_EUNSUPPORTED for string / tag / regex conditions. */
+int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t errlen);
+int sbx_set_filter(sbx_ctx*, const sbx_filter* f);
+
+/* -q, -m, --combined (depth.d:1127-1132); window/overlap and -T (depth.d:712-715,1015-1018). */
+int sbx_set_params(sbx_ctx*, int mode, uint8_t min_base_quality, int fix_mate_overlaps, int combined,
+                   uint32_t window_size, uint32_t overlap, const uint32_t* cov_thresholds, int n_thresholds);
+
+/* -L: the merged, sorted region list used to fetch reads (getReadsOverlapping, depth.d:1211 ->
+ * randomaccessmanager.d:316-338).  n == 0 means "all reads" (bam.reads, depth.d:1214). */
+int sbx_set_regions(sbx_ctx*, const sbx_region* regions, size_t n);
+
+/* Run BGZF inflate -> record index -> decode+accumulate on the device for everything the
+ * current filter/params/regions select.  Results stay resident in HBM until the next
+ * sbx_run()/sbx_close(); the sbx_depth_* getters below copy them out.  */
+int sbx_run(sbx_ctx*);
+
+/* depth base: counters[(pos-beg)*n_samples*7 + s*7 + k] for pos in [beg,end) of ref_id
+ * (k = A,C,G,T,other,DEL,REFSKIP; n_samples = 1 when --combined).  Positions no admitted read
+ * spans are all-zero.  covered (optional, may be NULL): 1 byte per position, non-zero iff >= 1
+ * admitted read spans the position (a pileup column exists there, pileup.d:345-397) -- needed
+ * to tell "column with COV 0" from "no column" when min_base_quality > 0. */
+int sbx_depth_base_tile(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, uint32_t* counters,
+                        uint8_t* covered);
+
+/* depth region: stats[r*n_samples + s] and cov_counts[(r*n_samples + s)*n_thresholds + t] for the
+ * raw (unmerged, input-order) region list given here (PerBedRegionPrinter, depth.d:879-931).
+ * seen[r] != 0 iff at least one column hit region r (is_first_occurrence cleared). */
+int sbx_depth_region_stats(sbx_ctx*, const sbx_region* raw_regions, size_t n_regions,
+                           sbx_region_stats* stats, uint32_t* cov_counts, uint8_t* seen);
+
+/* depth window: the same for windows [k*step, k*step + window) of ref_id, k in
+ * [first_win, first_win + n_win) (PerWindowPrinter, depth.d:933-1077). */
+int sbx_depth_window_stats(sbx_ctx*, uint32_t ref_id, uint64_t first_win, uint64_t n_win,
+                           sbx_region_stats* stats, uint32_t* cov_counts);
+
+/* Device-side row formatting of `depth base` (writeColumn's text, depth.d:534-555) for
+ * [beg,end) of ref_id into a caller buffer; returns bytes written through *out_len, or
+ * SBX_ENOMEM if cap is too small (then *out_len = required size). */
+int sbx_format_base_rows(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov,
+                         int annotate, char* out, size_t cap, size_t* out_len);
+
+/* Timing / accounting of the last sbx_run() (for bench.py): per-kernel milliseconds measured
+ * with HIP events on the engine's stream, record counts, byte counts. */
+typedef struct {
+    double ms_inflate, ms_index, ms_accumulate, ms_reduce, ms_total, ms_h2d;
+    uint64_t n_records, n_admitted, n_bgzf_blocks;
+    uint64_t compressed_bytes, uncompressed_bytes, counter_bytes, covered_positions;
+    uint64_t launches_inflate, launches_index, launches_accumulate;
+} sbx_run_stats;
+int sbx_last_run_stats(sbx_ctx*, sbx_run_stats* out);
+
+/* Geometry of the result tiles of the last sbx_run(): positions per tile and the effective
+ * number of samples (1 under --combined). */
+int sbx_tile_info(sbx_ctx*, uint32_t* tile_pos, uint32_t* n_samples);
+/* Next maximal run of tiles of ref_id holding >= 1 admitted read, at or after position `from`:
+ * [*beg,*end) in contig coordinates (tile-aligned end), or *beg == *end == UINT64_MAX when there is
+ * none.  Lets a caller walk a contig without copying the all-zero stretches. */
+int sbx_next_active_range(sbx_ctx*, uint32_t ref_id, uint64_t from, uint64_t* beg, uint64_t* end);
+
+/* Keep the compressed file resident in HBM across sbx_run() calls (bench: "inputs already
+ * resident in HBM when the timed region starts"). */
+int sbx_preload(sbx_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBX_DEPTH_H */

@@ -1,0 +1,213 @@
+"""ctypes binding of include/sbx_depth.h (no torch types, plain pointers and sizes)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(HERE, "csrc", "libsbx_depth.so")
+_CLI_PATH = os.path.join(HERE, "csrc", "sbx-depth")
+
+SBX_MODE_BASE, SBX_MODE_REGION, SBX_MODE_WINDOW = 0, 1, 2
+SBX_FILTER_MAX_OPS = 64
+NCOUNTERS = 7
+
+
+class SbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sbx error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class Region(C.Structure):
+    _fields_ = [("ref_id", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32)]
+
+
+class HeaderInfo(C.Structure):
+    _fields_ = [("n_ref", C.c_int32), ("n_samples", C.c_int32), ("n_read_groups", C.c_int32),
+                ("sorted_by_coordinate", C.c_int32), ("has_index", C.c_int32), ("reserved", C.c_int32),
+                ("n_bgzf_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64), ("uncompressed_bytes", C.c_uint64)]
+
+
+class RegionStats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_bases", C.c_uint32)]
+
+
+class FilterOp(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("field", C.c_uint8), ("cmp", C.c_uint8), ("pad", C.c_uint8),
+                ("mask", C.c_uint32), ("value", C.c_int64)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("n_ops", C.c_int32), ("reserved", C.c_int32), ("ops", FilterOp * SBX_FILTER_MAX_OPS)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("ms_inflate", C.c_double), ("ms_index", C.c_double), ("ms_accumulate", C.c_double),
+                ("ms_reduce", C.c_double), ("ms_total", C.c_double), ("ms_h2d", C.c_double),
+                ("n_records", C.c_uint64), ("n_admitted", C.c_uint64), ("n_bgzf_blocks", C.c_uint64),
+                ("compressed_bytes", C.c_uint64), ("uncompressed_bytes", C.c_uint64), ("counter_bytes", C.c_uint64),
+                ("covered_positions", C.c_uint64), ("launches_inflate", C.c_uint64), ("launches_index", C.c_uint64),
+                ("launches_accumulate", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/sbx_depth.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
+    "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_set_params",
+    "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_window_stats",
+    "sbx_format_base_rows", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
+]
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def cli_path():
+    return _CLI_PATH
+
+
+def lib():
+    """Load libsbx_depth.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("libsbx_depth.so is missing at %s -- run `python -m sambamba_amd.build` "
+                          "(the HIP library is the product; there is no CPU fallback)" % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.sbx_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.c_char_p, C.c_size_t]
+    L.sbx_inflate_blocks.restype = C.c_int
+    L.sbx_open.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.sbx_open.restype = C.c_void_p
+    L.sbx_close.argtypes = [C.c_void_p]
+    L.sbx_close.restype = None
+    L.sbx_last_error.argtypes = [C.c_void_p]
+    L.sbx_last_error.restype = C.c_char_p
+    L.sbx_header.argtypes = [C.c_void_p, C.POINTER(HeaderInfo)]
+    L.sbx_ref_name.argtypes = [C.c_void_p, C.c_int]
+    L.sbx_ref_name.restype = C.c_char_p
+    L.sbx_ref_length.argtypes = [C.c_void_p, C.c_int]
+    L.sbx_ref_length.restype = C.c_int64
+    L.sbx_ref_id.argtypes = [C.c_void_p, C.c_char_p]
+    L.sbx_sample_name.argtypes = [C.c_void_p, C.c_int]
+    L.sbx_sample_name.restype = C.c_char_p
+    L.sbx_header_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.sbx_header_text.restype = C.c_char_p
+    L.sbx_compile_filter.argtypes = [C.c_char_p, C.POINTER(Filter), C.c_char_p, C.c_size_t]
+    L.sbx_set_filter.argtypes = [C.c_void_p, C.POINTER(Filter)]
+    L.sbx_set_params.argtypes = [C.c_void_p, C.c_int, C.c_uint8, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
+    L.sbx_set_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sbx_run.argtypes = [C.c_void_p]
+    L.sbx_depth_base_tile.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.sbx_depth_region_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sbx_depth_window_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.sbx_format_base_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sbx_last_run_stats.argtypes = [C.c_void_p, C.POINTER(RunStats)]
+    L.sbx_tile_info.argtypes = [C.c_void_p, u32p, u32p]
+    L.sbx_next_active_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, u64p, u64p]
+    L.sbx_preload.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def inflate_blocks(comp, comp_off, comp_len, isize, out_off, out_size):
+    """sbx_inflate_blocks over numpy arrays; returns the inflated bytes (numpy uint8)."""
+    L = lib()
+    comp = np.ascontiguousarray(comp, dtype=np.uint8)
+    comp_off = np.ascontiguousarray(comp_off, dtype=np.uint64)
+    comp_len = np.ascontiguousarray(comp_len, dtype=np.uint32)
+    isize = np.ascontiguousarray(isize, dtype=np.uint32)
+    out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
+    out = np.zeros(int(out_size), dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    rc = L.sbx_inflate_blocks(comp.ctypes.data, comp_off.ctypes.data, comp_len.ctypes.data, isize.ctypes.data,
+                              len(comp_len), out.ctypes.data, out_off.ctypes.data, err, 512)
+    if rc != 0:
+        raise SbxError(rc, err.value.decode())
+    return out
+
+
+def compile_filter(query):
+    f = Filter()
+    err = C.create_string_buffer(512)
+    rc = lib().sbx_compile_filter(query.encode() if query is not None else None, C.byref(f), err, 512)
+    if rc != 0:
+        raise SbxError(rc, err.value.decode())
+    return f
+
+
+class Depth:
+    """Thin object wrapper over an sbx_ctx (one BAM, one device)."""
+
+    def __init__(self, bam_path, device=-1):
+        self._L = lib()
+        arr = (C.c_char_p * 1)(bam_path.encode())
+        err = C.create_string_buffer(1024)
+        self._ctx = self._L.sbx_open(arr, 1, device, err, 1024)
+        if not self._ctx:
+            raise SbxError(-1, err.value.decode())
+        hi = HeaderInfo()
+        self._check(self._L.sbx_header(self._ctx, C.byref(hi)))
+        self.info = hi
+        self.ref_names = [self._L.sbx_ref_name(self._ctx, i).decode() for i in range(hi.n_ref)]
+        self.ref_lengths = [self._L.sbx_ref_length(self._ctx, i) for i in range(hi.n_ref)]
+        self.sample_names = [self._L.sbx_sample_name(self._ctx, i).decode() for i in range(hi.n_samples)]
+        self.n_samples_eff = hi.n_samples
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SbxError(rc, self._L.sbx_last_error(self._ctx).decode())
+
+    def close(self):
+        if self._ctx:
+            self._L.sbx_close(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_filter(self, query):
+        f = compile_filter(query)
+        self._check(self._L.sbx_set_filter(self._ctx, C.byref(f)))
+
+    def set_params(self, mode=SBX_MODE_BASE, min_bq=0, fix_mate_overlaps=False, combined=False, window=0, overlap=0,
+                   thresholds=()):
+        thr = np.asarray(list(thresholds), dtype=np.uint32)
+        self._check(self._L.sbx_set_params(self._ctx, mode, min_bq, int(fix_mate_overlaps), int(combined), window, overlap,
+                                           thr.ctypes.data if len(thr) else None, len(thr)))
+        self.n_samples_eff = 1 if combined else self.info.n_samples
+
+    def set_regions(self, regions):
+        arr = (Region * len(regions))(*[Region(*r) for r in regions])
+        self._check(self._L.sbx_set_regions(self._ctx, arr, len(regions)))
+
+    def preload(self):
+        self._check(self._L.sbx_preload(self._ctx))
+
+    def run(self):
+        self._check(self._L.sbx_run(self._ctx))
+        st = RunStats()
+        self._check(self._L.sbx_last_run_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def base_counters(self, ref_id, beg, end, with_covered=False):
+        S = self.n_samples_eff
+        out = np.zeros((end - beg, S, NCOUNTERS), dtype=np.uint32)
+        cov = np.zeros(end - beg, dtype=np.uint8) if with_covered else None
+        self._check(self._L.sbx_depth_base_tile(self._ctx, ref_id, beg, end, out.ctypes.data,
+                                                cov.ctypes.data if with_covered else None))
+        return (out, cov) if with_covered else out

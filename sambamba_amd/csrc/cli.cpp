@@ -1,0 +1,446 @@
+// cli.cpp -- `sbx-depth`: the host side of `sambamba depth base|region|window` on top of the
+// C ABI of libsbx_depth.so.  It mirrors depth_main (sambamba/depth.d:1079-1245): same
+// sub-commands, same options (depth.d:59-98), same text output byte for byte, same error
+// line ("sambamba-depth: <msg>", exit code 1).  All counting happens on the MI355X through
+// sbx_run(); this file only parses arguments and prints.
+//
+//   sbx-depth base   [-F filter] [-o out] [-c min] [-C max] [-q bq] [-a] [--combined] [-L regions] [-z] in.bam
+//   sbx-depth region -L regions [-T thr]... [common options] in.bam
+//   sbx-depth window -w size [--overlap n] [-T thr]... [common options] in.bam
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sbx_depth.h"
+#include "host_io.hpp"
+
+using namespace sbx;
+
+namespace {
+
+struct Options {
+    std::string mode;
+    std::vector<std::string> bams;
+    std::string filter;
+    bool has_filter = false;
+    std::string output_fn;
+    int n_threads = 0;
+    double min_cov = 0.0, max_cov = 1e50;
+    int min_bq = 0;
+    bool annotate = false, combined = false, fix_mate = false;
+    std::string regions;
+    bool has_regions = false;
+    bool report_zero = false;
+    std::vector<uint32_t> thresholds;
+    unsigned long long window = 0, overlap = 0;
+};
+
+void usage() {  // depth.d:50-99
+    fputs("Usage: sambamba-depth region|window|base [options] input.bam  [input2.bam [...]]\n\n"
+          "          All BAM files must be coordinate-sorted and indexed.\n\n"
+          "          The tool has three modes: base, region, and window,\n"
+          "          each name means per which unit to print the statistics.\n\n"
+          "Common options:\n"
+          "         -F, --filter=FILTER\n"
+          "                    set custom filter for alignments; the default value is\n"
+          "                    'mapping_quality > 0 and not duplicate and not failed_quality_control'\n"
+          "         -o, --output-file=FILENAME\n"
+          "                    output filename (by default /dev/stdout)\n"
+          "         -t, --nthreads=NTHREADS\n"
+          "                    maximum number of threads to use\n"
+          "         -c, --min-coverage=MINCOVERAGE\n"
+          "                    minimum mean coverage for output (default: 0 for region/window, 1 for base)\n"
+          "         -C, --max-coverage=MAXCOVERAGE\n"
+          "                    maximum mean coverage for output\n"
+          "         -q, --min-base-quality=QUAL\n"
+          "                    don't count bases with lower base quality\n"
+          "         --combined\n"
+          "                    output combined statistics for all samples\n"
+          "         -a, --annotate\n"
+          "                    add additional column of y/n instead of\n"
+          "                    skipping records not satisfying the criteria\n"
+          "         -m, --fix-mate-overlaps\n"
+          "                    detect overlaps of mate reads and handle them on per-base basis\n"
+          "base subcommand options:\n"
+          "         -L, --regions=FILENAME|REGION\n"
+          "                    list or regions of interest or a single region in form chr:beg-end (optional)\n"
+          "         -z, --report-zero-coverage (DEPRECATED, use --min-coverage=0 instead)\n"
+          "                    don't skip zero coverage bases\n"
+          "region subcommand options:\n"
+          "         -L, --regions=FILENAME|REGION\n"
+          "                    list or regions of interest or a single region in form chr:beg-end (required)\n"
+          "         -T, --cov-threshold=COVTHRESHOLD\n"
+          "                    multiple thresholds can be provided,\n"
+          "                    for each one an extra column will be added,\n"
+          "                    the percentage of bases in the region\n"
+          "                    where coverage is more than this value\n"
+          "window subcommand options:\n"
+          "         -w, --window-size=WINDOWSIZE\n"
+          "                    breadth of the window, in bp (required)\n"
+          "         --overlap=OVERLAP\n"
+          "                    overlap of successive windows, in bp (default is 0)\n"
+          "         -T, --cov-threshold=COVTHRESHOLD\n"
+          "                    same meaning as in 'region' subcommand\n",
+          stderr);
+}
+
+bool parse_args(int argc, char** argv, Options* o, std::string* err) {
+    o->mode = argv[1];
+    if (o->mode == "base") o->min_cov = 1;  // depth.d:1113-1114
+    struct Spec { const char* lng; char sht; int kind; };
+    static const Spec specs[] = {
+        {"filter", 'F', 1}, {"output-filename", 'o', 1}, {"nthreads", 't', 1}, {"min-coverage", 'c', 1},
+        {"max-coverage", 'C', 1}, {"min-base-quality", 'q', 1}, {"annotate", 'a', 0}, {"combined", 0, 0},
+        {"fix-mate-overlaps", 'm', 0}, {"regions", 'L', 1}, {"report-zero-coverage", 'z', 0},
+        {"cov-threshold", 'T', 1}, {"window-size", 'w', 1}, {"overlap", 0, 1}};
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i];
+        const Spec* sp = nullptr;
+        std::string val;
+        bool have_val = false;
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            size_t eq = a.find('=');
+            std::string name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            for (auto& s : specs) if (name == s.lng) sp = &s;
+            if (eq != std::string::npos) { val = a.substr(eq + 1); have_val = true; }
+        } else if (a.size() >= 2 && a[0] == '-' && a[1] != '-') {
+            for (auto& s : specs) if (s.sht && a[1] == s.sht) sp = &s;
+            if (sp && a.size() > 2) { val = a.substr(a[2] == '=' ? 3 : 2); have_val = true; }
+        }
+        if (!sp) { o->bams.push_back(a); continue; }
+        if (sp->kind == 1 && !have_val) {
+            if (i + 1 >= argc) { *err = "Missing value for argument " + a + "."; return false; }
+            val = argv[++i];
+        }
+        std::string n = sp->lng;
+        if (n == "filter") { o->filter = val; o->has_filter = true; }
+        else if (n == "output-filename") o->output_fn = val;
+        else if (n == "nthreads") o->n_threads = atoi(val.c_str());
+        else if (n == "min-coverage") o->min_cov = atof(val.c_str());
+        else if (n == "max-coverage") o->max_cov = atof(val.c_str());
+        else if (n == "min-base-quality") o->min_bq = atoi(val.c_str());
+        else if (n == "annotate") o->annotate = true;
+        else if (n == "combined") o->combined = true;
+        else if (n == "fix-mate-overlaps") o->fix_mate = true;
+        else if (n == "regions") { o->regions = val; o->has_regions = true; }
+        else if (n == "report-zero-coverage") o->report_zero = true;
+        else if (n == "cov-threshold") o->thresholds.push_back((uint32_t)strtoul(val.c_str(), nullptr, 10));
+        else if (n == "window-size") o->window = strtoull(val.c_str(), nullptr, 10);
+        else if (n == "overlap") o->overlap = strtoull(val.c_str(), nullptr, 10);
+    }
+    if (o->mode == "window") o->has_regions = false;  // -L is not parsed in window mode (depth.d:1139)
+    return true;
+}
+
+struct Out {
+    FILE* fp = stdout;
+    std::string buf;
+    void put(const char* s, size_t n) {
+        buf.append(s, n);
+        if (buf.size() > (4u << 20)) flush();
+    }
+    void put(const std::string& s) { put(s.data(), s.size()); }
+    void flush() {
+        if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), fp);
+        buf.clear();
+    }
+};
+
+inline char* u64toa(uint64_t v, char* end) {  // writes backwards, returns start
+    do { *--end = (char)('0' + v % 10); v /= 10; } while (v);
+    return end;
+}
+
+struct Fail { std::string msg; };
+void check(sbx_ctx* c, int rc) { if (rc != SBX_OK) throw Fail{sbx_last_error(c)}; }
+
+bool region_less(const sbx_region& a, const sbx_region& b) {
+    if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+    if (a.start != b.start) return a.start < b.start;
+    return a.end < b.end;
+}
+
+// ---------------------------------------------------------------------------------------------
+// depth base: PerBasePrinter (depth.d:402-607) driven from the device's dense counter tiles.
+// A "column" exists at every position spanned by >= 1 admitted read (covered[] from the device).
+// ---------------------------------------------------------------------------------------------
+class BasePrinter {
+public:
+    BasePrinter(sbx_ctx* c, const Options& o, Out& out, const std::vector<std::string>& samples)
+        : c_(c), o_(o), out_(out), samples_(samples) {
+        sbx_header_info hi;
+        sbx_header(c, &hi);
+        n_ref_ = hi.n_ref;
+        S_ = o.combined ? 1u : (uint32_t)samples.size();
+    }
+    void set_bed(const std::vector<sbx_region>& bed) { bed_ = bed; raw_ = bed; bed_provided_ = true; cur_head_ = 0; raw_head_ = 0; }
+    void header() {
+        std::string h = "REF\tPOS\tCOV\tA\tC\tG\tT\tDEL\tREFSKIP";
+        if (!o_.combined) h += "\tSAMPLE";
+        if (o_.annotate) h += "\tFLAG";
+        h += "\n";
+        out_.put(h);
+    }
+    void run() {
+        std::vector<uint32_t> cnt;
+        std::vector<uint8_t> cov;
+        const uint64_t CH = 1u << 20;
+        for (int r = 0; r < n_ref_; ++r) {
+            uint64_t from = 0;
+            for (;;) {
+                uint64_t b, e;
+                check(c_, sbx_next_active_range(c_, (uint32_t)r, from, &b, &e));
+                if (b == ~0ULL) break;
+                for (uint64_t p = b; p < e; p += CH) {
+                    uint64_t q = std::min(e, p + CH);
+                    cnt.resize((size_t)(q - p) * S_ * SBX_NCOUNTERS);
+                    cov.resize((size_t)(q - p));
+                    check(c_, sbx_depth_base_tile(c_, (uint32_t)r, (uint32_t)p, (uint32_t)q, cnt.data(), cov.data()));
+                    for (uint64_t x = p; x < q; ++x)
+                        if (cov[(size_t)(x - p)]) push(r, (int64_t)x, &cnt[(size_t)(x - p) * S_ * SBX_NCOUNTERS]);
+                }
+                from = e;
+            }
+        }
+        close();
+    }
+
+private:
+    sbx_ctx* c_;
+    const Options& o_;
+    Out& out_;
+    const std::vector<std::string>& samples_;
+    int n_ref_ = 0;
+    uint32_t S_ = 1;
+    bool bed_provided_ = false;
+    std::vector<sbx_region> bed_;   // NonOverlappingRegionStatsCollector view (depth.d:171-198)
+    size_t cur_head_ = 0;
+    std::vector<sbx_region> raw_;   // raw_bed, consumed by writeEmptyColumns (depth.d:464-486)
+    size_t raw_head_ = 0;
+    int prev_ref_ = -2;
+    int64_t prev_pos_ = 0;
+    std::vector<std::string> tails_;
+
+    static bool fully_left_of(const sbx_region& g, uint32_t ref, uint32_t pos) { return g.ref_id < ref || (g.ref_id == ref && g.end <= pos); }
+    static bool overlaps(const sbx_region& g, uint32_t ref, uint32_t pos) { return g.ref_id == ref && g.start <= pos && pos < g.end; }
+
+    bool output_required(int ref, int64_t pos) {  // depth.d:558-565
+        if (!bed_provided_) return true;
+        while (cur_head_ < bed_.size() && fully_left_of(bed_[cur_head_], (uint32_t)ref, (uint32_t)pos)) ++cur_head_;
+        return cur_head_ < bed_.size() && overlaps(bed_[cur_head_], (uint32_t)ref, (uint32_t)pos);
+    }
+    void init_tails() {  // depth.d:436-450
+        if (!tails_.empty()) return;
+        if (o_.combined) {
+            tails_.push_back("\t0\t0\t0\t0\t0\t0\t0");
+            if (o_.annotate) tails_[0] += (o_.min_cov > 0 ? "\tn" : "\ty");
+        } else {
+            for (auto& s : samples_) {
+                tails_.push_back("\t0\t0\t0\t0\t0\t0\t0\t" + s);
+                if (o_.annotate) tails_.back() += (o_.min_cov > 0 ? "\tn" : "\ty");
+            }
+        }
+    }
+    void emit_empty(const char* ref_name, size_t ref_len, long from, long to) {
+        char num[24];
+        for (long pos = from; pos < to; ++pos) {
+            char* e = num + sizeof num;
+            char* s = u64toa((uint64_t)pos, e);
+            for (auto& t : tails_) {
+                out_.put(ref_name, ref_len);
+                out_.put("\t", 1);
+                out_.put(s, (size_t)(e - s));
+                out_.put(t);
+                out_.put("\n", 1);
+            }
+        }
+    }
+    void write_empty(long ref_id, long start, long end) {  // depth.d:452-487
+        if (o_.min_cov > 0 && !o_.annotate) return;
+        const char* name = sbx_ref_name(c_, (int)ref_id);
+        size_t nl = strlen(name);
+        init_tails();
+        if (!bed_provided_) { emit_empty(name, nl, start, end); return; }
+        if (raw_head_ >= raw_.size() || raw_[raw_head_].ref_id > (uint32_t)ref_id) return;
+        while (raw_head_ < raw_.size() && raw_[raw_head_].ref_id < (uint32_t)ref_id) ++raw_head_;
+        while (raw_head_ < raw_.size() && raw_[raw_head_].ref_id == (uint32_t)ref_id) {
+            sbx_region& f = raw_[raw_head_];
+            if (fully_left_of(f, (uint32_t)ref_id, (uint32_t)start)) { ++raw_head_; continue; }
+            long from = std::max<long>(start, f.start), to = std::min<long>(end, f.end);
+            if (from >= to) break;
+            emit_empty(name, nl, from, to);
+            f.start = (uint32_t)to;
+            if (f.start >= f.end) ++raw_head_;
+        }
+        bed_.assign(raw_.begin() + (long)raw_head_, raw_.end());   // collector rebuilt from what is left (depth.d:485)
+        cur_head_ = 0;
+    }
+    void write_column(int ref, int64_t pos, const uint32_t* cnt) {  // depth.d:534-555
+        const char* name = sbx_ref_name(c_, ref);
+        size_t nl = strlen(name);
+        char num[24];
+        for (uint32_t s = 0; s < S_; ++s) {
+            const uint32_t* v = cnt + (size_t)s * SBX_NCOUNTERS;
+            uint64_t total = (uint64_t)v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6];
+            bool ok = (double)total >= o_.min_cov && (double)total <= o_.max_cov;
+            if (!ok && !o_.annotate) return;  // return, not continue (depth.d:540-541)
+            out_.put(name, nl);
+            auto num_field = [&](uint64_t x) {
+                char* e = num + sizeof num;
+                char* b = u64toa(x, e);
+                out_.put("\t", 1);
+                out_.put(b, (size_t)(e - b));
+            };
+            num_field((uint64_t)pos);
+            num_field(total);
+            num_field(v[0]); num_field(v[1]); num_field(v[2]); num_field(v[3]);
+            num_field(v[5]); num_field(v[6]);
+            if (!o_.combined) { out_.put("\t", 1); out_.put(samples_[s]); }
+            if (o_.annotate) out_.put(ok ? "\ty" : "\tn", 2);
+            out_.put("\n", 1);
+        }
+    }
+    void push(int ref, int64_t pos, const uint32_t* cnt) {  // depth.d:567-591
+        if (o_.min_cov > 0) {
+            if (output_required(ref, pos)) write_column(ref, pos, cnt);
+            return;
+        }
+        if (prev_ref_ == -2) {
+            for (int id = 0; id < ref; ++id) write_empty(id, 0, (long)sbx_ref_length(c_, id));
+            write_empty(ref, 0, (long)pos);
+        } else if (prev_ref_ != ref) {
+            write_empty(prev_ref_, (long)prev_pos_ + 1, (long)sbx_ref_length(c_, prev_ref_));
+            write_empty(ref, 0, (long)pos);
+        } else if (prev_pos_ != pos - 1) {
+            write_empty(ref, (long)prev_pos_ + 1, (long)pos);
+        }
+        prev_ref_ = ref;
+        prev_pos_ = pos;
+        if (output_required(ref, pos)) write_column(ref, pos, cnt);
+    }
+    void close() {  // depth.d:593-606
+        if (!(o_.min_cov == 0)) return;
+        if (prev_ref_ == -2) {
+            for (int id = 0; id < n_ref_; ++id) write_empty(id, 0, (long)sbx_ref_length(c_, id));
+        } else {
+            write_empty(prev_ref_, (long)prev_pos_ + 1, (long)sbx_ref_length(c_, prev_ref_));
+            for (int id = prev_ref_ + 1; id < n_ref_; ++id) write_empty(id, 0, (long)sbx_ref_length(c_, id));
+        }
+    }
+};
+
+int depth_main(int argc, char** argv) {
+    if (argc < 3) { usage(); return 0; }
+    std::string mode = argv[1];
+    if (mode != "base" && mode != "region" && mode != "window") { usage(); return 0; }
+    Options o;
+    std::string perr;
+    if (!parse_args(argc, argv, &o, &perr)) { fprintf(stderr, "sambamba-depth: %s\n", perr.c_str()); return 1; }
+    if (o.mode == "region" && !o.has_regions) {
+        fputs("BED file or a region must be provided in region mode\n", stderr);
+        return 1;
+    }
+    Out out;
+    sbx_ctx* ctx = nullptr;
+    try {
+        if (!o.output_fn.empty()) {
+            out.fp = fopen(o.output_fn.c_str(), "w+");
+            if (!out.fp) throw Fail{"Cannot open file `" + o.output_fn + "' in mode `w+' (No such file or directory)"};
+        }
+        if (o.mode == "base") {  // PerBasePrinter.init (depth.d:412-427)
+            if (o.report_zero) o.min_cov = 0;
+        }
+        if (o.mode == "window") {
+            if (!(o.window > 0)) throw Fail{"positive window size must be specified"};
+            if (!(o.overlap < o.window)) throw Fail{"specified overlap is larger than window size"};
+        }
+        // The header line is printed by printer.init() before the BAM is opened (depth.d:1152),
+        // except in region mode where it needs the first BED line (setBed, depth.d:912-923).
+        std::vector<std::string> dummy_samples;
+        sbx_filter filt;
+        char ebuf[512] = {0};
+        int rc = sbx_compile_filter(o.has_filter ? o.filter.c_str() : nullptr, &filt, ebuf, sizeof ebuf);
+        if (rc != SBX_OK) throw Fail{ebuf};
+        if (o.bams.empty()) throw Fail{"no input files"};
+        std::vector<const char*> paths;
+        for (auto& b : o.bams) paths.push_back(b.c_str());
+        // base/window print their header before opening the file
+        if (o.mode == "base") {
+            std::string h = "REF\tPOS\tCOV\tA\tC\tG\tT\tDEL\tREFSKIP";
+            if (!o.combined) h += "\tSAMPLE";
+            if (o.annotate) h += "\tFLAG";
+            h += "\n";
+            out.put(h);
+        }
+        ctx = sbx_open(paths.data(), (int)paths.size(), -1, ebuf, sizeof ebuf);
+        if (!ctx) throw Fail{ebuf};
+        sbx_header_info hi;
+        check(ctx, sbx_header(ctx, &hi));
+        if (!hi.sorted_by_coordinate) throw Fail{"All files must be coordinate-sorted"};
+        if (!hi.has_index) throw Fail{"All files must be indexed"};
+        std::vector<std::string> samples;
+        for (int s = 0; s < hi.n_samples; ++s) samples.push_back(sbx_sample_name(ctx, s));
+        check(ctx, sbx_set_filter(ctx, &filt));
+        int mode_id = o.mode == "base" ? SBX_MODE_BASE : o.mode == "region" ? SBX_MODE_REGION : SBX_MODE_WINDOW;
+        check(ctx, sbx_set_params(ctx, mode_id, (uint8_t)o.min_bq, o.fix_mate, o.combined, (uint32_t)o.window,
+                                  (uint32_t)o.overlap, o.thresholds.data(), (int)o.thresholds.size()));
+
+        // -L (depth.d:1184-1212)
+        std::vector<sbx_region> merged, raw;
+        std::vector<std::string> raw_lines;
+        if (o.has_regions) {
+            // host-side header view for BED contig lookups
+            BamHeaderInfo hv;
+            for (int r = 0; r < hi.n_ref; ++r) hv.refs.push_back({sbx_ref_name(ctx, r), (int32_t)sbx_ref_length(ctx, r)});
+            std::vector<BedInterval> ivs;
+            std::vector<std::string> lines;
+            if (read_bed_file(o.regions, &ivs, &lines)) {
+                merged = bed_merged(ivs, hv);
+                raw = bed_raw(ivs, hv);
+                raw_lines = lines;
+            } else {
+                RegionString rs = parse_region_string(o.regions);
+                int id = sbx_ref_id(ctx, rs.reference.c_str());
+                if (id < 0) throw Fail{"couldn't open file " + o.regions + " or find reference " + rs.reference};
+                sbx_region g{(uint32_t)id, rs.beg, rs.end};
+                if (g.end == 0xFFFFFFFFu) g.end = (uint32_t)sbx_ref_length(ctx, id);
+                merged.push_back(g);
+                raw.push_back(g);
+                raw_lines = {rs.reference + "\t" + std::to_string(g.start) + "\t" + std::to_string(g.end)};
+            }
+            if (merged.empty()) throw Fail{"Enforcement failed"};
+            check(ctx, sbx_set_regions(ctx, merged.data(), merged.size()));
+        }
+        check(ctx, sbx_run(ctx));
+        if (o.mode == "base") {
+            BasePrinter p(ctx, o, out, samples);
+            if (o.has_regions) p.set_bed(merged);
+            // "Processing reference #N (name)" lines go to stderr in the reference (depth.d:1225-1229)
+            p.run();
+        } else {
+            throw Fail{"region/window printing is not available in this build"};
+        }
+        out.flush();
+        if (out.fp != stdout) fclose(out.fp);
+        sbx_close(ctx);
+        return 0;
+    } catch (const Fail& f) {
+        out.flush();
+        fprintf(stderr, "sambamba-depth: %s\n", f.msg.c_str());
+        if (ctx) sbx_close(ctx);
+        return 1;
+    } catch (const std::exception& e) {
+        out.flush();
+        fprintf(stderr, "sambamba-depth: %s\n", e.what());
+        if (ctx) sbx_close(ctx);
+        return 1;
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) { return depth_main(argc, argv); }

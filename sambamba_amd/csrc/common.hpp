@@ -1,0 +1,74 @@
+// common.hpp -- shared host-side helpers for libsbx_depth (HIP error handling, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sbx_depth.h"
+
+namespace sbx {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define SBX_HIP(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            throw ::sbx::Error(SBX_ENODEVICE, std::string("HIP error: ") + hipGetErrorString(_e) +  \
+                                                  " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+    } while (0)
+
+// RAII device allocation
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t count) { alloc(count); }
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) {
+            hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+            if (e != hipSuccess) {
+                p = nullptr; n = 0;
+                throw Error(e == hipErrorOutOfMemory ? SBX_ENOMEM : SBX_ENODEVICE,
+                            std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes failed: " + hipGetErrorString(e));
+            }
+        }
+    }
+    // grow-only (keeps the allocation when it is already large enough)
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// Device/stream bring-up; throws SBX_ENODEVICE when there is no usable GPU.
+void require_device(int device);
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventTimer() { SBX_HIP(hipEventCreate(&a)); SBX_HIP(hipEventCreate(&b)); }
+    ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    void start(hipStream_t s) { SBX_HIP(hipEventRecord(a, s)); }
+    void stop(hipStream_t s) { SBX_HIP(hipEventRecord(b, s)); }
+    double ms() { float f = 0; SBX_HIP(hipEventSynchronize(b)); SBX_HIP(hipEventElapsedTime(&f, a, b)); return (double)f; }
+};
+
+}  // namespace sbx

@@ -1,0 +1,184 @@
+// depth.hip -- K3 `decode_accumulate`: per-position coverage counters from BAM records.
+//
+// Replaces the hot loop of `sambamba depth`: PileupRange.popFront / PileupRead.incrementPosition
+// (BioD/bio/std/hts/bam/pileup.d:195-222,345-397), which advances every active read by one
+// reference base per column, and PerBasePrinter.writeColumn's per-read classification
+// (sambamba/depth.d:506-518,522-532).  Per SURVEY.md F5 / Appendix A the per-position output
+// of that sweep line is a pure histogram over reads:
+//     cnt[pos][sample][code] += 1  for every M/=/X base with qual >= min_bq,
+//                                  code = Base5(base): A0 C1 G2 T3, everything else 4
+//                                  (bio/core/base.d:85,163-186; 4-bit nibble, high nibble first,
+//                                  read.d:364-383),
+//     cnt[pos][sample][5]   += 1  for every position inside a D operation,
+//     cnt[pos][sample][6]   += 1  for every position inside an N operation,
+// so the GPU formulation is a scatter of read bases into position tiles:
+//   * one workgroup owns one tile of T reference positions; its counters live in LDS
+//     (T x n_samples x 7 u32, 56 KiB => 2 workgroups per CU) and are written to HBM exactly
+//     once with coalesced stores -- no global atomics, no zero-fill pass over HBM;
+//   * the records of a tile are a contiguous range [lo,hi) of the descriptor array (K2);
+//     each wavefront pulls 64 descriptors with one coalesced load, ballots the ones that
+//     overlap the tile, and spreads the bases of each such read across its 64 lanes
+//     (consecutive lanes -> consecutive quality bytes and consecutive LDS counters at a
+//     7-dword stride, which is conflict-free across 32 banks);
+//   * reads straddling a tile edge are visited by both tiles and clipped.
+// Roofline: HBM.  Algorithmic bytes per read = record bytes + 28 B per covered position
+// per sample written once.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace sbx {
+
+namespace {
+
+constexpr int kAccThreads = 256;
+constexpr uint32_t kCigarType = 0x3C1A7u;   // cigar.d:116
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// Base5 internal code of a BAM 4-bit base code ("=ACMGRSVTWYHKDBN" -> A0 C1 G2 T3 else 4)
+__device__ __forceinline__ uint32_t base5_of_nibble(uint32_t nib) {
+    // 16 x 3-bit LUT packed into 48 bits
+    const uint64_t lut = (4ULL << 0) | (0ULL << 3) | (1ULL << 6) | (4ULL << 9) | (2ULL << 12) | (4ULL << 15) |
+                         (4ULL << 18) | (4ULL << 21) | (3ULL << 24) | (4ULL << 27) | (4ULL << 30) | (4ULL << 33) |
+                         (4ULL << 36) | (4ULL << 39) | (4ULL << 42) | (4ULL << 45);
+    return (uint32_t)(lut >> (nib * 3)) & 7u;
+}
+
+template <bool kSpan>
+__global__ __launch_bounds__(kAccThreads) void k_accumulate(
+    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
+    const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, const uint32_t* __restrict__ tile_base,
+    int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq, uint32_t* __restrict__ counters,
+    uint32_t* __restrict__ span_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* cnt = lds;                       // [T][S][7]
+    uint32_t* spn = lds + (size_t)T * S * 7;   // [T] (only when kSpan)
+    const uint32_t tile = active[blockIdx.x];
+    const uint32_t n_cnt = T * S * 7;
+    for (uint32_t i = threadIdx.x; i < n_cnt + (kSpan ? T : 0u); i += kAccThreads) lds[i] = 0;
+
+    // which contig does this tile belong to?  (binary search in tile_base[0..n_ref])
+    int lo_r = 0, hi_r = n_ref;   // invariant: tile_base[lo_r] <= tile < tile_base[hi_r]
+    while (hi_r - lo_r > 1) {
+        int mid = (lo_r + hi_r) >> 1;
+        if (tile_base[mid] <= tile) lo_r = mid; else hi_r = mid;
+    }
+    const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T);   // first position of the tile in its contig
+    const int32_t te = ts + (int32_t)T;
+    const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t c = r_lo + wave * 64u; c < r_hi; c += (kAccThreads / 64) * 64u) {
+        const uint32_t ri = c + lane;
+        RecDesc d;
+        d.kind = 0;
+        d.pos = 0; d.end = 0; d.rec_off = 0; d.l_seq = 0; d.n_cigar = 0; d.l_name = 0; d.q_start = 0; d.sample = 0;
+        if (ri < r_hi) d = desc[ri];
+        const bool take = d.kind != 0 && d.pos < te && d.end > ts;
+        uint64_t mask = __ballot(take);
+        while (mask) {
+            const int r = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            // wave-uniform copies of record r
+            const uint32_t off_lo = __builtin_amdgcn_readlane((uint32_t)d.rec_off, r);
+            const uint32_t off_hi = __builtin_amdgcn_readlane((uint32_t)(d.rec_off >> 32), r);
+            const int32_t pos = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.pos, r);
+            const int32_t end = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.end, r);
+            const uint32_t l_seq = __builtin_amdgcn_readlane(d.l_seq, r);
+            const uint32_t misc = __builtin_amdgcn_readlane((uint32_t)d.n_cigar | ((uint32_t)d.l_name << 16) | ((uint32_t)d.kind << 24), r);
+            const uint32_t misc2 = __builtin_amdgcn_readlane((uint32_t)d.q_start | ((uint32_t)d.sample << 16), r);
+            const uint32_t n_cigar = misc & 0xFFFFu, l_name = (misc >> 16) & 0xFFu, kind = misc >> 24;
+            const uint32_t q_start = misc2 & 0xFFFFu, sample = (S > 1) ? (misc2 >> 16) : 0u;
+            const uint8_t* rec = U + (((uint64_t)off_hi << 32) | off_lo);
+            const uint8_t* cig = rec + 36 + l_name;
+            const uint8_t* seq = cig + 4 * n_cigar;
+            const uint8_t* qual = seq + ((l_seq + 1) >> 1);
+            uint32_t* cbase = cnt + sample * 7;
+
+            // one run of aligned bases [rp, rp+len) <-> query [qp, qp+len)
+            auto match_run = [&](int32_t rp, uint32_t qp, uint32_t len) {
+                int32_t i0 = ts > rp ? ts - rp : 0;
+                int32_t i1 = (int32_t)len < te - rp ? (int32_t)len : te - rp;
+                for (int32_t i = i0 + (int32_t)lane; i < i1; i += 64) {
+                    uint32_t q = qp + (uint32_t)i;
+                    if (q < l_seq) {
+                        uint32_t sb = seq[q >> 1];
+                        uint32_t nib = (q & 1u) ? (sb & 15u) : (sb >> 4);
+                        uint32_t ql = qual[q];
+                        uint32_t p = (uint32_t)(rp + i - ts);
+                        if (ql >= min_bq) atomicAdd(&cbase[p * S * 7 + base5_of_nibble(nib)], 1u);
+                    }
+                }
+            };
+            auto gap_run = [&](int32_t rp, uint32_t len, uint32_t code) {
+                int32_t i0 = ts > rp ? ts - rp : 0;
+                int64_t room = (int64_t)te - rp;
+                int32_t i1 = (int64_t)len < room ? (int32_t)len : (int32_t)(room < 0 ? 0 : room);
+                for (int32_t i = i0 + (int32_t)lane; i < i1; i += 64) {
+                    uint32_t p = (uint32_t)(rp + i - ts);
+                    atomicAdd(&cbase[p * S * 7 + code], 1u);
+                }
+            };
+            if (kSpan) {
+                int32_t a = pos > ts ? pos : ts, b2 = end < te ? end : te;
+                for (int32_t p = a + (int32_t)lane; p < b2; p += 64) atomicAdd(&spn[p - ts], 1u);
+            }
+            if (kind == 1) {
+                match_run(pos, q_start, (uint32_t)(end - pos));
+            } else {
+                int32_t rp = pos;
+                uint32_t qp = 0;
+                for (uint32_t k = 0; k < n_cigar; ++k) {
+                    uint32_t op = ld32u(cig + 4 * k);
+                    uint32_t ty = (kCigarType >> ((op & 15u) * 2u)) & 3u, len = op >> 4;
+                    if (ty == 3) {
+                        match_run(rp, qp, len);
+                        rp += (int32_t)len;
+                        qp += len;
+                    } else if (ty == 2) {
+                        gap_run(rp, len, (op & 15u) == 2u ? 5u : 6u);   // D -> DEL, otherwise (N) -> REFSKIP
+                        rp += (int32_t)len;
+                    } else if (ty == 1) {
+                        qp += len;
+                    }
+                    if (rp >= te) break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // write the tile once, coalesced
+    uint32_t* out = counters + (size_t)blockIdx.x * n_cnt;
+    for (uint32_t i = threadIdx.x; i < n_cnt; i += kAccThreads) out[i] = cnt[i];
+    if (kSpan) {
+        uint32_t* so = span_out + (size_t)blockIdx.x * T;
+        for (uint32_t i = threadIdx.x; i < T; i += kAccThreads) so[i] = spn[i];
+    }
+}
+
+}  // namespace
+
+void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_tile_lo, const uint32_t* d_tile_hi,
+                       const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base, int32_t n_ref,
+                       uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
+                       hipStream_t stream) {
+    if (!n_active) return;
+    size_t lds = (size_t)tile_pos * n_samples * 7 * 4 + (d_span ? (size_t)tile_pos * 4 : 0);
+    if (d_span) {
+        SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_accumulate<true>, dim3(n_active), dim3(kAccThreads), lds, stream, d_U, d_desc, d_tile_lo,
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+    } else {
+        SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_accumulate<false>, dim3(n_active), dim3(kAccThreads), lds, stream, d_U, d_desc, d_tile_lo,
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+    }
+    SBX_HIP(hipGetLastError());
+}
+
+}  // namespace sbx

@@ -1,0 +1,578 @@
+// engine.cpp -- the C ABI of libsbx_depth.so (include/sbx_depth.h) and the device pipeline
+//   compressed BAM in HBM -> K1 inflate -> K2 record index -> K3 decode+accumulate -> counters in HBM.
+// Host code here is orchestration only; every byte of BGZF payload, every record and every
+// counter is produced on the device.  There is no CPU fallback: without a HIP device the compute
+// entry points fail with SBX_ENODEVICE.
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+
+#include "common.hpp"
+#include "host_io.hpp"
+#include "kernels.hpp"
+
+namespace sbx {
+
+void require_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        throw Error(SBX_ENODEVICE, std::string("no HIP device available (libsbx_depth has no CPU fallback): ") +
+                                       (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        device = lr ? atoi(lr) % n : 0;
+    }
+    if (device >= n) throw Error(SBX_ENODEVICE, "HIP device ordinal " + std::to_string(device) + " out of range");
+    SBX_HIP(hipSetDevice(device));
+}
+
+static uint32_t floor_pow2(uint32_t x) {
+    uint32_t p = 1;
+    while (p * 2 <= x) p *= 2;
+    return p;
+}
+
+}  // namespace sbx
+
+using namespace sbx;
+
+struct sbx_ctx {
+    std::string last_error;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    FileMap file;
+    BlockTable blocks;
+    BamHeaderInfo hdr;
+    BaiIndex bai;
+    bool has_index = false;
+
+    // parameters
+    int mode = SBX_MODE_BASE;
+    uint32_t min_bq = 0;
+    bool fix_mate = false, combined = false;
+    uint32_t window = 0, overlap = 0;
+    std::vector<uint32_t> thresholds;
+    sbx_filter filter;
+    std::vector<sbx_region> regions;
+
+    // device state
+    bool comp_resident = false;
+    DevBuf<uint8_t> d_comp;
+    DevBuf<uint64_t> d_comp_off, d_out_off;
+    DevBuf<uint32_t> d_comp_len, d_isize, d_status;
+    DevBuf<uint8_t> d_U, d_scratch;
+    DevBuf<uint64_t> d_entry, d_exit, d_base;
+    DevBuf<uint32_t> d_count, d_flag;
+    DevBuf<RecDesc> d_desc;
+    DevBuf<int32_t> d_ref_len;
+    DevBuf<uint32_t> d_tile_base, d_tile_lo, d_tile_hi, d_active, d_slot_of, d_n_active;
+    DevBuf<uint32_t> d_counters, d_span;
+    DevBuf<DeviceFilter> d_filter;
+    DevBuf<char> d_rg_ids;
+    DevBuf<uint32_t> d_rg_off;
+    DevBuf<uint16_t> d_rg_sample;
+    DevBuf<IndexStats> d_stats;
+    bool tables_uploaded = false;
+
+    // results of the last run
+    bool have_run = false;
+    uint32_t tile_pos = 0, n_samples_eff = 1, n_tiles = 0, n_active = 0;
+    bool span_valid = false;
+    std::vector<uint32_t> h_tile_base, h_slot_of;
+    sbx_run_stats stats{};
+};
+
+namespace {
+
+template <class F>
+int guarded(sbx_ctx* c, F&& f) {
+    try {
+        f();
+        return SBX_OK;
+    } catch (const Error& e) {
+        if (c) c->last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        if (c) c->last_error = e.what();
+        return SBX_EINVAL;
+    }
+}
+
+void set_err(char* err, size_t n, const std::string& m) {
+    if (err && n) snprintf(err, n, "%s", m.c_str());
+}
+
+void upload_tables(sbx_ctx* c) {
+    if (c->tables_uploaded) return;
+    size_t n = c->blocks.size();
+    c->d_comp_off.alloc(n + 1);
+    c->d_comp_len.alloc(n + 1);
+    c->d_isize.alloc(n + 1);
+    c->d_out_off.alloc(n + 1);
+    if (n) {
+        SBX_HIP(hipMemcpy(c->d_comp_off.p, c->blocks.comp_off.data(), n * 8, hipMemcpyHostToDevice));
+        SBX_HIP(hipMemcpy(c->d_comp_len.p, c->blocks.comp_len.data(), n * 4, hipMemcpyHostToDevice));
+        SBX_HIP(hipMemcpy(c->d_isize.p, c->blocks.isize.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    SBX_HIP(hipMemcpy(c->d_out_off.p, c->blocks.out_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    c->tables_uploaded = true;
+}
+
+void upload_file(sbx_ctx* c) {
+    if (c->comp_resident) return;
+    EventTimer t;
+    t.start(c->stream);
+    c->d_comp.alloc(c->file.size + 64);
+    SBX_HIP(hipMemsetAsync(c->d_comp.p + c->file.size, 0, 64, c->stream));
+    if (c->file.size) SBX_HIP(hipMemcpyAsync(c->d_comp.p, c->file.data, c->file.size, hipMemcpyHostToDevice, c->stream));
+    t.stop(c->stream);
+    c->stats.ms_h2d = t.ms();
+    c->comp_resident = true;
+}
+
+// inflate blocks [b0,b1) into d_U (which is laid out for the whole file) and check their status
+void inflate_blocks(sbx_ctx* c, uint32_t b0, uint32_t b1) {
+    if (b1 <= b0) return;
+    uint32_t n = b1 - b0;
+    c->d_status.ensure(c->blocks.size() + 1);
+    c->d_scratch.ensure(inflate_scratch_bytes((uint32_t)c->blocks.size()));
+    launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p + b0, c->d_comp_len.p + b0, c->d_isize.p + b0, c->d_out_off.p + b0,
+                        c->d_U.p, n, c->d_scratch.p, c->d_status.p + b0, c->stream);
+}
+
+void check_inflate_status(sbx_ctx* c, uint32_t b0, uint32_t b1) {
+    if (b1 <= b0) return;
+    std::vector<uint32_t> st(b1 - b0);
+    SBX_HIP(hipMemcpyAsync(st.data(), c->d_status.p + b0, st.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    SBX_HIP(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < st.size(); ++i)
+        if (st[i] != 0)
+            throw Error(SBX_EFORMAT, "Error inflating BGZF block starting from offset " +
+                                         std::to_string(c->blocks.coffset[b0 + i]) + ": " + inflate_status_string(st[i]));
+}
+
+void parse_header_on_device(sbx_ctx* c) {
+    uint64_t total = c->blocks.out_off.back();
+    if (total < 12) throw Error(SBX_EFORMAT, "BAM header is truncated");
+    upload_tables(c);
+    upload_file(c);
+    c->d_U.ensure(total + 64);
+    uint32_t nb = (uint32_t)c->blocks.size();
+    uint32_t k = std::min<uint32_t>(nb, 4);
+    std::vector<uint8_t> host;
+    for (;;) {
+        inflate_blocks(c, 0, k);
+        check_inflate_status(c, 0, k);
+        uint64_t have = c->blocks.out_off[k];
+        host.resize(have);
+        SBX_HIP(hipMemcpy(host.data(), c->d_U.p, have, hipMemcpyDeviceToHost));
+        if (parse_bam_header(host.data(), have, total, &c->hdr)) break;
+        if (k == nb) throw Error(SBX_EFORMAT, "BAM header is truncated");
+        k = std::min<uint32_t>(nb, k * 4);
+    }
+}
+
+void default_filter(sbx_filter* f) {
+    FilterCompiler fc("mapping_quality > 0 and not duplicate and not failed_quality_control", f);  // depth.d:1159
+    fc.compile();
+}
+
+}  // namespace
+
+extern "C" {
+
+int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len, const uint32_t* isize,
+                       uint32_t n_blocks, uint8_t* out, const uint64_t* out_off, char* err, size_t errlen) {
+    try {
+        require_device(-1);
+        if (n_blocks == 0) return SBX_OK;
+        uint64_t in_end = 0, out_end = 0;
+        for (uint32_t i = 0; i < n_blocks; ++i) {
+            in_end = std::max(in_end, comp_off[i] + comp_len[i]);
+            out_end = std::max(out_end, out_off[i] + isize[i]);
+        }
+        DevBuf<uint8_t> d_in(in_end + 64), d_out(out_end + 64), d_scr(inflate_scratch_bytes(n_blocks));
+        DevBuf<uint64_t> d_coff(n_blocks), d_ooff(n_blocks);
+        DevBuf<uint32_t> d_clen(n_blocks), d_isz(n_blocks), d_st(n_blocks);
+        SBX_HIP(hipMemset(d_in.p + in_end, 0, 64));
+        SBX_HIP(hipMemcpy(d_in.p, comp, in_end, hipMemcpyHostToDevice));
+        SBX_HIP(hipMemcpy(d_coff.p, comp_off, n_blocks * 8ull, hipMemcpyHostToDevice));
+        SBX_HIP(hipMemcpy(d_ooff.p, out_off, n_blocks * 8ull, hipMemcpyHostToDevice));
+        SBX_HIP(hipMemcpy(d_clen.p, comp_len, n_blocks * 4ull, hipMemcpyHostToDevice));
+        SBX_HIP(hipMemcpy(d_isz.p, isize, n_blocks * 4ull, hipMemcpyHostToDevice));
+        launch_bgzf_inflate(d_in.p, d_coff.p, d_clen.p, d_isz.p, d_ooff.p, d_out.p, n_blocks, d_scr.p, d_st.p, nullptr);
+        std::vector<uint32_t> st(n_blocks);
+        SBX_HIP(hipMemcpy(st.data(), d_st.p, n_blocks * 4ull, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_blocks; ++i)
+            if (st[i]) throw Error(SBX_EFORMAT, "block " + std::to_string(i) + ": " + inflate_status_string(st[i]));
+        // copy out exactly the produced ranges (blocks may be sparse in `out`)
+        for (uint32_t i = 0; i < n_blocks; ++i)
+            if (isize[i]) SBX_HIP(hipMemcpy(out + out_off[i], d_out.p + out_off[i], isize[i], hipMemcpyDeviceToHost));
+        return SBX_OK;
+    } catch (const Error& e) {
+        set_err(err, errlen, e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, e.what());
+        return SBX_EINVAL;
+    }
+}
+
+sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* err, size_t errlen) {
+    std::unique_ptr<sbx_ctx> c(new sbx_ctx());
+    try {
+        if (n_bams != 1 || !bam_paths || !bam_paths[0])
+            throw Error(SBX_EUNSUPPORTED, "exactly one BAM file is supported in this version (multi-BAM merge: SURVEY 8f-2)");
+        require_device(device);
+        SBX_HIP(hipGetDevice(&c->device));
+        SBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->file.open(bam_paths[0]);
+        c->blocks = scan_bgzf(c->file.data, c->file.size);
+        c->has_index = load_bai(c->file.path, &c->bai);
+        default_filter(&c->filter);
+        parse_header_on_device(c.get());
+        return c.release();
+    } catch (const std::exception& e) {
+        set_err(err, errlen, e.what());
+        if (c && c->stream) (void)hipStreamDestroy(c->stream);
+        return nullptr;
+    }
+}
+
+void sbx_close(sbx_ctx* c) {
+    if (!c) return;
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    delete c;
+}
+
+const char* sbx_last_error(sbx_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
+
+int sbx_header(sbx_ctx* c, sbx_header_info* out) {
+    if (!c || !out) return SBX_EINVAL;
+    out->n_ref = (int32_t)c->hdr.refs.size();
+    out->n_samples = (int32_t)c->hdr.sample_names.size();
+    out->n_read_groups = (int32_t)c->hdr.read_groups.size();
+    out->sorted_by_coordinate = c->hdr.sorting_order == "coordinate";
+    out->has_index = c->has_index ? 1 : 0;
+    out->reserved = 0;
+    out->n_bgzf_blocks = c->blocks.size();
+    out->compressed_bytes = c->file.size;
+    out->uncompressed_bytes = c->blocks.out_off.back();
+    return SBX_OK;
+}
+const char* sbx_ref_name(sbx_ctx* c, int r) { return (c && r >= 0 && (size_t)r < c->hdr.refs.size()) ? c->hdr.refs[(size_t)r].name.c_str() : nullptr; }
+int64_t sbx_ref_length(sbx_ctx* c, int r) { return (c && r >= 0 && (size_t)r < c->hdr.refs.size()) ? c->hdr.refs[(size_t)r].length : -1; }
+int sbx_ref_id(sbx_ctx* c, const char* name) { return (c && name) ? c->hdr.find_ref(name) : -1; }
+const char* sbx_sample_name(sbx_ctx* c, int s) { return (c && s >= 0 && (size_t)s < c->hdr.sample_names.size()) ? c->hdr.sample_names[(size_t)s].c_str() : nullptr; }
+const char* sbx_header_text(sbx_ctx* c, size_t* len) {
+    if (!c) return nullptr;
+    if (len) *len = c->hdr.text.size();
+    return c->hdr.text.c_str();
+}
+
+int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t errlen) {
+    if (!out) return SBX_EINVAL;
+    try {
+        memset(out, 0, sizeof *out);
+        if (!query) default_filter(out);
+        else { FilterCompiler fc(query, out); fc.compile(); }
+        return SBX_OK;
+    } catch (const Error& e) {
+        set_err(err, errlen, e.what());
+        return e.code;
+    }
+}
+
+int sbx_set_filter(sbx_ctx* c, const sbx_filter* f) {
+    if (!c || !f || f->n_ops < 0 || f->n_ops > SBX_FILTER_MAX_OPS) return SBX_EINVAL;
+    c->filter = *f;
+    c->have_run = false;
+    return SBX_OK;
+}
+
+int sbx_set_params(sbx_ctx* c, int mode, uint8_t min_bq, int fix_mate, int combined, uint32_t window, uint32_t overlap,
+                   const uint32_t* thr, int n_thr) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        if (mode < 0 || mode > 2) throw Error(SBX_EINVAL, "unknown mode");
+        if (mode == SBX_MODE_WINDOW) {
+            if (window == 0) throw Error(SBX_EINVAL, "positive window size must be specified");        // depth.d:1020-1021
+            if (overlap >= window) throw Error(SBX_EINVAL, "specified overlap is larger than window size");  // depth.d:1023-1024
+        }
+        c->mode = mode;
+        c->min_bq = min_bq;
+        c->fix_mate = fix_mate != 0;
+        c->combined = combined != 0;
+        c->window = window;
+        c->overlap = overlap;
+        c->thresholds.assign(thr, thr + (n_thr > 0 ? n_thr : 0));
+        c->have_run = false;
+    });
+}
+
+int sbx_set_regions(sbx_ctx* c, const sbx_region* r, size_t n) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        for (size_t i = 0; i < n; ++i) {
+            if (r[i].ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
+            if (!(r[i].start < r[i].end)) throw Error(SBX_EINVAL, "Enforcement failed");   // randomaccessmanager.d:256
+        }
+        c->regions.assign(r, r + n);
+        c->have_run = false;
+    });
+}
+
+int sbx_preload(sbx_ctx* c) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        SBX_HIP(hipSetDevice(c->device));
+        upload_tables(c);
+        upload_file(c);
+        SBX_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int sbx_run(sbx_ctx* c) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
+        if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
+        if (c->fix_mate) throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps is not on the device path yet");
+        SBX_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        c->have_run = false;
+        double ms_h2d = c->stats.ms_h2d;
+        c->stats = sbx_run_stats{};
+        upload_tables(c);
+        upload_file(c);
+        if (c->stats.ms_h2d == 0) c->stats.ms_h2d = ms_h2d;
+        const uint32_t nb = (uint32_t)c->blocks.size();
+        const uint64_t total = c->blocks.out_off.back();
+        EventTimer t_all, t1, t2, t3;
+        t_all.start(s);
+
+        // ---- K1 ----
+        c->d_U.ensure(total + 64);
+        t1.start(s);
+        inflate_blocks(c, 0, nb);
+        t1.stop(s);
+        check_inflate_status(c, 0, nb);
+
+        // ---- K2 ----
+        const int32_t n_ref = (int32_t)c->hdr.refs.size();
+        const uint32_t S = c->combined ? 1u : (uint32_t)c->hdr.sample_names.size();
+        const uint32_t T = std::max<uint32_t>(16, floor_pow2(std::max<uint32_t>(1, 2048u / std::max<uint32_t>(1, S))));
+        std::vector<int32_t> ref_len((size_t)n_ref);
+        std::vector<uint32_t> tile_base((size_t)n_ref + 1);
+        uint64_t nt = 0;
+        for (int32_t r = 0; r < n_ref; ++r) {
+            ref_len[(size_t)r] = c->hdr.refs[(size_t)r].length;
+            tile_base[(size_t)r] = (uint32_t)nt;
+            // one spare tile per contig for alignments hanging over the contig end
+            nt += ((uint64_t)std::max(0, c->hdr.refs[(size_t)r].length) + T - 1) / T + 1;
+            if (nt > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "too many position tiles");
+        }
+        tile_base[(size_t)n_ref] = (uint32_t)nt;
+        c->d_ref_len.ensure((size_t)n_ref + 1);
+        c->d_tile_base.ensure((size_t)n_ref + 1);
+        if (n_ref) SBX_HIP(hipMemcpyAsync(c->d_ref_len.p, ref_len.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_tile_base.p, tile_base.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+        RefTable refs{c->d_ref_len.p, c->d_tile_base.p, n_ref};
+
+        c->d_entry.ensure(nb + 1);
+        c->d_exit.ensure(nb + 1);
+        c->d_count.ensure(nb + 1);
+        c->d_base.ensure(nb + 2);
+        c->d_flag.ensure(4);
+        t2.start(s);
+        launch_block_walk(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, refs, c->d_entry.p,
+                          c->d_exit.p, c->d_count.p, s);
+        for (uint32_t iter = 0;; ++iter) {
+            SBX_HIP(hipMemsetAsync(c->d_flag.p, 0, 4, s));
+            launch_chain_verify(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, c->d_entry.p,
+                                c->d_exit.p, c->d_count.p, c->d_flag.p, s);
+            uint32_t changed = 0;
+            SBX_HIP(hipMemcpyAsync(&changed, c->d_flag.p, 4, hipMemcpyDeviceToHost, s));
+            SBX_HIP(hipStreamSynchronize(s));
+            if (!changed) break;
+            if (iter > nb + 2) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
+        }
+        if (nb) {
+            // the chain must end exactly at the end of the stream
+            uint64_t last_exit = 0;
+            SBX_HIP(hipMemcpy(&last_exit, c->d_exit.p + (nb - 1), 8, hipMemcpyDeviceToHost));
+            if (last_exit != total) throw Error(SBX_EFORMAT, "BAM record chain is broken (truncated or corrupt record)");
+        }
+        launch_count_scan(c->d_count.p, nb, c->d_base.p, nullptr, 0, s);
+        uint64_t n_records = 0;
+        SBX_HIP(hipMemcpyAsync(&n_records, c->d_base.p + nb, 8, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+        if (n_records > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "more than 2^32 records in one batch");
+        c->d_desc.ensure((size_t)n_records + 64);
+        c->d_tile_lo.ensure((size_t)nt + 1);
+        c->d_tile_hi.ensure((size_t)nt + 1);
+        c->d_active.ensure((size_t)nt + 1);
+        c->d_slot_of.ensure((size_t)nt + 1);
+        c->d_n_active.ensure(4);
+        SBX_HIP(hipMemsetAsync(c->d_tile_lo.p, 0xFF, (size_t)nt * 4, s));
+        SBX_HIP(hipMemsetAsync(c->d_tile_hi.p, 0, (size_t)nt * 4, s));
+        // filter + read groups
+        c->d_filter.ensure(1);
+        DeviceFilter df;
+        memset(&df, 0, sizeof df);
+        df.n_ops = c->filter.n_ops;
+        memcpy(df.ops, c->filter.ops, sizeof(sbx_filter_op) * (size_t)c->filter.n_ops);
+        SBX_HIP(hipMemcpyAsync(c->d_filter.p, &df, sizeof df, hipMemcpyHostToDevice, s));
+        RgTable rg{nullptr, nullptr, nullptr, 0, 0};
+        std::string ids;
+        std::vector<uint32_t> id_off;
+        if (!c->hdr.read_groups.empty()) {
+            for (auto& g : c->hdr.read_groups) { id_off.push_back((uint32_t)ids.size()); ids += g.id; ids.push_back('\0'); }
+            c->d_rg_ids.ensure(ids.size());
+            c->d_rg_off.ensure(id_off.size());
+            c->d_rg_sample.ensure(id_off.size());
+            SBX_HIP(hipMemcpyAsync(c->d_rg_ids.p, ids.data(), ids.size(), hipMemcpyHostToDevice, s));
+            SBX_HIP(hipMemcpyAsync(c->d_rg_off.p, id_off.data(), id_off.size() * 4, hipMemcpyHostToDevice, s));
+            SBX_HIP(hipMemcpyAsync(c->d_rg_sample.p, c->hdr.rg_sample.data(), id_off.size() * 2, hipMemcpyHostToDevice, s));
+            rg = RgTable{c->d_rg_ids.p, c->d_rg_off.p, c->d_rg_sample.p, (int32_t)id_off.size(), 1};
+        }
+        c->d_stats.ensure(1);
+        SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
+        launch_describe(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
+                        T, c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_stats.p, s);
+        launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
+        t2.stop(s);
+        uint32_t n_active = 0;
+        IndexStats ist{};
+        SBX_HIP(hipMemcpyAsync(&n_active, c->d_n_active.p, 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(&ist, c->d_stats.p, sizeof ist, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+        if (ist.n_unknown_rg)
+            throw Error(SBX_ERG, "error in read: read group is not present in the header (" + std::to_string(ist.n_unknown_rg) + " reads)");
+
+        // ---- K3 ----
+        const bool want_span = c->min_bq > 0;
+        size_t per_tile = (size_t)T * S * SBX_NCOUNTERS;
+        c->d_counters.ensure((size_t)n_active * per_tile + 4);
+        if (want_span) c->d_span.ensure((size_t)n_active * T + 4);
+        t3.start(s);
+        launch_accumulate(c->d_U.p, c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, c->d_tile_base.p,
+                          n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+        t3.stop(s);
+        t_all.stop(s);
+        c->h_slot_of.resize((size_t)nt);
+        if (nt) SBX_HIP(hipMemcpyAsync(c->h_slot_of.data(), c->d_slot_of.p, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+
+        c->h_tile_base = tile_base;
+        c->tile_pos = T;
+        c->n_samples_eff = S;
+        c->n_tiles = (uint32_t)nt;
+        c->n_active = n_active;
+        c->span_valid = want_span;
+        c->stats.ms_inflate = t1.ms();
+        c->stats.ms_index = t2.ms();
+        c->stats.ms_accumulate = t3.ms();
+        c->stats.ms_total = t_all.ms();
+        c->stats.n_records = ist.n_records;
+        c->stats.n_admitted = ist.n_admitted;
+        c->stats.n_bgzf_blocks = nb;
+        c->stats.compressed_bytes = c->file.size;
+        c->stats.uncompressed_bytes = total;
+        c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4;
+        c->stats.covered_positions = (uint64_t)n_active * T;
+        c->stats.launches_inflate = 1;
+        c->stats.launches_index = 5;
+        c->stats.launches_accumulate = 1;
+        c->have_run = true;
+    });
+}
+
+int sbx_last_run_stats(sbx_ctx* c, sbx_run_stats* out) {
+    if (!c || !out) return SBX_EINVAL;
+    *out = c->stats;
+    return SBX_OK;
+}
+
+int sbx_depth_base_tile(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, uint32_t* counters, uint8_t* covered) {
+    return guarded(c, [&] {
+        if (!c || !counters) throw Error(SBX_EINVAL, "null argument");
+        if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
+        if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
+        SBX_HIP(hipSetDevice(c->device));
+        const uint32_t T = c->tile_pos, S = c->n_samples_eff;
+        const size_t row = (size_t)S * SBX_NCOUNTERS;
+        const uint32_t t_first = c->h_tile_base[ref_id], t_end = c->h_tile_base[ref_id + 1];
+        memset(counters, 0, (size_t)(end - beg) * row * 4);
+        if (covered) memset(covered, 0, (size_t)(end - beg));
+        std::vector<uint32_t> spn;
+        for (uint64_t p = beg; p < end;) {
+            uint32_t t = t_first + (uint32_t)(p / T);
+            uint64_t tile_start = (uint64_t)(t - t_first) * T;
+            if (t >= t_end || c->h_slot_of[t] == 0xFFFFFFFFu) { p = std::min<uint64_t>(end, tile_start + T); continue; }
+            // a run of consecutive active tiles occupies consecutive slots: one copy for the whole run
+            uint32_t t2 = t + 1;
+            while (t2 < t_end && (uint64_t)(t2 - t_first) * T < end && c->h_slot_of[t2] == c->h_slot_of[t] + (t2 - t)) ++t2;
+            uint64_t stop = std::min<uint64_t>(end, (uint64_t)(t2 - t_first) * T);
+            size_t slot = c->h_slot_of[t];
+            uint32_t* dst = counters + (size_t)(p - beg) * row;
+            SBX_HIP(hipMemcpy(dst, c->d_counters.p + slot * T * row + (size_t)(p - tile_start) * row, (size_t)(stop - p) * row * 4,
+                              hipMemcpyDeviceToHost));
+            if (covered) {
+                if (c->span_valid) {
+                    spn.resize((size_t)(stop - p));
+                    SBX_HIP(hipMemcpy(spn.data(), c->d_span.p + slot * T + (size_t)(p - tile_start), (size_t)(stop - p) * 4,
+                                      hipMemcpyDeviceToHost));
+                    for (uint64_t q = p; q < stop; ++q) covered[q - beg] = spn[(size_t)(q - p)] ? 1 : 0;
+                } else {
+                    for (uint64_t q = p; q < stop; ++q) {
+                        const uint32_t* r = counters + (size_t)(q - beg) * row;
+                        uint32_t any = 0;
+                        for (size_t k = 0; k < row; ++k) any |= r[k];
+                        covered[q - beg] = any ? 1 : 0;
+                    }
+                }
+            }
+            p = stop;
+        }
+    });
+}
+
+int sbx_depth_region_stats(sbx_ctx* c, const sbx_region*, size_t, sbx_region_stats*, uint32_t*, uint8_t*) {
+    if (c) c->last_error = "region mode is not on the device path yet";
+    return SBX_EUNSUPPORTED;
+}
+int sbx_depth_window_stats(sbx_ctx* c, uint32_t, uint64_t, uint64_t, sbx_region_stats*, uint32_t*) {
+    if (c) c->last_error = "window mode is not on the device path yet";
+    return SBX_EUNSUPPORTED;
+}
+int sbx_format_base_rows(sbx_ctx* c, uint32_t, uint32_t, uint32_t, double, double, int, char*, size_t, size_t*) {
+    if (c) c->last_error = "device-side row formatting is not implemented yet";
+    return SBX_EUNSUPPORTED;
+}
+
+// extent of the tile grid of a contig (positions) and activity of a tile -- used by the CLI to skip
+// empty stretches without copying zeros.
+int sbx_tile_info(sbx_ctx* c, uint32_t* tile_pos, uint32_t* n_samples) {
+    if (!c || !c->have_run) return SBX_EINVAL;
+    if (tile_pos) *tile_pos = c->tile_pos;
+    if (n_samples) *n_samples = c->n_samples_eff;
+    return SBX_OK;
+}
+// next active tile of ref_id at or after position `from`; returns its [beg,end) or beg==end==UINT32_MAX
+int sbx_next_active_range(sbx_ctx* c, uint32_t ref_id, uint64_t from, uint64_t* beg, uint64_t* end) {
+    if (!c || !c->have_run || ref_id >= c->hdr.refs.size() || !beg || !end) return SBX_EINVAL;
+    const uint32_t T = c->tile_pos;
+    const uint32_t t_first = c->h_tile_base[ref_id], t_end = c->h_tile_base[ref_id + 1];
+    uint64_t t = t_first + from / T;
+    while (t < t_end && c->h_slot_of[(size_t)t] == 0xFFFFFFFFu) ++t;
+    if (t >= t_end) { *beg = *end = ~0ULL; return SBX_OK; }
+    uint64_t t2 = t;
+    while (t2 < t_end && c->h_slot_of[(size_t)t2] != 0xFFFFFFFFu) ++t2;
+    *beg = std::max<uint64_t>(from, (t - t_first) * (uint64_t)T);
+    *end = (t2 - t_first) * (uint64_t)T;
+    return SBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,477 @@
+// index.hip -- K2 `record_index`: find every BAM record in the inflated stream and describe it.
+//
+// Replaces, for the whole file at once, the serial loop of BamReadRange.readNext
+// (BioD/bio/std/hts/bam/readrange.d:118-173: read int32 block_size, slice block_size bytes),
+// the BamRead field accessors (read.d:907-1003), BamRead.basesCovered (read.d:255-262), the
+// -F filter objects (sambamba/utils/common/filtering.d:86-214), the RG -> sample lookup of
+// CustomBamRead (depth.d:240-250; read.d:1070-1087,1219-1230) and pileupColumns' zero-span
+// filter (pileup.d:510).
+//
+// The record chain is inherently serial (each block_size tells where the next record starts),
+// so it is cut at BGZF block granularity: one lane per BGZF block
+//   1. guesses the first record start inside its block with a structural plausibility test
+//      (ids/positions in range, lengths consistent with block_size, NUL-terminated name,
+//      two further records chain correctly and are coordinate-sorted),
+//   2. walks the chain to the end of its block -> (count, exit offset);
+// then `chain_verify` checks exit[b-1] == entry[b] for every block and re-walks any block whose
+// guess was wrong, repeated until nothing changes.  By induction from the exactly known offset of
+// the first record, a consistent chain IS the true chain -- the guess only buys parallelism, it
+// can never change the result.  A scan of the counts gives every block its slot range in the
+// descriptor array and `describe` walks once more, now writing one 32-byte RecDesc per record
+// and the [lo,hi) record range of every position tile the record overlaps.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace sbx {
+
+namespace {
+
+constexpr int kWalkThreads = 64;
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) {
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
+
+// CIGAR_TYPE table of cigar.d:116 -- bit0: consumes query, bit1: consumes reference (MIDNSHP=X)
+constexpr uint32_t kCigarType = 0x3C1A7u;
+__device__ __forceinline__ uint32_t cig_type(uint32_t raw) { return (kCigarType >> ((raw & 15u) * 2u)) & 3u; }
+
+// Structural plausibility of a BAM record starting at offset o of the stream (fixed part only).
+__device__ bool plausible_record(const uint8_t* U, uint64_t total, uint64_t o, const RefTable& refs, uint64_t* next,
+                                 uint32_t* sort_key_ref, int32_t* sort_key_pos) {
+    if (o + 36 > total) return false;
+    const uint8_t* p = U + o;
+    int64_t bs = (int32_t)ld32(p);
+    int32_t ref = (int32_t)ld32(p + 4);
+    if (ref < -1 || ref >= refs.n_ref) return false;
+    int32_t pos = (int32_t)ld32(p + 8);
+    if (pos < -1) return false;
+    if (ref >= 0 && pos > refs.ref_len[ref]) return false;
+    uint32_t bmn = ld32(p + 12);
+    uint32_t l_name = bmn & 0xFFu;
+    if (l_name < 1) return false;
+    uint32_t fnc = ld32(p + 16);
+    uint32_t n_cigar = fnc & 0xFFFFu;
+    int32_t l_seq = (int32_t)ld32(p + 20);
+    if (l_seq < 0) return false;
+    int32_t nref = (int32_t)ld32(p + 24);
+    if (nref < -1 || nref >= refs.n_ref) return false;
+    int32_t npos = (int32_t)ld32(p + 28);
+    if (npos < -1) return false;
+    int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 + (int64_t)l_seq;
+    if (bs < fixed || bs > (int64_t)(1 << 29)) return false;
+    if (o + 4 + (uint64_t)bs > total) return false;
+    // read name: printable, NUL only at the end
+    const uint8_t* name = p + 36;
+    if (name[l_name - 1] != 0) return false;
+    if (l_name > 1 && (name[0] < 33 || name[0] > 126)) return false;
+    if (n_cigar) {
+        uint32_t op = ld32(name + l_name) & 15u;
+        if (op > 8) return false;
+    }
+    *next = o + 4 + (uint64_t)bs;
+    *sort_key_ref = (uint32_t)ref;
+    *sort_key_pos = pos;
+    return true;
+}
+
+// first record start in [from, limit) that passes the plausibility test 3 records deep
+__device__ uint64_t guess_entry(const uint8_t* U, uint64_t total, uint64_t from, uint64_t limit, const RefTable& refs) {
+    for (uint64_t o = from; o < limit; ++o) {
+        uint64_t n1, n2, n3;
+        uint32_t r1, r2, r3;
+        int32_t p1, p2, p3;
+        if (!plausible_record(U, total, o, refs, &n1, &r1, &p1)) continue;
+        if (n1 == total) return o;
+        if (!plausible_record(U, total, n1, refs, &n2, &r2, &p2)) continue;
+        if (r2 < r1 || (r2 == r1 && p2 < p1)) continue;     // coordinate order (unmapped = 0xFFFFFFFF last)
+        if (n2 == total) return o;
+        if (!plausible_record(U, total, n2, refs, &n3, &r3, &p3)) continue;
+        if (r3 < r2 || (r3 == r2 && p3 < p2)) continue;
+        return o;
+    }
+    return kOffUnknown;
+}
+
+// walk the chain from `entry` until it leaves [.., block_end); returns exit offset or kOffInvalid
+__device__ uint64_t walk_block(const uint8_t* U, uint64_t total, uint64_t entry, uint64_t block_end, uint32_t* count) {
+    uint64_t o = entry;
+    uint32_t n = 0;
+    while (o < block_end) {
+        if (o + 4 > total) { *count = n; return kOffInvalid; }
+        int64_t bs = (int32_t)ld32(U + o);
+        if (bs < 32 || o + 4 + (uint64_t)bs > total) { *count = n; return kOffInvalid; }
+        ++n;
+        o += 4 + (uint64_t)bs;
+    }
+    *count = n;
+    return o;
+}
+
+__global__ __launch_bounds__(kWalkThreads) void k_block_walk(const uint8_t* __restrict__ U, uint64_t total,
+                                                              const uint64_t* __restrict__ out_off,
+                                                              const uint32_t* __restrict__ isize, uint32_t n_blocks,
+                                                              uint64_t first_record_off, RefTable refs,
+                                                              uint64_t* __restrict__ entry, uint64_t* __restrict__ exit_,
+                                                              uint32_t* __restrict__ count) {
+    uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint64_t beg = out_off[b], end = beg + isize[b];
+    uint64_t e;
+    if (end <= first_record_off) {
+        // block lies entirely inside the BAM header: the chain enters the next block at first_record_off
+        entry[b] = first_record_off;
+        exit_[b] = first_record_off;
+        count[b] = 0;
+        return;
+    }
+    if (beg <= first_record_off) e = first_record_off;       // exactly known
+    else e = guess_entry(U, total, beg, end, refs);
+    uint32_t n = 0;
+    uint64_t x = kOffUnknown;
+    if (e != kOffUnknown) x = walk_block(U, total, e, end, &n);
+    entry[b] = e;
+    exit_[b] = x;
+    count[b] = n;
+}
+
+// entry[b] must equal exit[b-1] (the chain passes through blocks that contain no record start:
+// walk_block returns its entry unchanged when entry >= block_end).
+__global__ __launch_bounds__(kWalkThreads) void k_chain_verify(const uint8_t* __restrict__ U, uint64_t total,
+                                                                const uint64_t* __restrict__ out_off,
+                                                                const uint32_t* __restrict__ isize, uint32_t n_blocks,
+                                                                uint64_t first_record_off, uint64_t* entry, uint64_t* exit_,
+                                                                uint32_t* count, uint32_t* changed) {
+    uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint64_t want = (b == 0) ? first_record_off : exit_[b - 1];
+    if (want == kOffUnknown) return;                 // predecessor not resolved yet
+    if (b == 0 && out_off[0] + isize[0] <= first_record_off) return;
+    uint64_t end = out_off[b] + isize[b];
+    if (end <= first_record_off) return;             // header-only block, already exact
+    if (want == kOffInvalid) {
+        if (entry[b] != kOffInvalid) { entry[b] = kOffInvalid; exit_[b] = kOffInvalid; count[b] = 0; *changed = 1; }
+        return;
+    }
+    if (entry[b] == want) return;
+    uint32_t n = 0;
+    uint64_t x = walk_block(U, total, want, end, &n);
+    entry[b] = want;
+    exit_[b] = x;
+    count[b] = n;
+    *changed = 1;
+}
+
+// ---- scan of the per-block counts (single workgroup, 3 phases; n_blocks is ~1e5..1e6) -----------
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_count_scan(const uint32_t* __restrict__ count, uint32_t n,
+                                                              uint64_t* __restrict__ base) {
+    __shared__ uint64_t part[kScanThreads];
+    uint32_t t = threadIdx.x;
+    uint32_t per = (n + kScanThreads - 1) / kScanThreads;
+    uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += count[i];
+    part[t] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
+        uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        base[i] = run;
+        run += count[i];
+    }
+    if (t == kScanThreads - 1) base[n] = part[kScanThreads - 1];
+}
+
+// ---- describe ---------------------------------------------------------------------------------
+__device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID */) {
+    // postfix program over a tiny bool stack (bit stack in a 64-bit word)
+    uint64_t stack = 0;
+    int sp = 0;
+    int32_t ref = (int32_t)ld32(p), pos = (int32_t)ld32(p + 4);
+    uint32_t bmn = ld32(p + 8), fnc = ld32(p + 12);
+    uint32_t flag = fnc >> 16, mapq = (bmn >> 8) & 0xFF;
+    for (int i = 0; i < f->n_ops; ++i) {
+        const sbx_filter_op& op = f->ops[i];
+        bool v = true;
+        switch (op.kind) {
+            case 0: v = (flag & op.mask) != 0; break;
+            case 1: v = (flag & 1) && !(flag & 4) && !(flag & 8) && ref != (int32_t)ld32(p + 20); break;
+            case 2: {
+                int64_t x = 0;
+                switch (op.field) {
+                    case 0: x = ref; break;
+                    case 1: x = pos; break;
+                    case 2: x = mapq; break;
+                    case 3: x = (int32_t)ld32(p + 16); break;
+                    case 4: x = (int32_t)ld32(p + 20); break;
+                    case 5: x = (int32_t)ld32(p + 24); break;
+                    default: x = (int32_t)ld32(p + 28); break;
+                }
+                switch (op.cmp) {
+                    case 0: v = x > op.value; break;
+                    case 1: v = x < op.value; break;
+                    case 2: v = x >= op.value; break;
+                    case 3: v = x <= op.value; break;
+                    case 4: v = x == op.value; break;
+                    default: v = x != op.value; break;
+                }
+                break;
+            }
+            case 3: { bool b2 = stack & 1; stack >>= 1; bool a2 = stack & 1; stack >>= 1; sp -= 2; v = a2 && b2; break; }
+            case 4: { bool b2 = stack & 1; stack >>= 1; bool a2 = stack & 1; stack >>= 1; sp -= 2; v = a2 || b2; break; }
+            case 5: { bool a2 = stack & 1; stack >>= 1; sp -= 1; v = !a2; break; }
+            default: v = true; break;
+        }
+        stack = (stack << 1) | (v ? 1u : 0u);
+        ++sp;
+    }
+    return sp > 0 ? (stack & 1) : true;
+}
+
+// RG:Z lookup: linear scan of the aux fields (read.d:1070-1087, skipValue read.d:1219-1230).
+// returns sample id, 0 when the read has no RG tag, 0xFFFF when the id is not in the header.
+__device__ uint32_t lookup_sample(const uint8_t* t, const uint8_t* e, const RgTable& rg) {
+    while (t + 3 <= e) {
+        uint8_t k0 = t[0], k1 = t[1], ty = t[2];
+        t += 3;
+        const uint8_t* v = t;
+        switch (ty) {
+            case 'A': case 'c': case 'C': t += 1; break;
+            case 's': case 'S': t += 2; break;
+            case 'i': case 'I': case 'f': t += 4; break;
+            case 'Z': case 'H': while (t < e && *t) ++t; ++t; break;
+            case 'B': {
+                if (t + 5 > e) return 0;
+                uint8_t sub = t[0];
+                uint32_t n = ld32(t + 1);
+                uint32_t w = (sub == 'c' || sub == 'C') ? 1u : (sub == 's' || sub == 'S') ? 2u : 4u;
+                t += 5 + (uint64_t)n * w;
+                break;
+            }
+            default: return 0;
+        }
+        if (k0 == 'R' && k1 == 'G') {
+            if (ty != 'Z' && ty != 'H') return 0xFFFFu;
+            uint32_t len = (uint32_t)((t - 1) - v);
+            for (int g = 0; g < rg.n_rg; ++g) {
+                const char* id = rg.ids + rg.id_off[g];
+                uint32_t k = 0;
+                while (k < len && id[k] && (uint8_t)id[k] == v[k]) ++k;
+                if (k == len && id[k] == 0) return rg.sample_of[g];
+            }
+            return 0xFFFFu;
+        }
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __restrict__ U, uint64_t total,
+                                                            const uint64_t* __restrict__ out_off,
+                                                            const uint32_t* __restrict__ isize, uint32_t n_blocks,
+                                                            const uint64_t* __restrict__ entry,
+                                                            const uint64_t* __restrict__ base, RefTable refs,
+                                                            const DeviceFilter* __restrict__ filt, RgTable rg,
+                                                            uint32_t tile_pos, RecDesc* __restrict__ desc,
+                                                            uint32_t* tile_lo, uint32_t* tile_hi, IndexStats* stats) {
+    uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint64_t end = out_off[b] + isize[b];
+    uint64_t o = entry[b];
+    uint64_t idx = base[b];
+    unsigned long long n_rec = 0, n_adm = 0, n_bad = 0, n_urg = 0;
+    // tile-range bookkeeping aggregated per lane: flush on tile change
+    uint32_t cur_t0 = 0xFFFFFFFFu, cur_t1 = 0, cur_lo = 0, cur_hi = 0;
+    auto flush = [&]() {
+        if (cur_t0 == 0xFFFFFFFFu) return;
+        for (uint32_t t = cur_t0; t <= cur_t1; ++t) {
+            atomicMin(&tile_lo[t], cur_lo);
+            atomicMax(&tile_hi[t], cur_hi);
+        }
+        cur_t0 = 0xFFFFFFFFu;
+    };
+    while (o < end && o != kOffUnknown && o != kOffInvalid) {
+        const uint8_t* p = U + o;
+        int64_t bs = (int32_t)ld32(p);
+        const uint8_t* r = p + 4;
+        int32_t ref = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+        uint32_t bmn = ld32(r + 8), fnc = ld32(r + 12);
+        uint32_t l_name = bmn & 0xFF, mapq = (bmn >> 8) & 0xFF;
+        uint32_t n_cigar = fnc & 0xFFFF, flag = fnc >> 16;
+        int32_t l_seq = (int32_t)ld32(r + 16);
+        RecDesc d;
+        d.rec_off = o;
+        d.pos = pos;
+        d.end = pos;
+        d.l_seq = (uint32_t)l_seq;
+        d.n_cigar = (uint16_t)n_cigar;
+        d.l_name = (uint8_t)l_name;
+        d.mapq = (uint8_t)mapq;
+        d.flag = (uint16_t)flag;
+        d.sample = 0;
+        d.q_start = 0;
+        d.kind = 0;
+        d.pad = 0;
+        ++n_rec;
+        int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
+        bool sane = l_seq >= 0 && bs >= fixed && ref >= -1 && ref < refs.n_ref;
+        if (!sane) ++n_bad;
+        bool admit = sane && !(flag & 0x4) && ref >= 0;                       // read.d:256, unmapped reads cover nothing
+        if (admit) admit = eval_filter(filt, r);                              // filtering.d:36-38
+        if (admit) {
+            // basesCovered + shape of the CIGAR
+            const uint8_t* cg = r + 32 + l_name;
+            int64_t span = 0;
+            uint32_t q_lead = 0;         // query bases before the first reference-consuming op
+            uint32_t runs = 0;           // number of maximal runs of M/=/X
+            bool in_run = false, other_ref = false, q_inside = false, seen_ref = false;
+            for (uint32_t i = 0; i < n_cigar; ++i) {
+                uint32_t op = ld32(cg + 4 * i);
+                uint32_t ty = cig_type(op), len = op >> 4;
+                if (ty == 3) {
+                    if (!in_run) { ++runs; in_run = true; }
+                    span += len;
+                    seen_ref = true;
+                } else {
+                    if (ty & 2) { other_ref = true; span += len; seen_ref = true; in_run = false; }
+                    else if (ty & 1) {
+                        if (!seen_ref) q_lead += len;
+                        else { in_run = false; q_inside = true; }   // I or trailing S: ends the run
+                    }
+                    // H / P (ty == 0) neither end a run nor consume anything
+                }
+            }
+            // q_inside is also set by a trailing soft clip, which is harmless for the fast path
+            // as long as there is exactly one run and no D/N: positions map 1:1 onto the query.
+            (void)q_inside;
+            if (span <= 0 || span > 0x7FFFFFFF - (int64_t)pos) admit = false;   // pileup.d:510
+            else {
+                d.end = pos + (int32_t)span;
+                if (runs == 1 && !other_ref && q_lead <= 0xFFFF) { d.kind = 1; d.q_start = (uint16_t)q_lead; }
+                else d.kind = 2;
+            }
+        }
+        if (admit && rg.lookup) {
+            const uint8_t* tags = r + fixed;
+            uint32_t s = lookup_sample(tags, r + bs, rg);
+            if (s == 0xFFFFu) { ++n_urg; s = 0; }
+            d.sample = (uint16_t)s;
+        }
+        if (admit) {
+            ++n_adm;
+            uint32_t t0 = refs.tile_base[ref] + (uint32_t)pos / tile_pos;
+            uint32_t t1 = refs.tile_base[ref] + (uint32_t)(d.end - 1) / tile_pos;
+            uint32_t last_tile = refs.tile_base[ref + 1] - 1;      // clip alignments hanging over the contig end
+            if (t1 > last_tile) t1 = last_tile;
+            if (t0 > last_tile) { admit = false; d.kind = 0; d.end = d.pos; --n_adm; ++n_bad; }
+            else if (t0 == cur_t0 && t1 == cur_t1) { cur_hi = (uint32_t)idx + 1; }
+            else {
+                flush();
+                cur_t0 = t0; cur_t1 = t1; cur_lo = (uint32_t)idx; cur_hi = (uint32_t)idx + 1;
+            }
+        }
+        desc[idx] = d;
+        ++idx;
+        if (bs < 32) break;
+        o += 4 + (uint64_t)bs;
+    }
+    flush();
+    if (n_rec) atomicAdd(&stats->n_records, n_rec);
+    if (n_adm) atomicAdd(&stats->n_admitted, n_adm);
+    if (n_bad) atomicAdd(&stats->n_bad, n_bad);
+    if (n_urg) atomicAdd(&stats->n_unknown_rg, n_urg);
+}
+
+// ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
+__global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* __restrict__ tile_lo,
+                                                                const uint32_t* __restrict__ tile_hi, uint32_t n_tiles,
+                                                                uint32_t* __restrict__ active, uint32_t* __restrict__ slot_of,
+                                                                uint32_t* __restrict__ n_active) {
+    __shared__ uint32_t part[kScanThreads];
+    uint32_t t = threadIdx.x;
+    uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+    uint32_t lo = t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += (tile_hi[i] > tile_lo[i]) ? 1u : 0u;
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        if (tile_hi[i] > tile_lo[i]) {
+            active[run] = i;
+            slot_of[i] = run;
+            ++run;
+        } else {
+            slot_of[i] = 0xFFFFFFFFu;
+        }
+    }
+    if (t == kScanThreads - 1) *n_active = part[kScanThreads - 1];
+}
+
+}  // namespace
+
+void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                       uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry, uint64_t* d_exit,
+                       uint32_t* d_count, hipStream_t stream) {
+    if (!n_blocks) return;
+    dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
+    hipLaunchKernelGGL(k_block_walk, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, first_record_off,
+                       refs, d_entry, d_exit, d_count);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_chain_verify(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                         uint32_t n_blocks, uint64_t first_record_off, uint64_t* d_entry, uint64_t* d_exit,
+                         uint32_t* d_count, uint32_t* d_changed, hipStream_t stream) {
+    if (!n_blocks) return;
+    dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
+    hipLaunchKernelGGL(k_chain_verify, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks,
+                       first_record_off, d_entry, d_exit, d_count, d_changed);
+    SBX_HIP(hipGetLastError());
+}
+
+size_t count_scan_tmp_bytes(uint32_t) { return 0; }
+
+void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void*, size_t, hipStream_t stream) {
+    hipLaunchKernelGGL(k_count_scan, dim3(1), dim3(kScanThreads), 0, stream, d_count, n_blocks, d_base);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
+                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, uint32_t* d_tile_lo,
+                     uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream) {
+    if (!n_blocks) return;
+    dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
+    hipLaunchKernelGGL(k_describe, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, d_entry, d_base,
+                       refs, d_filter, rg, tile_pos, d_desc, d_tile_lo, d_tile_hi, d_stats);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t* d_active,
+                         uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(kScanThreads), 0, stream, d_tile_lo, d_tile_hi, n_tiles, d_active,
+                       d_slot_of, d_n_active);
+    SBX_HIP(hipGetLastError());
+}
+
+}  // namespace sbx

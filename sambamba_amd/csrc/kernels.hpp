@@ -1,0 +1,98 @@
+// kernels.hpp -- device data structures and launchers of the HIP kernels of libsbx_depth.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/sbx_depth.h"
+
+namespace sbx {
+
+// ---------------------------------------------------------------------------------------------
+// Data layout in HBM
+//   comp      : the BAM file bytes as on disk (BGZF blocks back to back)
+//   U         : the inflated BAM byte stream, block b at U[out_off[b] .. +isize[b])
+//   RecDesc[] : one 32-byte descriptor per BAM record, in file order
+//   tiles     : the concatenated reference is cut into tiles of kTilePos positions, every contig
+//               starting on a tile boundary; tile t covers positions [t*T - base, ...) of its contig
+//   counters  : per *active* tile (>= 1 admitted read overlaps it): u32[T][n_samples][7]
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kOffUnknown = ~0ULL;       // "no value yet" in the record-chain arrays
+constexpr uint64_t kOffInvalid = ~0ULL - 1;   // walking from a guess ran into garbage
+
+struct RecDesc {            // 32 bytes, one per BAM record (read.d:907-1003 fields the path needs)
+    uint64_t rec_off;       // offset of the record's block_size field in U
+    int32_t pos;            // 0-based leftmost position (BamRead.position)
+    int32_t end;            // pos + basesCovered() (read.d:255-262); == pos when the read is not admitted
+    uint32_t l_seq;
+    uint16_t n_cigar;
+    uint8_t l_name;
+    uint8_t mapq;
+    uint16_t flag;
+    uint16_t sample;        // CustomBamRead.sample_id (depth.d:240-250); 0 when --combined / single sample
+    uint16_t q_start;       // kind==1: query offset of the first aligned base
+    uint8_t kind;           // 0 not admitted, 1 one run of M/=/X (fast path), 2 general CIGAR
+    uint8_t pad;
+};
+static_assert(sizeof(RecDesc) == 32, "RecDesc must be 32 bytes");
+
+struct DeviceFilter {       // compiled -F program (sbx_filter), evaluated per record
+    int32_t n_ops;
+    sbx_filter_op ops[SBX_FILTER_MAX_OPS];
+};
+
+struct RefTable {           // per-reference device arrays
+    const int32_t* ref_len;        // [n_ref]
+    const uint32_t* tile_base;     // [n_ref + 1] index of the contig's first tile
+    int32_t n_ref;
+};
+
+struct RgTable {            // read-group id strings -> sample id (depth.d:1170-1181)
+    const char* ids;               // concatenated NUL-terminated ids
+    const uint32_t* id_off;        // [n_rg] offsets into ids
+    const uint16_t* sample_of;     // [n_rg]
+    int32_t n_rg;
+    int32_t lookup;                // 0: every read is sample 0 and RG tags are not inspected
+};
+
+// ---- K1: BGZF inflate (inflate.hip) -------------------------------------------------------
+size_t inflate_scratch_bytes(uint32_t n_blocks);
+void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
+                         const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
+                         uint8_t* d_scratch, uint32_t* d_status, hipStream_t stream);
+const char* inflate_status_string(uint32_t s);
+
+// ---- K2: record index (index.hip) ---------------------------------------------------------
+// guess + walk: per BGZF block, first record start g[b] >= out_off[b], record count and exit.
+void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                       uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry,
+                       uint64_t* d_exit, uint32_t* d_count, hipStream_t stream);
+// one repair sweep; *d_changed is set to 1 if any block's entry had to be corrected
+void launch_chain_verify(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                         uint32_t n_blocks, uint64_t first_record_off, uint64_t* d_entry, uint64_t* d_exit,
+                         uint32_t* d_count, uint32_t* d_changed, hipStream_t stream);
+// exclusive scan of per-block record counts -> d_base[n_blocks+1]
+void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void* d_tmp, size_t tmp_bytes,
+                       hipStream_t stream);
+size_t count_scan_tmp_bytes(uint32_t n_blocks);
+
+struct IndexStats {         // device-side accumulators of the describe pass
+    unsigned long long n_records, n_admitted, n_bad, n_unknown_rg;
+};
+// walk again, decode fixed fields + CIGAR span, apply filter, write descriptors, mark tile ranges
+void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
+                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, uint32_t* d_tile_lo,
+                     uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream);
+// compact the tiles that have work: active[] = tile ids, slot_of[t] = index into active or ~0u
+void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t* d_active,
+                         uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream);
+
+// ---- K3: decode + accumulate (depth.hip) -------------------------------------------------
+void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_tile_lo, const uint32_t* d_tile_hi,
+                       const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base, int32_t n_ref,
+                       uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
+                       hipStream_t stream);
+
+}  // namespace sbx
