@@ -177,6 +177,7 @@ typedef struct {
     uint64_t n_records, n_admitted, n_bgzf_blocks;
     uint64_t compressed_bytes, uncompressed_bytes, counter_bytes, covered_positions;
     uint64_t launches_inflate, launches_index, launches_accumulate;
+    double ms_huffman, ms_lz77;   /* the two kernels of ms_inflate */
 } sbx_run_stats;
 int sbx_last_run_stats(sbx_ctx*, sbx_run_stats* out);
 

@@ -49,7 +49,7 @@ class RunStats(C.Structure):
                 ("n_records", C.c_uint64), ("n_admitted", C.c_uint64), ("n_bgzf_blocks", C.c_uint64),
                 ("compressed_bytes", C.c_uint64), ("uncompressed_bytes", C.c_uint64), ("counter_bytes", C.c_uint64),
                 ("covered_positions", C.c_uint64), ("launches_inflate", C.c_uint64), ("launches_index", C.c_uint64),
-                ("launches_accumulate", C.c_uint64)]
+                ("launches_accumulate", C.c_uint64), ("ms_huffman", C.c_double), ("ms_lz77", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

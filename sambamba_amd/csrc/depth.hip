@@ -48,6 +48,24 @@ __device__ __forceinline__ uint32_t base5_of_nibble(uint32_t nib) {
     return (uint32_t)(lut >> (nib * 3)) & 7u;
 }
 
+// LDS layout of a tile: positions are split by (p & 3) into 4 sub-arrays so that a lane owning 4
+// consecutive positions (the dword fast path) and a lane owning 1 position (D/N runs) both spread
+// over all 32 banks: dword index of position p = (p & 3) * sub_dw + (p >> 2) * (S * 7),
+// sub_dw = (T / 4) * S * 7 + 8.
+__device__ __forceinline__ uint32_t pos_dw(uint32_t p, uint32_t sub_dw, uint32_t s7) { return (p & 3u) * sub_dw + (p >> 2) * s7; }
+
+struct RecU {   // wave-uniform view of one record (values live in SGPRs)
+    const uint8_t* seq;
+    const uint8_t* qual;
+    const uint8_t* cig;
+    int32_t pos, end;
+    uint32_t l_seq, n_cigar, kind, q_start, sample;
+};
+
+struct Pre {    // per-lane prefetched data of the first pass of a kind-1 record
+    uint32_t qw, sw;
+};
+
 template <bool kSpan>
 __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
@@ -55,11 +73,12 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq, uint32_t* __restrict__ counters,
     uint32_t* __restrict__ span_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t* cnt = lds;                       // [T][S][7]
-    uint32_t* spn = lds + (size_t)T * S * 7;   // [T] (only when kSpan)
+    const uint32_t s7 = S * 7;
+    const uint32_t sub_dw = (T / 4) * s7 + 8;
+    uint32_t* cnt = lds;                  // 4 * sub_dw dwords
+    uint32_t* spn = lds + 4 * sub_dw;     // [T] (only when kSpan)
     const uint32_t tile = active[blockIdx.x];
-    const uint32_t n_cnt = T * S * 7;
-    for (uint32_t i = threadIdx.x; i < n_cnt + (kSpan ? T : 0u); i += kAccThreads) lds[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 4 * sub_dw + (kSpan ? T : 0u); i += kAccThreads) lds[i] = 0;
 
     // which contig does this tile belong to?  (binary search in tile_base[0..n_ref])
     int lo_r = 0, hi_r = n_ref;   // invariant: tile_base[lo_r] <= tile < tile_base[hi_r]
@@ -73,6 +92,47 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+    // 4 bases of a match run held by this lane: bases q..q+nb-1 of the read at tile offsets p0..
+    auto add4 = [&](uint32_t qw, uint32_t sw, uint32_t q, uint32_t nb, uint32_t p0, uint32_t sample) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (k < nb) {
+                const uint32_t qi = (q & 1u) + k;                        // nibble index inside sw
+                const uint32_t byte = (sw >> (8u * (qi >> 1))) & 0xFFu;
+                const uint32_t nib = (qi & 1u) ? (byte & 15u) : (byte >> 4);
+                const uint32_t ql = (qw >> (8u * k)) & 0xFFu;
+                if (ql >= min_bq) atomicAdd(&cnt[pos_dw(p0 + k, sub_dw, s7) + sample * 7 + base5_of_nibble(nib)], 1u);
+            }
+        }
+    };
+    // clipped range of a run [rp, rp+len) of aligned bases whose first base is query offset qp
+    auto clip = [&](int32_t rp, uint32_t qp, uint32_t len, uint32_t l_seq, int32_t* i0, int32_t* i1) {
+        *i0 = ts > rp ? ts - rp : 0;
+        int32_t e = (int32_t)len < te - rp ? (int32_t)len : te - rp;
+        if ((int64_t)qp + (int64_t)e > (int64_t)l_seq) e = (int32_t)l_seq - (int32_t)qp;   // malformed record guard
+        *i1 = e;
+    };
+    // passes of a match run beyond what was prefetched (or all passes when first == 0)
+    auto match_run = [&](const RecU& R, int32_t rp, uint32_t qp, uint32_t len, int32_t first) {
+        int32_t i0, i1;
+        clip(rp, qp, len, R.l_seq, &i0, &i1);
+        for (int32_t i = i0 + first + 4 * (int32_t)lane; i < i1; i += 256) {
+            const uint32_t q = qp + (uint32_t)i;
+            const uint32_t nb = (uint32_t)(i1 - i) < 4u ? (uint32_t)(i1 - i) : 4u;
+            // 4 quality bytes + the <= 3 sequence bytes holding bases q..q+3; the few bytes read past
+            // the run stay inside the record (tags / next record) or the stream's 64-byte padding
+            add4(ld32u(R.qual + q), ld32u(R.seq + (q >> 1)), q, nb, (uint32_t)(rp + i - ts), R.sample);
+        }
+    };
+    auto gap_run = [&](const RecU& R, int32_t rp, uint32_t len, uint32_t code) {
+        int32_t i0 = ts > rp ? ts - rp : 0;
+        int64_t room = (int64_t)te - rp;
+        int32_t i1 = (int64_t)len < room ? (int32_t)len : (int32_t)(room < 0 ? 0 : room);
+        for (int32_t i = i0 + (int32_t)lane; i < i1; i += 64)
+            atomicAdd(&cnt[pos_dw((uint32_t)(rp + i - ts), sub_dw, s7) + R.sample * 7 + code], 1u);
+    };
+
     for (uint32_t c = r_lo + wave * 64u; c < r_hi; c += (kAccThreads / 64) * 64u) {
         const uint32_t ri = c + lane;
         RecDesc d;
@@ -81,67 +141,67 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
         if (ri < r_hi) d = desc[ri];
         const bool take = d.kind != 0 && d.pos < te && d.end > ts;
         uint64_t mask = __ballot(take);
-        while (mask) {
-            const int r = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            // wave-uniform copies of record r
+        // wave-uniform view of record r of this batch
+        auto view = [&](int r) {
+            RecU R;
             const uint32_t off_lo = __builtin_amdgcn_readlane((uint32_t)d.rec_off, r);
             const uint32_t off_hi = __builtin_amdgcn_readlane((uint32_t)(d.rec_off >> 32), r);
-            const int32_t pos = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.pos, r);
-            const int32_t end = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.end, r);
-            const uint32_t l_seq = __builtin_amdgcn_readlane(d.l_seq, r);
+            R.pos = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.pos, r);
+            R.end = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.end, r);
+            R.l_seq = __builtin_amdgcn_readlane(d.l_seq, r);
             const uint32_t misc = __builtin_amdgcn_readlane((uint32_t)d.n_cigar | ((uint32_t)d.l_name << 16) | ((uint32_t)d.kind << 24), r);
             const uint32_t misc2 = __builtin_amdgcn_readlane((uint32_t)d.q_start | ((uint32_t)d.sample << 16), r);
-            const uint32_t n_cigar = misc & 0xFFFFu, l_name = (misc >> 16) & 0xFFu, kind = misc >> 24;
-            const uint32_t q_start = misc2 & 0xFFFFu, sample = (S > 1) ? (misc2 >> 16) : 0u;
+            R.n_cigar = misc & 0xFFFFu;
+            R.kind = misc >> 24;
+            R.q_start = misc2 & 0xFFFFu;
+            R.sample = (S > 1) ? (misc2 >> 16) : 0u;
             const uint8_t* rec = U + (((uint64_t)off_hi << 32) | off_lo);
-            const uint8_t* cig = rec + 36 + l_name;
-            const uint8_t* seq = cig + 4 * n_cigar;
-            const uint8_t* qual = seq + ((l_seq + 1) >> 1);
-            uint32_t* cbase = cnt + sample * 7;
-
-            // one run of aligned bases [rp, rp+len) <-> query [qp, qp+len)
-            auto match_run = [&](int32_t rp, uint32_t qp, uint32_t len) {
-                int32_t i0 = ts > rp ? ts - rp : 0;
-                int32_t i1 = (int32_t)len < te - rp ? (int32_t)len : te - rp;
-                for (int32_t i = i0 + (int32_t)lane; i < i1; i += 64) {
-                    uint32_t q = qp + (uint32_t)i;
-                    if (q < l_seq) {
-                        uint32_t sb = seq[q >> 1];
-                        uint32_t nib = (q & 1u) ? (sb & 15u) : (sb >> 4);
-                        uint32_t ql = qual[q];
-                        uint32_t p = (uint32_t)(rp + i - ts);
-                        if (ql >= min_bq) atomicAdd(&cbase[p * S * 7 + base5_of_nibble(nib)], 1u);
-                    }
+            R.cig = rec + 36 + ((misc >> 16) & 0xFFu);
+            R.seq = R.cig + 4 * R.n_cigar;
+            R.qual = R.seq + ((R.l_seq + 1) >> 1);
+            return R;
+        };
+        // issue the loads of the first pass of a kind-1 record (one memory round trip per read)
+        auto prefetch = [&](const RecU& R, Pre& P) {
+            P.qw = 0; P.sw = 0;
+            if (R.kind == 1) {
+                int32_t i0, i1;
+                clip(R.pos, R.q_start, (uint32_t)(R.end - R.pos), R.l_seq, &i0, &i1);
+                const int32_t i = i0 + 4 * (int32_t)lane;
+                if (i < i1) {
+                    const uint32_t q = R.q_start + (uint32_t)i;
+                    P.qw = ld32u(R.qual + q);
+                    P.sw = ld32u(R.seq + (q >> 1));
                 }
-            };
-            auto gap_run = [&](int32_t rp, uint32_t len, uint32_t code) {
-                int32_t i0 = ts > rp ? ts - rp : 0;
-                int64_t room = (int64_t)te - rp;
-                int32_t i1 = (int64_t)len < room ? (int32_t)len : (int32_t)(room < 0 ? 0 : room);
-                for (int32_t i = i0 + (int32_t)lane; i < i1; i += 64) {
-                    uint32_t p = (uint32_t)(rp + i - ts);
-                    atomicAdd(&cbase[p * S * 7 + code], 1u);
-                }
-            };
+            }
+        };
+        auto consume = [&](const RecU& R, const Pre& P) {
             if (kSpan) {
-                int32_t a = pos > ts ? pos : ts, b2 = end < te ? end : te;
+                int32_t a = R.pos > ts ? R.pos : ts, b2 = R.end < te ? R.end : te;
                 for (int32_t p = a + (int32_t)lane; p < b2; p += 64) atomicAdd(&spn[p - ts], 1u);
             }
-            if (kind == 1) {
-                match_run(pos, q_start, (uint32_t)(end - pos));
+            if (R.kind == 1) {
+                int32_t i0, i1;
+                const uint32_t len = (uint32_t)(R.end - R.pos);
+                clip(R.pos, R.q_start, len, R.l_seq, &i0, &i1);
+                const int32_t i = i0 + 4 * (int32_t)lane;
+                if (i < i1) {
+                    const uint32_t nb = (uint32_t)(i1 - i) < 4u ? (uint32_t)(i1 - i) : 4u;
+                    add4(P.qw, P.sw, R.q_start + (uint32_t)i, nb, (uint32_t)(R.pos + i - ts), R.sample);
+                }
+                if (i1 - i0 > 256) match_run(R, R.pos, R.q_start, len, 256);   // reads longer than 256 aligned bases
             } else {
-                int32_t rp = pos;
+                int32_t rp = R.pos;
                 uint32_t qp = 0;
-                for (uint32_t k = 0; k < n_cigar; ++k) {
-                    uint32_t op = ld32u(cig + 4 * k);
+                for (uint32_t k = 0; k < R.n_cigar; ++k) {
+                    uint32_t op = ld32u(R.cig + 4 * k);
                     uint32_t ty = (kCigarType >> ((op & 15u) * 2u)) & 3u, len = op >> 4;
                     if (ty == 3) {
-                        match_run(rp, qp, len);
+                        match_run(R, rp, qp, len, 0);
                         rp += (int32_t)len;
                         qp += len;
                     } else if (ty == 2) {
-                        gap_run(rp, len, (op & 15u) == 2u ? 5u : 6u);   // D -> DEL, otherwise (N) -> REFSKIP
+                        gap_run(R, rp, len, (op & 15u) == 2u ? 5u : 6u);   // D -> DEL, otherwise (N) -> REFSKIP
                         rp += (int32_t)len;
                     } else if (ty == 1) {
                         qp += len;
@@ -149,12 +209,35 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
                     if (rp >= te) break;
                 }
             }
+        };
+        if (mask) {
+            // software pipeline: the loads of record n+1 are in flight while record n is accumulated
+            int r = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            RecU cur = view(r);
+            Pre pc;
+            prefetch(cur, pc);
+            while (mask) {
+                r = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                RecU nxt = view(r);
+                Pre pn;
+                prefetch(nxt, pn);
+                consume(cur, pc);
+                cur = nxt;
+                pc = pn;
+            }
+            consume(cur, pc);
         }
     }
     __syncthreads();
-    // write the tile once, coalesced
+    // write the tile once, coalesced (undoing the (p & 3) split)
+    const uint32_t n_cnt = T * s7;
     uint32_t* out = counters + (size_t)blockIdx.x * n_cnt;
-    for (uint32_t i = threadIdx.x; i < n_cnt; i += kAccThreads) out[i] = cnt[i];
+    for (uint32_t i = threadIdx.x; i < n_cnt; i += kAccThreads) {
+        const uint32_t p = i / s7, k = i - p * s7;
+        out[i] = cnt[pos_dw(p, sub_dw, s7) + k];
+    }
     if (kSpan) {
         uint32_t* so = span_out + (size_t)blockIdx.x * T;
         for (uint32_t i = threadIdx.x; i < T; i += kAccThreads) so[i] = spn[i];
@@ -168,7 +251,7 @@ void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t
                        uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
                        hipStream_t stream) {
     if (!n_active) return;
-    size_t lds = (size_t)tile_pos * n_samples * 7 * 4 + (d_span ? (size_t)tile_pos * 4 : 0);
+    size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0);
     if (d_span) {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate<true>, dim3(n_active), dim3(kAccThreads), lds, stream, d_U, d_desc, d_tile_lo,

@@ -61,7 +61,8 @@ struct sbx_ctx {
     DevBuf<uint8_t> d_comp;
     DevBuf<uint64_t> d_comp_off, d_out_off;
     DevBuf<uint32_t> d_comp_len, d_isize, d_status;
-    DevBuf<uint8_t> d_U, d_scratch;
+    DevBuf<uint8_t> d_U, d_scratch, d_lit;
+    DevBuf<uint32_t> d_ent, d_nent;
     DevBuf<uint64_t> d_entry, d_exit, d_base;
     DevBuf<uint32_t> d_count, d_flag;
     DevBuf<RecDesc> d_desc;
@@ -132,13 +133,19 @@ void upload_file(sbx_ctx* c) {
 }
 
 // inflate blocks [b0,b1) into d_U (which is laid out for the whole file) and check their status
-void inflate_blocks(sbx_ctx* c, uint32_t b0, uint32_t b1) {
+void inflate_blocks(sbx_ctx* c, uint32_t b0, uint32_t b1, hipEvent_t ev_mid = nullptr) {
     if (b1 <= b0) return;
     uint32_t n = b1 - b0;
-    c->d_status.ensure(c->blocks.size() + 1);
-    c->d_scratch.ensure(inflate_scratch_bytes((uint32_t)c->blocks.size()));
+    const uint32_t nb = (uint32_t)c->blocks.size();
+    const uint64_t total = c->blocks.out_off.back();
+    c->d_status.ensure(nb + 1);
+    c->d_nent.ensure(nb + 1);
+    c->d_scratch.ensure(inflate_scratch_bytes(nb));
+    c->d_lit.ensure(inflate_lit_bytes(total, nb));
+    c->d_ent.ensure(inflate_ent_words(total, nb));
     launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p + b0, c->d_comp_len.p + b0, c->d_isize.p + b0, c->d_out_off.p + b0,
-                        c->d_U.p, n, c->d_scratch.p, c->d_status.p + b0, c->stream);
+                        c->d_U.p, n, b0, c->d_scratch.p + (size_t)b0 * (inflate_scratch_bytes(2) / 2), c->d_lit.p, c->d_ent.p,
+                        c->d_nent.p + b0, c->d_status.p + b0, c->stream, ev_mid);
 }
 
 void check_inflate_status(sbx_ctx* c, uint32_t b0, uint32_t b1) {
@@ -193,6 +200,8 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
             out_end = std::max(out_end, out_off[i] + isize[i]);
         }
         DevBuf<uint8_t> d_in(in_end + 64), d_out(out_end + 64), d_scr(inflate_scratch_bytes(n_blocks));
+        DevBuf<uint8_t> d_lit(inflate_lit_bytes(out_end, n_blocks));
+        DevBuf<uint32_t> d_ent(inflate_ent_words(out_end, n_blocks)), d_nent(n_blocks);
         DevBuf<uint64_t> d_coff(n_blocks), d_ooff(n_blocks);
         DevBuf<uint32_t> d_clen(n_blocks), d_isz(n_blocks), d_st(n_blocks);
         SBX_HIP(hipMemset(d_in.p + in_end, 0, 64));
@@ -201,7 +210,8 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
         SBX_HIP(hipMemcpy(d_ooff.p, out_off, n_blocks * 8ull, hipMemcpyHostToDevice));
         SBX_HIP(hipMemcpy(d_clen.p, comp_len, n_blocks * 4ull, hipMemcpyHostToDevice));
         SBX_HIP(hipMemcpy(d_isz.p, isize, n_blocks * 4ull, hipMemcpyHostToDevice));
-        launch_bgzf_inflate(d_in.p, d_coff.p, d_clen.p, d_isz.p, d_ooff.p, d_out.p, n_blocks, d_scr.p, d_st.p, nullptr);
+        launch_bgzf_inflate(d_in.p, d_coff.p, d_clen.p, d_isz.p, d_ooff.p, d_out.p, n_blocks, 0, d_scr.p, d_lit.p, d_ent.p,
+                            d_nent.p, d_st.p, nullptr);
         std::vector<uint32_t> st(n_blocks);
         SBX_HIP(hipMemcpy(st.data(), d_st.p, n_blocks * 4ull, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n_blocks; ++i)
@@ -349,20 +359,20 @@ int sbx_run(sbx_ctx* c) {
         if (c->stats.ms_h2d == 0) c->stats.ms_h2d = ms_h2d;
         const uint32_t nb = (uint32_t)c->blocks.size();
         const uint64_t total = c->blocks.out_off.back();
-        EventTimer t_all, t1, t2, t3;
+        EventTimer t_all, t1, t1m, t2, t3;
         t_all.start(s);
 
         // ---- K1 ----
         c->d_U.ensure(total + 64);
         t1.start(s);
-        inflate_blocks(c, 0, nb);
+        inflate_blocks(c, 0, nb, t1m.b);
         t1.stop(s);
         check_inflate_status(c, 0, nb);
 
         // ---- K2 ----
         const int32_t n_ref = (int32_t)c->hdr.refs.size();
         const uint32_t S = c->combined ? 1u : (uint32_t)c->hdr.sample_names.size();
-        const uint32_t T = std::max<uint32_t>(16, floor_pow2(std::max<uint32_t>(1, 2048u / std::max<uint32_t>(1, S))));
+        const uint32_t T = std::max<uint32_t>(16, floor_pow2(std::max<uint32_t>(1, 1024u / std::max<uint32_t>(1, S))));
         std::vector<int32_t> ref_len((size_t)n_ref);
         std::vector<uint32_t> tile_base((size_t)n_ref + 1);
         uint64_t nt = 0;
@@ -385,19 +395,36 @@ int sbx_run(sbx_ctx* c) {
         c->d_count.ensure(nb + 1);
         c->d_base.ensure(nb + 2);
         c->d_flag.ensure(4);
+        const bool dbg = getenv("SBX_DEBUG") != nullptr;
+        auto lap = [&](const char* what) {
+            if (!dbg) return;
+            static thread_local double t_prev = 0;
+            SBX_HIP(hipStreamSynchronize(s));
+            struct timespec ts2; clock_gettime(CLOCK_MONOTONIC, &ts2);
+            double now = ts2.tv_sec * 1e3 + ts2.tv_nsec * 1e-6;
+            fprintf(stderr, "[sbx]   %-14s +%.3f ms\n", what, t_prev ? now - t_prev : 0.0);
+            t_prev = now;
+        };
+        lap("start-index");
         t2.start(s);
         launch_block_walk(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, refs, c->d_entry.p,
                           c->d_exit.p, c->d_count.p, s);
-        for (uint32_t iter = 0;; ++iter) {
-            SBX_HIP(hipMemsetAsync(c->d_flag.p, 0, 4, s));
-            launch_chain_verify(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, c->d_entry.p,
-                                c->d_exit.p, c->d_count.p, c->d_flag.p, s);
-            uint32_t changed = 0;
-            SBX_HIP(hipMemcpyAsync(&changed, c->d_flag.p, 4, hipMemcpyDeviceToHost, s));
+        lap("block_walk");
+        uint32_t verify_iters = 0;   // number of blocks whose guessed entry had to be re-walked
+        {
+            uint32_t first_bad = 0xFFFFFFFFu;
+            SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 4, s));
+            launch_chain_check(c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, c->d_entry.p, c->d_exit.p, c->d_flag.p, s);
+            SBX_HIP(hipMemcpyAsync(&first_bad, c->d_flag.p, 4, hipMemcpyDeviceToHost, s));
             SBX_HIP(hipStreamSynchronize(s));
-            if (!changed) break;
-            if (iter > nb + 2) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
+            if (first_bad != 0xFFFFFFFFu) {
+                launch_chain_repair(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, first_bad,
+                                    c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_flag.p + 1, s);
+                SBX_HIP(hipMemcpyAsync(&verify_iters, c->d_flag.p + 1, 4, hipMemcpyDeviceToHost, s));
+                SBX_HIP(hipStreamSynchronize(s));
+            }
         }
+        lap("chain_verify");
         if (nb) {
             // the chain must end exactly at the end of the stream
             uint64_t last_exit = 0;
@@ -439,9 +466,12 @@ int sbx_run(sbx_ctx* c) {
         }
         c->d_stats.ensure(1);
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
+        lap("scan+setup");
         launch_describe(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
                         T, c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_stats.p, s);
+        lap("describe");
         launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
+        lap("tile_compact");
         t2.stop(s);
         uint32_t n_active = 0;
         IndexStats ist{};
@@ -472,6 +502,12 @@ int sbx_run(sbx_ctx* c) {
         c->n_active = n_active;
         c->span_valid = want_span;
         c->stats.ms_inflate = t1.ms();
+        {
+            float f = 0;
+            SBX_HIP(hipEventElapsedTime(&f, t1.a, t1m.b));
+            c->stats.ms_huffman = f;
+            c->stats.ms_lz77 = c->stats.ms_inflate - f;
+        }
         c->stats.ms_index = t2.ms();
         c->stats.ms_accumulate = t3.ms();
         c->stats.ms_total = t_all.ms();
@@ -483,7 +519,10 @@ int sbx_run(sbx_ctx* c) {
         c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4;
         c->stats.covered_positions = (uint64_t)n_active * T;
         c->stats.launches_inflate = 1;
-        c->stats.launches_index = 5;
+        c->stats.launches_index = 5 + (verify_iters ? 1 : 0);
+        if (getenv("SBX_DEBUG"))
+            fprintf(stderr, "[sbx] blocks=%u records=%llu rewalked_blocks=%u tiles=%llu active=%u T=%u\n", nb,
+                    (unsigned long long)n_records, verify_iters, (unsigned long long)nt, n_active, T);
         c->stats.launches_accumulate = 1;
         c->have_run = true;
     });

@@ -142,31 +142,61 @@ __global__ __launch_bounds__(kWalkThreads) void k_block_walk(const uint8_t* __re
     count[b] = n;
 }
 
-// entry[b] must equal exit[b-1] (the chain passes through blocks that contain no record start:
-// walk_block returns its entry unchanged when entry >= block_end).
-__global__ __launch_bounds__(kWalkThreads) void k_chain_verify(const uint8_t* __restrict__ U, uint64_t total,
-                                                                const uint64_t* __restrict__ out_off,
-                                                                const uint32_t* __restrict__ isize, uint32_t n_blocks,
-                                                                uint64_t first_record_off, uint64_t* entry, uint64_t* exit_,
-                                                                uint32_t* count, uint32_t* changed) {
+// Parallel check of the guessed chain: entry[b] must equal exit[b-1] (exit of a block that contains
+// no record start is its entry, see walk_block).  The lowest inconsistent block goes to *first_bad.
+__global__ __launch_bounds__(kWalkThreads) void k_chain_check(const uint64_t* __restrict__ out_off,
+                                                               const uint32_t* __restrict__ isize, uint32_t n_blocks,
+                                                               uint64_t first_record_off, const uint64_t* __restrict__ entry,
+                                                               const uint64_t* __restrict__ exit_, uint32_t* first_bad) {
     uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
     if (b >= n_blocks) return;
-    uint64_t want = (b == 0) ? first_record_off : exit_[b - 1];
-    if (want == kOffUnknown) return;                 // predecessor not resolved yet
-    if (b == 0 && out_off[0] + isize[0] <= first_record_off) return;
     uint64_t end = out_off[b] + isize[b];
-    if (end <= first_record_off) return;             // header-only block, already exact
-    if (want == kOffInvalid) {
-        if (entry[b] != kOffInvalid) { entry[b] = kOffInvalid; exit_[b] = kOffInvalid; count[b] = 0; *changed = 1; }
-        return;
+    if (end <= first_record_off) return;             // header-only block: exact by construction
+    uint64_t want = (b == 0) ? first_record_off : exit_[b - 1];
+    bool ok = want != kOffUnknown && want != kOffInvalid && entry[b] == want && exit_[b] != kOffUnknown && exit_[b] != kOffInvalid;
+    if (!ok) atomicMin(first_bad, b);
+}
+
+// Serial repair from the first inconsistent block on (one wavefront; rare).  Everything before
+// `from` is consistent with the exactly known first record offset, hence true; from there the chain
+// is followed block by block: a block whose guessed entry equals the running offset keeps its
+// pre-computed walk (O(1)), any other block is re-walked from the true entry.
+__global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__ U, uint64_t total,
+                                                      const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize,
+                                                      uint32_t n_blocks, uint64_t first_record_off, uint32_t from,
+                                                      uint64_t* entry, uint64_t* exit_, uint32_t* count, uint32_t* n_rewalked) {
+    const uint32_t lane = threadIdx.x;
+    uint64_t cur = (from == 0) ? first_record_off : exit_[from - 1];
+    uint32_t rewalked = 0;
+    for (uint32_t b0 = from; b0 < n_blocks; b0 += 64) {
+        const uint32_t b = b0 + lane;
+        uint64_t e = kOffUnknown, x = kOffUnknown, end = 0;
+        uint32_t n = 0;
+        if (b < n_blocks) { e = entry[b]; x = exit_[b]; n = count[b]; end = out_off[b] + isize[b]; }
+        const uint32_t lim = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
+        bool dirty = false;
+        for (uint32_t i = 0; i < lim; ++i) {
+            const uint64_t e_i = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(e >> 32), i) << 32) | __builtin_amdgcn_readlane((uint32_t)e, i);
+            const uint64_t x_i = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(x >> 32), i) << 32) | __builtin_amdgcn_readlane((uint32_t)x, i);
+            const uint64_t end_i = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(end >> 32), i) << 32) | __builtin_amdgcn_readlane((uint32_t)end, i);
+            uint64_t ne, nx;
+            uint32_t nn;
+            if (cur == kOffInvalid) { ne = kOffInvalid; nx = kOffInvalid; nn = 0; }
+            else if (end_i <= first_record_off) { ne = e_i; nx = x_i; nn = 0; }   // header-only block
+            else if (e_i == cur && x_i != kOffUnknown) { ne = e_i; nx = x_i; nn = __builtin_amdgcn_readlane(n, i); }
+            else {
+                uint32_t c = 0;
+                nx = walk_block(U, total, cur, end_i, &c);     // wave-uniform re-walk
+                ne = cur;
+                nn = c;
+                ++rewalked;
+            }
+            if (lane == i && (ne != e || nx != x || nn != n)) { e = ne; x = nx; n = nn; dirty = true; }
+            if (!(end_i <= first_record_off)) cur = nx;
+        }
+        if (dirty && b < n_blocks) { entry[b] = e; exit_[b] = x; count[b] = n; }
     }
-    if (entry[b] == want) return;
-    uint32_t n = 0;
-    uint64_t x = walk_block(U, total, want, end, &n);
-    entry[b] = want;
-    exit_[b] = x;
-    count[b] = n;
-    *changed = 1;
+    if (lane == 0) *n_rewalked = rewalked;
 }
 
 // ---- scan of the per-block counts (single workgroup, 3 phases; n_blocks is ~1e5..1e6) -----------
@@ -439,13 +469,20 @@ void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out
     SBX_HIP(hipGetLastError());
 }
 
-void launch_chain_verify(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                         uint32_t n_blocks, uint64_t first_record_off, uint64_t* d_entry, uint64_t* d_exit,
-                         uint32_t* d_count, uint32_t* d_changed, hipStream_t stream) {
+void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint32_t n_blocks, uint64_t first_record_off,
+                        const uint64_t* d_entry, const uint64_t* d_exit, uint32_t* d_first_bad, hipStream_t stream) {
     if (!n_blocks) return;
     dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
-    hipLaunchKernelGGL(k_chain_verify, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks,
-                       first_record_off, d_entry, d_exit, d_count, d_changed);
+    hipLaunchKernelGGL(k_chain_check, grid, block, 0, stream, d_out_off, d_isize, n_blocks, first_record_off, d_entry, d_exit,
+                       d_first_bad);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, uint64_t* d_entry, uint64_t* d_exit,
+                         uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream) {
+    hipLaunchKernelGGL(k_chain_repair, dim3(1), dim3(64), 0, stream, d_U, total, d_out_off, d_isize, n_blocks,
+                       first_record_off, from, d_entry, d_exit, d_count, d_n_rewalked);
     SBX_HIP(hipGetLastError());
 }
 

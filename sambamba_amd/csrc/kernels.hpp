@@ -57,10 +57,17 @@ struct RgTable {            // read-group id strings -> sample id (depth.d:1170-
 };
 
 // ---- K1: BGZF inflate (inflate.hip) -------------------------------------------------------
+// Two launches: K1a huffman_decode (lane per block -> literal + match-entry streams) and
+// K1b lz77_resolve (wave per block -> inflated bytes).  The per-block arrays are indexed from 0 for
+// the n_blocks blocks of this launch; block0 is the index of the first one in the whole file (it
+// only positions the blocks' slices inside the token streams).
 size_t inflate_scratch_bytes(uint32_t n_blocks);
+size_t inflate_lit_bytes(uint64_t total_out, uint32_t n_blocks);
+size_t inflate_ent_words(uint64_t total_out, uint32_t n_blocks);
 void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
                          const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
-                         uint8_t* d_scratch, uint32_t* d_status, hipStream_t stream);
+                         uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
+                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid = nullptr);
 const char* inflate_status_string(uint32_t s);
 
 // ---- K2: record index (index.hip) ---------------------------------------------------------
@@ -68,10 +75,13 @@ const char* inflate_status_string(uint32_t s);
 void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                        uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry,
                        uint64_t* d_exit, uint32_t* d_count, hipStream_t stream);
-// one repair sweep; *d_changed is set to 1 if any block's entry had to be corrected
-void launch_chain_verify(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                         uint32_t n_blocks, uint64_t first_record_off, uint64_t* d_entry, uint64_t* d_exit,
-                         uint32_t* d_count, uint32_t* d_changed, hipStream_t stream);
+// parallel consistency check of the guessed chain: *d_first_bad = lowest inconsistent block (or unchanged)
+void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint32_t n_blocks, uint64_t first_record_off,
+                        const uint64_t* d_entry, const uint64_t* d_exit, uint32_t* d_first_bad, hipStream_t stream);
+// serial (one wave) repair of the chain from block `from` on; *d_n_rewalked = blocks whose guess was wrong
+void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
+                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, uint64_t* d_entry, uint64_t* d_exit,
+                         uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream);
 // exclusive scan of per-block record counts -> d_base[n_blocks+1]
 void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void* d_tmp, size_t tmp_bytes,
                        hipStream_t stream);
