@@ -333,6 +333,126 @@ private:
     }
 };
 
+std::string fmt_g(float f) {  // D's write(float) == %g with 6 significant digits (depth.d:859-864)
+    char b[64];
+    snprintf(b, sizeof b, "%g", (double)f);
+    return b;
+}
+
+void print_bed_header(Out& out, const Options& o, size_t n_before) {  // depth.d:643-659
+    static const char* def[] = {"chrom", "chromStart", "chromEnd"};
+    std::string h = "# ";
+    for (size_t i = 0; i < std::min<size_t>(3, n_before); ++i) h += std::string(def[i]) + "\t";
+    for (size_t k = 3; k < n_before; ++k) h += "F" + std::to_string(k) + "\t";
+    h += "readCount\tmeanCoverage";
+    for (auto t : o.thresholds) h += "\tpercentage" + std::to_string(t);
+    if (!o.combined) h += "\tsampleName";
+    if (o.annotate) h += "\tmeanCovWithinBounds";
+    h += "\n";
+    out.put(h);
+}
+
+// printRegionStats (depth.d:847-876)
+void print_region_row(Out& out, const Options& o, const std::string& prefix, uint32_t length, const sbx_region_stats& st,
+                      const uint32_t* cov, const std::string& sample) {
+    float mean_cov = (float)st.n_bases / (float)length;
+    bool ok = (double)mean_cov >= o.min_cov && (double)mean_cov <= o.max_cov;
+    if (!ok && !o.annotate) return;
+    std::string row = prefix;
+    row += std::to_string(st.n_reads) + "\t" + fmt_g(mean_cov);
+    for (size_t j = 0; j < o.thresholds.size(); ++j) {
+        float pct = (float)cov[j] * 100 / (float)length;
+        if (o.thresholds[j] == 0) pct = 100.0f;
+        row += "\t" + fmt_g(pct);
+    }
+    if (!o.combined) row += "\t" + sample;
+    if (o.annotate) row += ok ? "\ty" : "\tn";
+    row += "\n";
+    out.put(row);
+}
+
+// position of the first pileup column of the run (first admitted read), or false if there is none
+bool first_column(sbx_ctx* c, int n_ref, int* ref_out, uint64_t* pos_out) {
+    std::vector<uint32_t> cnt;
+    std::vector<uint8_t> cov;
+    uint32_t T = 0, S = 0;
+    check(c, sbx_tile_info(c, &T, &S));
+    for (int r = 0; r < n_ref; ++r) {
+        uint64_t from = 0;
+        for (;;) {
+            uint64_t b, e;
+            check(c, sbx_next_active_range(c, (uint32_t)r, from, &b, &e));
+            if (b == ~0ULL) break;
+            for (uint64_t p = b; p < e; p += 65536) {
+                uint64_t q = std::min(e, p + 65536);
+                cnt.resize((size_t)(q - p) * S * SBX_NCOUNTERS);
+                cov.resize((size_t)(q - p));
+                check(c, sbx_depth_base_tile(c, (uint32_t)r, (uint32_t)p, (uint32_t)q, cnt.data(), cov.data()));
+                for (uint64_t x = p; x < q; ++x)
+                    if (cov[(size_t)(x - p)]) { *ref_out = r; *pos_out = x; return true; }
+            }
+            from = e;
+        }
+    }
+    return false;
+}
+
+// PerBedRegionPrinter.close (depth.d:925-930): rows in input order; nothing at all unless some column
+// fell inside some region (the samples array is created lazily)
+void print_regions(sbx_ctx* c, const Options& o, Out& out, const std::vector<std::string>& samples,
+                   const std::vector<sbx_region>& raw, const std::vector<std::string>& lines) {
+    const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
+    const size_t n_thr = o.thresholds.size();
+    std::vector<sbx_region_stats> st(raw.size() * S);
+    std::vector<uint32_t> cov(raw.size() * S * std::max<size_t>(1, n_thr));
+    std::vector<uint8_t> seen(raw.size());
+    check(c, sbx_depth_region_stats(c, raw.data(), raw.size(), st.data(), cov.data(), seen.data()));
+    bool any = false;
+    for (auto v : seen) any |= v != 0;
+    if (!any) return;
+    for (size_t id = 0; id < raw.size(); ++id) {
+        std::string l = lines[id];
+        while (!l.empty() && isspace((unsigned char)l.back())) l.pop_back();   // stripRight (depth.d:904)
+        l += "\t";
+        for (uint32_t s = 0; s < S; ++s)
+            print_region_row(out, o, l, raw[id].end - raw[id].start, st[id * S + s], &cov[(id * S + s) * n_thr], samples[s]);
+    }
+}
+
+// PerWindowPrinter (depth.d:933-1077), overlap == 0
+void print_windows(sbx_ctx* c, const Options& o, Out& out, const std::vector<std::string>& samples, int n_ref) {
+    const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
+    const size_t n_thr = o.thresholds.size();
+    int fref = 0;
+    uint64_t fpos = 0;
+    if (!first_column(c, n_ref, &fref, &fpos)) return;   // no column at all: header only
+    const uint64_t w = o.window;
+    std::vector<sbx_region_stats> st;
+    std::vector<uint32_t> cov;
+    for (int r = fref; r < n_ref; ++r) {
+        const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r));
+        const uint64_t n_full = len / w;
+        if (!n_full) continue;
+        const std::string name = sbx_ref_name(c, r);
+        const uint64_t CH = 1u << 18;
+        for (uint64_t k0 = 0; k0 < n_full; k0 += CH) {
+            const uint64_t k1 = std::min(n_full, k0 + CH);
+            st.assign((size_t)(k1 - k0) * S, sbx_region_stats{0, 0});
+            cov.assign((size_t)(k1 - k0) * S * std::max<size_t>(1, n_thr), 0);
+            if (k0 == 0 && k1 == n_full) check(c, sbx_depth_window_stats(c, (uint32_t)r, 0, n_full, st.data(), cov.data()));
+            else check(c, sbx_depth_window_stats(c, (uint32_t)r, k0, k1 - k0, st.data(), cov.data()));
+            for (uint64_t k = k0; k < k1; ++k) {
+                // windows finished before the first column of the run print nothing (samples not created yet)
+                if (r == fref && (k + 1) * w <= fpos) continue;
+                std::string prefix = name + "\t" + std::to_string(k * w) + "\t" + std::to_string((k + 1) * w) + "\t";
+                for (uint32_t s = 0; s < S; ++s)
+                    print_region_row(out, o, prefix, (uint32_t)w, st[(size_t)(k - k0) * S + s],
+                                     &cov[((size_t)(k - k0) * S + s) * n_thr], samples[s]);
+            }
+        }
+    }
+}
+
 int depth_main(int argc, char** argv) {
     if (argc < 3) { usage(); return 0; }
     std::string mode = argv[1];
@@ -375,6 +495,8 @@ int depth_main(int argc, char** argv) {
             if (o.annotate) h += "\tFLAG";
             h += "\n";
             out.put(h);
+        } else if (o.mode == "window") {
+            print_bed_header(out, o, 3);   // PerWindowPrinter.init (depth.d:1036)
         }
         ctx = sbx_open(paths.data(), (int)paths.size(), -1, ebuf, sizeof ebuf);
         if (!ctx) throw Fail{ebuf};
@@ -398,10 +520,18 @@ int depth_main(int argc, char** argv) {
             for (int r = 0; r < hi.n_ref; ++r) hv.refs.push_back({sbx_ref_name(ctx, r), (int32_t)sbx_ref_length(ctx, r)});
             std::vector<BedInterval> ivs;
             std::vector<std::string> lines;
-            if (read_bed_file(o.regions, &ivs, &lines)) {
+            std::vector<size_t> line_of;
+            if (read_bed_file(o.regions, &ivs, &lines, &line_of)) {
                 merged = bed_merged(ivs, hv);
-                raw = bed_raw(ivs, hv);
-                raw_lines = lines;
+                // raw list in file order; every kept region keeps its own input line (the reference
+                // pairs them by index, which misaligns when a line is dropped -- SURVEY App. B-6)
+                for (size_t i = 0; i < ivs.size(); ++i) {
+                    int id = hv.find_ref(ivs[i].chr);
+                    if (id < 0) continue;
+                    raw.push_back({(uint32_t)id, (uint32_t)ivs[i].beg, (uint32_t)ivs[i].end});
+                    raw_lines.push_back(lines[line_of[i]]);
+                }
+                if (o.mode == "region" && lines.empty()) throw Fail{"Attempting to fetch the front of an empty array of string"};
             } else {
                 RegionString rs = parse_region_string(o.regions);
                 int id = sbx_ref_id(ctx, rs.reference.c_str());
@@ -415,14 +545,17 @@ int depth_main(int argc, char** argv) {
             if (merged.empty()) throw Fail{"Enforcement failed"};
             check(ctx, sbx_set_regions(ctx, merged.data(), merged.size()));
         }
+        if (o.mode == "region") print_bed_header(out, o, split_ws(raw_lines.empty() ? std::string("a b c") : raw_lines[0]).size());
         check(ctx, sbx_run(ctx));
-        if (o.mode == "base") {
+        if (o.mode == "region") {
+            print_regions(ctx, o, out, samples, raw, raw_lines);
+        } else if (o.mode == "window") {
+            print_windows(ctx, o, out, samples, hi.n_ref);
+        } else if (o.mode == "base") {
             BasePrinter p(ctx, o, out, samples);
             if (o.has_regions) p.set_bed(merged);
             // "Processing reference #N (name)" lines go to stderr in the reference (depth.d:1225-1229)
             p.run();
-        } else {
-            throw Fail{"region/window printing is not available in this build"};
         }
         out.flush();
         if (out.fp != stdout) fclose(out.fp);

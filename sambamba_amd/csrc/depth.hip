@@ -191,11 +191,20 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
                 }
                 if (i1 - i0 > 256) match_run(R, R.pos, R.q_start, len, 256);   // reads longer than 256 aligned bases
             } else {
+                // General CIGAR walk.  Every reference-consuming op occupies max(len, 1) columns (a
+                // zero-length op still shows for one column in the reference's cursor, pileup.d:195-205)
+                // and the read leaves the pileup at end = pos + sum(len) (read.d:1380-1383), which
+                // truncates whatever is left.
                 int32_t rp = R.pos;
                 uint32_t qp = 0;
                 for (uint32_t k = 0; k < R.n_cigar; ++k) {
                     uint32_t op = ld32u(R.cig + 4 * k);
                     uint32_t ty = (kCigarType >> ((op & 15u) * 2u)) & 3u, len = op >> 4;
+                    if (ty & 2u) {
+                        if (len == 0) len = 1;
+                        const int32_t room = R.end - rp;
+                        if ((int64_t)len > (int64_t)room) len = (uint32_t)(room > 0 ? room : 0);
+                    }
                     if (ty == 3) {
                         match_run(R, rp, qp, len, 0);
                         rp += (int32_t)len;
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
                     } else if (ty == 1) {
                         qp += len;
                     }
-                    if (rp >= te) break;
+                    if (rp >= te || rp >= R.end) break;
                 }
             }
         };

@@ -66,6 +66,7 @@ struct sbx_ctx {
     DevBuf<uint64_t> d_entry, d_exit, d_base;
     DevBuf<uint32_t> d_count, d_flag;
     DevBuf<RecDesc> d_desc;
+    DevBuf<int32_t> d_rec_ref;
     DevBuf<int32_t> d_ref_len;
     DevBuf<uint32_t> d_tile_base, d_tile_lo, d_tile_hi, d_active, d_slot_of, d_n_active;
     DevBuf<uint32_t> d_counters, d_span;
@@ -412,19 +413,75 @@ int sbx_run(sbx_ctx* c) {
         lap("block_walk");
         uint32_t verify_iters = 0;   // number of blocks whose guessed entry had to be re-walked
         {
-            uint32_t first_bad = 0xFFFFFFFFu;
-            SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 4, s));
-            launch_chain_check(c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, c->d_entry.p, c->d_exit.p, c->d_flag.p, s);
-            SBX_HIP(hipMemcpyAsync(&first_bad, c->d_flag.p, 4, hipMemcpyDeviceToHost, s));
-            SBX_HIP(hipStreamSynchronize(s));
-            if (first_bad != 0xFFFFFFFFu) {
-                launch_chain_repair(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, first_bad,
-                                    c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_flag.p + 1, s);
-                SBX_HIP(hipMemcpyAsync(&verify_iters, c->d_flag.p + 1, 4, hipMemcpyDeviceToHost, s));
+            // check -> repair the first inconsistent stretch -> re-check ...; wrong guesses are rare and
+            // isolated, so this converges in a handful of rounds; a file full of them (e.g. records much
+            // longer than a BGZF block) falls back to one serial pass over the rest of the chain
+            SBX_HIP(hipMemsetAsync(c->d_flag.p + 1, 0, 4, s));
+            const char* force = getenv("SBX_FORCE_REPAIR");   // debug hook (tests/test_gpu_repair.py)
+            for (int round = 0;; ++round) {
+                uint32_t first_bad = 0xFFFFFFFFu;
+                SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 4, s));
+                launch_chain_check(c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, c->d_entry.p, c->d_exit.p, c->d_flag.p, s);
+                SBX_HIP(hipMemcpyAsync(&first_bad, c->d_flag.p, 4, hipMemcpyDeviceToHost, s));
                 SBX_HIP(hipStreamSynchronize(s));
+                bool forced = false;
+                if (force && round == 0) { uint32_t f = (uint32_t)atoi(force); if (f < first_bad && f < nb) { first_bad = f; forced = true; } }
+                if (first_bad == 0xFFFFFFFFu || first_bad >= nb) break;
+                const bool to_the_end = forced || round >= 16;
+                launch_chain_repair(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, first_bad,
+                                    !to_the_end, c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_flag.p + 1, s);
+                if (round > 64) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
             }
+            SBX_HIP(hipMemcpyAsync(&verify_iters, c->d_flag.p + 1, 4, hipMemcpyDeviceToHost, s));
+            SBX_HIP(hipStreamSynchronize(s));
         }
         lap("chain_verify");
+        if (dbg && nb) {
+            std::vector<uint64_t> he(nb), hx(nb);
+            std::vector<uint32_t> hc(nb);
+            SBX_HIP(hipMemcpy(he.data(), c->d_entry.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
+            SBX_HIP(hipMemcpy(hx.data(), c->d_exit.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
+            SBX_HIP(hipMemcpy(hc.data(), c->d_count.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
+            uint64_t bad = 0, first = ~0ull, passthru = 0, sum = 0;
+            for (uint32_t b = 0; b < nb; ++b) {
+                uint64_t end = c->blocks.out_off[b] + c->blocks.isize[b];
+                uint64_t want = b ? hx[b - 1] : c->hdr.first_record_off;
+                sum += hc[b];
+                if (end <= c->hdr.first_record_off) continue;
+                if (he[b] >= end) ++passthru;
+                if (he[b] != want) { ++bad; if (first == ~0ull) first = b; }
+            }
+            fprintf(stderr, "[sbx]   chain: inconsistent=%llu first=%lld passthrough=%llu sum_count=%llu\n", (unsigned long long)bad,
+                    (long long)first, (unsigned long long)passthru, (unsigned long long)sum);
+            for (uint32_t b = 1; b < nb; ++b) {
+                uint64_t end = c->blocks.out_off[b] + c->blocks.isize[b];
+                if (end <= c->hdr.first_record_off || he[b] < end) continue;
+                uint32_t q = b - 1;
+                fprintf(stderr, "[sbx]   first passthrough block %u entry=%llu end=%llu | prev: entry=%llu exit=%llu count=%u beg=%llu isize=%u total=%llu\n",
+                        b, (unsigned long long)he[b], (unsigned long long)end, (unsigned long long)he[q], (unsigned long long)hx[q], hc[q],
+                        (unsigned long long)c->blocks.out_off[q], c->blocks.isize[q], (unsigned long long)total);
+                // walk block q on the host
+                std::vector<uint8_t> buf(c->blocks.isize[q] + 65536 + 64);
+                uint64_t beg = c->blocks.out_off[q];
+                size_t nbytes = (size_t)std::min<uint64_t>(buf.size(), total - beg);
+                SBX_HIP(hipMemcpy(buf.data(), c->d_U.p + beg, nbytes, hipMemcpyDeviceToHost));
+                uint64_t o = he[q];
+                int k = 0;
+                while (o < beg + c->blocks.isize[q] && o - beg + 4 <= nbytes && k < 400) {
+                    int32_t bs; memcpy(&bs, buf.data() + (o - beg), 4);
+                    int32_t pos; memcpy(&pos, buf.data() + (o - beg) + 8, 4);
+                    if (k < 3 || bs < 32 || bs > 1000) fprintf(stderr, "[sbx]     rec %d at %llu bs=%d pos=%d\n", k, (unsigned long long)o, bs, pos);
+                    if (bs < 32) break;
+                    o += 4 + (uint64_t)bs; ++k;
+                }
+                fprintf(stderr, "[sbx]     host walk: %d records, exit=%llu\n", k, (unsigned long long)o);
+                break;
+            }
+            if (first != ~0ull)
+                fprintf(stderr, "[sbx]   block %llu: entry=%llu want=%llu exit=%llu count=%u beg=%llu\n", (unsigned long long)first,
+                        (unsigned long long)he[first], (unsigned long long)(first ? hx[first - 1] : 0), (unsigned long long)hx[first],
+                        hc[first], (unsigned long long)c->blocks.out_off[first]);
+        }
         if (nb) {
             // the chain must end exactly at the end of the stream
             uint64_t last_exit = 0;
@@ -437,6 +494,7 @@ int sbx_run(sbx_ctx* c) {
         SBX_HIP(hipStreamSynchronize(s));
         if (n_records > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "more than 2^32 records in one batch");
         c->d_desc.ensure((size_t)n_records + 64);
+        c->d_rec_ref.ensure((size_t)n_records + 64);
         c->d_tile_lo.ensure((size_t)nt + 1);
         c->d_tile_hi.ensure((size_t)nt + 1);
         c->d_active.ensure((size_t)nt + 1);
@@ -468,7 +526,7 @@ int sbx_run(sbx_ctx* c) {
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
         lap("scan+setup");
         launch_describe(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
-                        T, c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_stats.p, s);
+                        T, c->d_desc.p, c->d_rec_ref.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_stats.p, s);
         lap("describe");
         launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
         lap("tile_compact");
@@ -478,6 +536,9 @@ int sbx_run(sbx_ctx* c) {
         SBX_HIP(hipMemcpyAsync(&n_active, c->d_n_active.p, 4, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipMemcpyAsync(&ist, c->d_stats.p, sizeof ist, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));
+        if (ist.n_records != n_records)
+            throw Error(SBX_EFORMAT, "internal error: record chain (" + std::to_string(n_records) + ") and describe pass (" +
+                                         std::to_string(ist.n_records) + ") disagree on the number of records");
         if (ist.n_unknown_rg)
             throw Error(SBX_ERG, "error in read: read group is not present in the header (" + std::to_string(ist.n_unknown_rg) + " reads)");
 
@@ -578,13 +639,146 @@ int sbx_depth_base_tile(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end,
     });
 }
 
-int sbx_depth_region_stats(sbx_ctx* c, const sbx_region*, size_t, sbx_region_stats*, uint32_t*, uint8_t*) {
-    if (c) c->last_error = "region mode is not on the device path yet";
-    return SBX_EUNSUPPORTED;
+// Shared implementation of region / window statistics over an explicit list of ranges.
+// ranges[i] gets id i; stats/cov are [i][S] / [i][S][n_thr]; seen[i] (optional).
+static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool windows, uint32_t window,
+                        const std::vector<uint64_t>& win_base, const std::vector<uint64_t>& n_win, sbx_region_stats* stats,
+                        uint32_t* cov_counts, uint8_t* seen) {
+    if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
+    SBX_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t S = c->n_samples_eff, T = c->tile_pos;
+    const uint32_t n_thr = (uint32_t)c->thresholds.size();
+    if (n_thr > (uint32_t)kMaxThresholds) throw Error(SBX_EUNSUPPORTED, "more than 16 coverage thresholds");
+    const size_t n = ranges.size();
+    if (n > 0x7FFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "too many regions / windows");
+    // chunk list for the position reductions
+    std::vector<RangeChunk> chunks;
+    const uint32_t CH = 16384;
+    for (size_t i = 0; i < n; ++i)
+        for (uint64_t p = ranges[i].start; p < ranges[i].end; p += CH)
+            chunks.push_back({ranges[i].ref_id, (uint32_t)p, (uint32_t)std::min<uint64_t>(ranges[i].end, p + CH), (uint32_t)i});
+    DevBuf<RangeChunk> d_chunks(chunks.size() + 1);
+    DevBuf<uint32_t> d_nb(n * S + 1), d_nr(n * S + 1), d_cov(n * S * std::max<uint32_t>(1, n_thr) + 1), d_seen(n + 1), d_thr(n_thr + 1);
+    if (!chunks.empty()) SBX_HIP(hipMemcpyAsync(d_chunks.p, chunks.data(), chunks.size() * sizeof(RangeChunk), hipMemcpyHostToDevice, s));
+    if (n_thr) SBX_HIP(hipMemcpyAsync(d_thr.p, c->thresholds.data(), n_thr * 4, hipMemcpyHostToDevice, s));
+    SBX_HIP(hipMemsetAsync(d_nb.p, 0, d_nb.bytes(), s));
+    SBX_HIP(hipMemsetAsync(d_nr.p, 0, d_nr.bytes(), s));
+    SBX_HIP(hipMemsetAsync(d_cov.p, 0, d_cov.bytes(), s));
+    SBX_HIP(hipMemsetAsync(d_seen.p, 0, d_seen.bytes(), s));
+    EventTimer t;
+    t.start(s);
+    launch_range_reduce(d_chunks.p, (uint32_t)chunks.size(), c->d_counters.p, c->span_valid ? c->d_span.p : nullptr, c->d_slot_of.p,
+                        c->d_tile_base.p, T, S, d_thr.p, n_thr, d_nb.p, d_cov.p, d_seen.p, s);
+    const uint64_t n_records = c->stats.n_records;
+    DevBuf<uint64_t> d_wb, d_nw;
+    DevBuf<SortedRegion> d_regs;
+    DevBuf<uint32_t> d_pmax, d_first;
+    if (windows) {
+        d_wb.alloc(win_base.size() + 1);
+        d_nw.alloc(n_win.size() + 1);
+        SBX_HIP(hipMemcpyAsync(d_wb.p, win_base.data(), win_base.size() * 8, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(d_nw.p, n_win.data(), n_win.size() * 8, hipMemcpyHostToDevice, s));
+        launch_count_reads_windows(c->d_U.p, c->d_desc.p, n_records, c->d_rec_ref.p, window, d_wb.p, d_nw.p, S, c->min_bq, d_nr.p, s);
+    } else {
+        // (ref, start)-sorted view + prefix max of ends per contig
+        const size_t n_ref = c->hdr.refs.size();
+        std::vector<uint32_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (ranges[x].ref_id != ranges[y].ref_id) return ranges[x].ref_id < ranges[y].ref_id;
+            return ranges[x].start < ranges[y].start;
+        });
+        std::vector<SortedRegion> regs(n);
+        std::vector<uint32_t> pmax(n), first(n_ref + 1, 0);
+        size_t j = 0;
+        for (size_t r = 0; r < n_ref; ++r) {
+            first[r] = (uint32_t)j;
+            uint32_t mx = 0;
+            while (j < n && ranges[order[j]].ref_id == r) {
+                regs[j] = {ranges[order[j]].start, ranges[order[j]].end, order[j]};
+                mx = std::max(mx, ranges[order[j]].end);
+                pmax[j] = mx;
+                ++j;
+            }
+        }
+        first[n_ref] = (uint32_t)j;
+        d_regs.alloc(n + 1);
+        d_pmax.alloc(n + 1);
+        d_first.alloc(n_ref + 2);
+        if (n) {
+            SBX_HIP(hipMemcpyAsync(d_regs.p, regs.data(), n * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
+            SBX_HIP(hipMemcpyAsync(d_pmax.p, pmax.data(), n * 4, hipMemcpyHostToDevice, s));
+        }
+        SBX_HIP(hipMemcpyAsync(d_first.p, first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+        launch_count_reads_regions(c->d_U.p, c->d_desc.p, n_records, c->d_rec_ref.p, d_regs.p, d_pmax.p, d_first.p, S, c->min_bq,
+                                   d_nr.p, s);
+        SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
+    }
+    t.stop(s);
+    std::vector<uint32_t> h_nb(n * S), h_nr(n * S), h_seen(n);
+    if (n) {
+        SBX_HIP(hipMemcpyAsync(h_nb.data(), d_nb.p, n * S * 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(h_nr.data(), d_nr.p, n * S * 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(h_seen.data(), d_seen.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (n_thr && cov_counts) SBX_HIP(hipMemcpyAsync(cov_counts, d_cov.p, n * S * n_thr * 4, hipMemcpyDeviceToHost, s));
+    }
+    SBX_HIP(hipStreamSynchronize(s));
+    c->stats.ms_reduce = t.ms();
+    for (size_t i = 0; i < n * S; ++i) { stats[i].n_reads = h_nr[i]; stats[i].n_bases = h_nb[i]; }
+    if (seen) for (size_t i = 0; i < n; ++i) seen[i] = h_seen[i] ? 1 : 0;
 }
-int sbx_depth_window_stats(sbx_ctx* c, uint32_t, uint64_t, uint64_t, sbx_region_stats*, uint32_t*) {
-    if (c) c->last_error = "window mode is not on the device path yet";
-    return SBX_EUNSUPPORTED;
+
+int sbx_depth_region_stats(sbx_ctx* c, const sbx_region* raw, size_t n, sbx_region_stats* stats, uint32_t* cov_counts,
+                           uint8_t* seen) {
+    return guarded(c, [&] {
+        if (!c || (!raw && n) || !stats) throw Error(SBX_EINVAL, "null argument");
+        std::vector<sbx_region> ranges(raw, raw + n);
+        for (auto& r : ranges) {
+            if (r.ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
+            if (r.end < r.start) r.end = r.start;
+        }
+        range_stats(c, ranges, false, 0, {}, {}, stats, cov_counts, seen);
+    });
+}
+
+int sbx_depth_window_stats(sbx_ctx* c, uint32_t ref_id, uint64_t first_win, uint64_t n_win, sbx_region_stats* stats,
+                           uint32_t* cov_counts) {
+    return guarded(c, [&] {
+        if (!c || !stats) throw Error(SBX_EINVAL, "null argument");
+        if (ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
+        if (c->window == 0) throw Error(SBX_EINVAL, "positive window size must be specified");
+        if (c->overlap != 0)
+            throw Error(SBX_EUNSUPPORTED, "--overlap > 0 is not supported on the device path (the reference's overlapping-window "
+                                          "bookkeeping is order dependent, see DESIGN.md section 6)");
+        const uint64_t w = c->window;
+        const uint64_t len = (uint64_t)std::max(0, c->hdr.refs[ref_id].length);
+        const uint64_t total_win = len / w;                       // only full windows are ever printed (depth.d:1057,1071)
+        if (first_win + n_win > total_win) throw Error(SBX_EINVAL, "window range exceeds the contig");
+        std::vector<sbx_region> ranges((size_t)n_win);
+        for (uint64_t k = 0; k < n_win; ++k) ranges[(size_t)k] = {ref_id, (uint32_t)((first_win + k) * w), (uint32_t)((first_win + k + 1) * w)};
+        // count_reads_windows indexes windows as win_base[ref] + k with k counted from 0 on the contig
+        std::vector<uint64_t> wb(c->hdr.refs.size(), 0), nw(c->hdr.refs.size(), 0);
+        // windows before first_win are not requested: shift the base so that id = k - first_win
+        wb[ref_id] = (uint64_t)0 - first_win;
+        nw[ref_id] = first_win + n_win;
+        // records of other contigs see n_win == 0 and are skipped; windows k < first_win would get a
+        // "negative" id: exclude them by temporarily treating them through a per-call clamp
+        if (first_win != 0) {
+            // simple and exact: compute from window 0 and copy the requested slice
+            std::vector<sbx_region> all((size_t)(first_win + n_win));
+            for (uint64_t k = 0; k < first_win + n_win; ++k) all[(size_t)k] = {ref_id, (uint32_t)(k * w), (uint32_t)((k + 1) * w)};
+            wb[ref_id] = 0;
+            const uint32_t S = c->n_samples_eff, n_thr = (uint32_t)c->thresholds.size();
+            std::vector<sbx_region_stats> st(all.size() * S);
+            std::vector<uint32_t> cv(all.size() * S * std::max<uint32_t>(1, n_thr));
+            range_stats(c, all, true, (uint32_t)w, wb, nw, st.data(), cv.data(), nullptr);
+            memcpy(stats, st.data() + first_win * S, (size_t)n_win * S * sizeof(sbx_region_stats));
+            if (cov_counts && n_thr) memcpy(cov_counts, cv.data() + first_win * S * n_thr, (size_t)n_win * S * n_thr * 4);
+            return;
+        }
+        range_stats(c, ranges, true, (uint32_t)w, wb, nw, stats, cov_counts, nullptr);
+    });
 }
 int sbx_format_base_rows(sbx_ctx* c, uint32_t, uint32_t, uint32_t, double, double, int, char*, size_t, size_t*) {
     if (c) c->last_error = "device-side row formatting is not implemented yet";

@@ -301,7 +301,8 @@ inline std::vector<std::string> split_ws(const std::string& s) {
 
 // readIntervals (bed.d:59-98).  Returns false if the file cannot be read or a coordinate does not
 // parse (the reference then treats the argument as a region string, depth.d:1194-1208).
-inline bool read_bed_file(const std::string& path, std::vector<BedInterval>* ivs, std::vector<std::string>* lines) {
+inline bool read_bed_file(const std::string& path, std::vector<BedInterval>* ivs, std::vector<std::string>* lines,
+                          std::vector<size_t>* line_of_iv = nullptr) {
     FILE* fp = fopen(path.c_str(), "rb");
     if (!fp) return false;
     std::string text;
@@ -332,7 +333,7 @@ inline bool read_bed_file(const std::string& path, std::vector<BedInterval>* ivs
         if (!to_long(f[1], &iv.beg)) return false;
         if (f.size() >= 3) { if (!to_long(f[2], &iv.end)) return false; } else iv.end = iv.beg + 1;
         if (iv.beg == iv.end) iv.end = iv.beg + 1;
-        if (iv.beg < iv.end) ivs->push_back(iv);
+        if (iv.beg < iv.end) { ivs->push_back(iv); if (line_of_iv) line_of_iv->push_back(lines->size()); }
         lines->push_back(str);
     }
     return true;

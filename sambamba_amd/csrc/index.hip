@@ -13,10 +13,12 @@
 //      (ids/positions in range, lengths consistent with block_size, NUL-terminated name,
 //      two further records chain correctly and are coordinate-sorted),
 //   2. walks the chain to the end of its block -> (count, exit offset);
-// then `chain_verify` checks exit[b-1] == entry[b] for every block and re-walks any block whose
-// guess was wrong, repeated until nothing changes.  By induction from the exactly known offset of
-// the first record, a consistent chain IS the true chain -- the guess only buys parallelism, it
-// can never change the result.  A scan of the counts gives every block its slot range in the
+// then `chain_check` tests exit[b-1] == entry[b] for every block in parallel; if any block is
+// inconsistent (rare: a decoy inside a record that looks like a record chain, or a block without any
+// record start), `chain_repair` follows the chain serially from the first such block, keeping the
+// pre-computed walk of every block whose guess turns out right.  By induction from the exactly
+// known offset of the first record, a consistent chain IS the true chain -- the guess only buys
+// parallelism, it can never change the result.  A scan of the counts gives every block its slot range in the
 // descriptor array and `describe` walks once more, now writing one 32-byte RecDesc per record
 // and the [lo,hi) record range of every position tile the record overlaps.
 #include "common.hpp"
@@ -153,8 +155,17 @@ __global__ __launch_bounds__(kWalkThreads) void k_chain_check(const uint64_t* __
     uint64_t end = out_off[b] + isize[b];
     if (end <= first_record_off) return;             // header-only block: exact by construction
     uint64_t want = (b == 0) ? first_record_off : exit_[b - 1];
-    bool ok = want != kOffUnknown && want != kOffInvalid && entry[b] == want && exit_[b] != kOffUnknown && exit_[b] != kOffInvalid;
+    bool ok = want != kOffUnknown && want != kOffInvalid && entry[b] == want && exit_[b] != kOffUnknown && exit_[b] != kOffInvalid &&
+              exit_[b] >= entry[b];
     if (!ok) atomicMin(first_bad, b);
+}
+
+// wave-uniform copy of lane i's 64-bit value (readlane works on 32-bit ints: cast each half to
+// uint32_t before widening, or bit 31 of the low half sign-extends into the high half)
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t i) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i);
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
 }
 
 // Serial repair from the first inconsistent block on (one wavefront; rare).  Everything before
@@ -164,11 +175,13 @@ __global__ __launch_bounds__(kWalkThreads) void k_chain_check(const uint64_t* __
 __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__ U, uint64_t total,
                                                       const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize,
                                                       uint32_t n_blocks, uint64_t first_record_off, uint32_t from,
-                                                      uint64_t* entry, uint64_t* exit_, uint32_t* count, uint32_t* n_rewalked) {
+                                                      uint32_t stop_at_trusted, uint64_t* entry, uint64_t* exit_, uint32_t* count,
+                                                      uint32_t* n_rewalked) {
     const uint32_t lane = threadIdx.x;
     uint64_t cur = (from == 0) ? first_record_off : exit_[from - 1];
     uint32_t rewalked = 0;
-    for (uint32_t b0 = from; b0 < n_blocks; b0 += 64) {
+    bool done = false;
+    for (uint32_t b0 = from; b0 < n_blocks && !done; b0 += 64) {
         const uint32_t b = b0 + lane;
         uint64_t e = kOffUnknown, x = kOffUnknown, end = 0;
         uint32_t n = 0;
@@ -176,14 +189,16 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
         const uint32_t lim = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
         bool dirty = false;
         for (uint32_t i = 0; i < lim; ++i) {
-            const uint64_t e_i = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(e >> 32), i) << 32) | __builtin_amdgcn_readlane((uint32_t)e, i);
-            const uint64_t x_i = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(x >> 32), i) << 32) | __builtin_amdgcn_readlane((uint32_t)x, i);
-            const uint64_t end_i = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(end >> 32), i) << 32) | __builtin_amdgcn_readlane((uint32_t)end, i);
+            const uint64_t e_i = bcast64(e, i), x_i = bcast64(x, i), end_i = bcast64(end, i);
             uint64_t ne, nx;
             uint32_t nn;
             if (cur == kOffInvalid) { ne = kOffInvalid; nx = kOffInvalid; nn = 0; }
             else if (end_i <= first_record_off) { ne = e_i; nx = x_i; nn = 0; }   // header-only block
-            else if (e_i == cur && x_i != kOffUnknown) { ne = e_i; nx = x_i; nn = __builtin_amdgcn_readlane(n, i); }
+            else if (e_i == cur && x_i != kOffUnknown) {
+                // guess confirmed: everything from here to the next inconsistent block is already right
+                if (stop_at_trusted && rewalked) { done = true; break; }
+                ne = e_i; nx = x_i; nn = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
+            }
             else {
                 uint32_t c = 0;
                 nx = walk_block(U, total, cur, end_i, &c);     // wave-uniform re-walk
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
         }
         if (dirty && b < n_blocks) { entry[b] = e; exit_[b] = x; count[b] = n; }
     }
-    if (lane == 0) *n_rewalked = rewalked;
+    if (lane == 0) *n_rewalked += rewalked;
 }
 
 // ---- scan of the per-block counts (single workgroup, 3 phases; n_blocks is ~1e5..1e6) -----------
@@ -316,7 +331,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
                                                             const uint64_t* __restrict__ base, RefTable refs,
                                                             const DeviceFilter* __restrict__ filt, RgTable rg,
                                                             uint32_t tile_pos, RecDesc* __restrict__ desc,
-                                                            uint32_t* tile_lo, uint32_t* tile_hi, IndexStats* stats) {
+                                                            int32_t* __restrict__ rec_ref, uint32_t* tile_lo, uint32_t* tile_hi,
+                                                            IndexStats* stats) {
     uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
     if (b >= n_blocks) return;
     uint64_t end = out_off[b] + isize[b];
@@ -367,10 +383,14 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
             int64_t span = 0;
             uint32_t q_lead = 0;         // query bases before the first reference-consuming op
             uint32_t runs = 0;           // number of maximal runs of M/=/X
-            bool in_run = false, other_ref = false, q_inside = false, seen_ref = false;
+            bool in_run = false, other_ref = false, q_inside = false, seen_ref = false, zero_ref = false;
             for (uint32_t i = 0; i < n_cigar; ++i) {
                 uint32_t op = ld32(cg + 4 * i);
                 uint32_t ty = cig_type(op), len = op >> 4;
+                // a zero-length reference-consuming op still occupies one pileup column in the reference
+                // (PileupRead.incrementPosition tests offset >= length only after stepping, pileup.d:195-205):
+                // such reads take the general path, which emulates it
+                if (len == 0 && (ty & 2)) zero_ref = true;
                 if (ty == 3) {
                     if (!in_run) { ++runs; in_run = true; }
                     span += len;
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
             if (span <= 0 || span > 0x7FFFFFFF - (int64_t)pos) admit = false;   // pileup.d:510
             else {
                 d.end = pos + (int32_t)span;
-                if (runs == 1 && !other_ref && q_lead <= 0xFFFF) { d.kind = 1; d.q_start = (uint16_t)q_lead; }
+                if (runs == 1 && !other_ref && !zero_ref && q_lead <= 0xFFFF) { d.kind = 1; d.q_start = (uint16_t)q_lead; }
                 else d.kind = 2;
             }
         }
@@ -414,6 +434,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
             }
         }
         desc[idx] = d;
+        rec_ref[idx] = ref;
         ++idx;
         if (bs < 32) break;
         o += 4 + (uint64_t)bs;
@@ -479,10 +500,10 @@ void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint
 }
 
 void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, uint64_t* d_entry, uint64_t* d_exit,
-                         uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream) {
+                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, bool stop_at_trusted, uint64_t* d_entry,
+                         uint64_t* d_exit, uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream) {
     hipLaunchKernelGGL(k_chain_repair, dim3(1), dim3(64), 0, stream, d_U, total, d_out_off, d_isize, n_blocks,
-                       first_record_off, from, d_entry, d_exit, d_count, d_n_rewalked);
+                       first_record_off, from, stop_at_trusted ? 1u : 0u, d_entry, d_exit, d_count, d_n_rewalked);
     SBX_HIP(hipGetLastError());
 }
 
@@ -495,12 +516,12 @@ void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_b
 
 void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                      uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
-                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, uint32_t* d_tile_lo,
-                     uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream) {
+                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
+                     uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream) {
     if (!n_blocks) return;
     dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
     hipLaunchKernelGGL(k_describe, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, d_entry, d_base,
-                       refs, d_filter, rg, tile_pos, d_desc, d_tile_lo, d_tile_hi, d_stats);
+                       refs, d_filter, rg, tile_pos, d_desc, d_rec_ref, d_tile_lo, d_tile_hi, d_stats);
     SBX_HIP(hipGetLastError());
 }
 

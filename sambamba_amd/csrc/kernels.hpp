@@ -37,6 +37,15 @@ struct RecDesc {            // 32 bytes, one per BAM record (read.d:907-1003 fie
 };
 static_assert(sizeof(RecDesc) == 32, "RecDesc must be 32 bytes");
 
+constexpr int kMaxThresholds = 16;   // -T options handled per launch
+
+struct RangeChunk {         // a piece (<= 16384 positions) of a region or one window
+    uint32_t ref_id, start, end, id;
+};
+struct SortedRegion {       // regions of the raw BED list sorted by (ref, start)
+    uint32_t start, end, id;
+};
+
 struct DeviceFilter {       // compiled -F program (sbx_filter), evaluated per record
     int32_t n_ops;
     sbx_filter_op ops[SBX_FILTER_MAX_OPS];
@@ -78,10 +87,11 @@ void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out
 // parallel consistency check of the guessed chain: *d_first_bad = lowest inconsistent block (or unchanged)
 void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint32_t n_blocks, uint64_t first_record_off,
                         const uint64_t* d_entry, const uint64_t* d_exit, uint32_t* d_first_bad, hipStream_t stream);
-// serial (one wave) repair of the chain from block `from` on; *d_n_rewalked = blocks whose guess was wrong
+// serial (one wave) repair of the chain from block `from` on; with stop_at_trusted it returns at the first
+// block after a fix whose guessed entry is confirmed (the caller re-checks); *d_n_rewalked += wrong guesses
 void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, uint64_t* d_entry, uint64_t* d_exit,
-                         uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream);
+                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, bool stop_at_trusted, uint64_t* d_entry,
+                         uint64_t* d_exit, uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream);
 // exclusive scan of per-block record counts -> d_base[n_blocks+1]
 void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void* d_tmp, size_t tmp_bytes,
                        hipStream_t stream);
@@ -93,8 +103,8 @@ struct IndexStats {         // device-side accumulators of the describe pass
 // walk again, decode fixed fields + CIGAR span, apply filter, write descriptors, mark tile ranges
 void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                      uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
-                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, uint32_t* d_tile_lo,
-                     uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream);
+                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
+                     uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream);
 // compact the tiles that have work: active[] = tile ids, slot_of[t] = index into active or ~0u
 void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t* d_active,
                          uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream);
@@ -104,5 +114,17 @@ void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t
                        const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base, int32_t n_ref,
                        uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
                        hipStream_t stream);
+
+// ---- K5: region / window statistics (reduce.hip) --------------------------------------------
+void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_counters, const uint32_t* d_span,
+                         const uint32_t* d_slot_of, const uint32_t* d_tile_base, uint32_t T, uint32_t S,
+                         const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases, uint32_t* d_cov_counts,
+                         uint32_t* d_seen, hipStream_t stream);
+void launch_count_reads_windows(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
+                                uint32_t window, const uint64_t* d_win_base, const uint64_t* d_n_win, uint32_t S,
+                                uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);
+void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
+                                const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first, uint32_t S,
+                                uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);
 
 }  // namespace sbx

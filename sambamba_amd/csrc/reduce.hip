@@ -1,0 +1,201 @@
+// reduce.hip -- K5: per-region / per-window statistics of `sambamba depth region|window`.
+//
+// Replaces PerRegionPrinter.push / countRead / countOverlappingBases and the per-column threshold
+// bookkeeping (sambamba/depth.d:661-698,760-845) plus the stats collectors (depth.d:107-227).
+// Without -m these are closed forms over the per-position counters of K3 (SURVEY.md Appendix A,
+// verified against a literal restatement):
+//     n_bases[r]      = sum_{p in r} (# M/=/X bases at p with qual >= min_bq)      = sum of codes 0..4
+//     cov_count[r][t] = #{p in r : COV(p) >= T_t},  COV = all 7 counters (D/N count as quality 255)
+//     n_reads[r]      = # admitted reads having >= 1 M/=/X base with qual >= min_bq inside r
+// `range_reduce` does the first two as segmented reductions over the counter tiles (one wave per
+// range chunk, coalesced 28-byte rows); `count_reads` does the third per record (regions located by
+// binary search in the (ref,start)-sorted list with a prefix maximum of ends, so overlapping and
+// duplicate BED lines each get their own count, as GeneralRegionStatsCollector gives them).
+// Counters are 32-bit and wrap like the reference's `uint` fields (depth.d:618-620).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace sbx {
+
+namespace {
+
+constexpr int kRedThreads = 256;
+constexpr uint32_t kCigarType = 0x3C1A7u;
+
+__device__ __forceinline__ uint32_t ld32r(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kRedThreads) void k_range_reduce(
+    const RangeChunk* __restrict__ chunks, uint32_t n_chunks, const uint32_t* __restrict__ counters,
+    const uint32_t* __restrict__ span, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ tile_base,
+    uint32_t T, uint32_t S, const uint32_t* __restrict__ thresholds, uint32_t n_thr, uint32_t* n_bases /*[id][S]*/,
+    uint32_t* cov_counts /*[id][S][n_thr]*/, uint32_t* seen /*[id]*/) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t ci = blockIdx.x * (kRedThreads / 64) + wv;
+    if (ci >= n_chunks) return;
+    const RangeChunk ch = chunks[ci];
+    const uint32_t tb = tile_base[ch.ref_id];
+    const uint32_t t_end = tile_base[ch.ref_id + 1];
+    const uint32_t row = S * 7;
+    uint32_t any = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        uint32_t nb = 0;
+        uint32_t cc[kMaxThresholds];
+#pragma unroll
+        for (int t = 0; t < kMaxThresholds; ++t) cc[t] = 0;
+        for (uint32_t p = ch.start + lane; p < ch.end; p += 64) {
+            const uint32_t tile = tb + p / T;
+            if (tile >= t_end) continue;
+            const uint32_t slot = slot_of[tile];
+            if (slot == 0xFFFFFFFFu) continue;
+            const uint32_t* c = counters + ((size_t)slot * T + (p & (T - 1))) * row + s * 7;
+            const uint32_t m = c[0] + c[1] + c[2] + c[3] + c[4];
+            const uint32_t cov = m + c[5] + c[6];
+            nb += m;
+            if (span) any |= span[(size_t)slot * T + (p & (T - 1))];
+            else any |= cov;
+#pragma unroll
+            for (int t = 0; t < kMaxThresholds; ++t)
+                if ((uint32_t)t < n_thr && cov >= thresholds[t]) cc[t] += 1;
+        }
+        nb = wave_sum(nb);
+        if (lane == 0 && nb) atomicAdd(&n_bases[(size_t)ch.id * S + s], nb);
+#pragma unroll
+        for (int t = 0; t < kMaxThresholds; ++t) {
+            if ((uint32_t)t < n_thr) {
+                uint32_t v = wave_sum(cc[t]);
+                if (lane == 0 && v) atomicAdd(&cov_counts[((size_t)ch.id * S + s) * n_thr + t], v);
+            }
+        }
+    }
+    const uint64_t am = __ballot(any != 0);
+    if (lane == 0 && am) seen[ch.id] = 1;
+}
+
+// does the read have an M/=/X base with quality >= min_bq at a reference position inside [rs, re)?
+// (countOverlappingBases > 0, depth.d:671-698; zero-length reference-consuming ops occupy one column,
+// and the read ends at d.end, exactly as in K3)
+__device__ bool has_good_base(const uint8_t* U, const RecDesc& d, uint32_t min_bq, int64_t rs, int64_t re) {
+    const uint8_t* rec = U + d.rec_off;
+    const uint8_t* cig = rec + 36 + d.l_name;
+    const uint8_t* seq = cig + 4 * (uint32_t)d.n_cigar;
+    const uint8_t* qual = seq + ((d.l_seq + 1) >> 1);
+    auto run = [&](int64_t rp, uint32_t qp, uint32_t len) -> bool {
+        int64_t a = rs > rp ? rs : rp, b = re < rp + (int64_t)len ? re : rp + (int64_t)len;
+        if (a >= b) return false;
+        uint32_t q0 = qp + (uint32_t)(a - rp), q1 = qp + (uint32_t)(b - rp);
+        if (q1 > d.l_seq) q1 = d.l_seq;
+        if (q0 >= q1) return false;
+        if (min_bq == 0) return true;
+        for (uint32_t q = q0; q < q1; ++q)
+            if (qual[q] >= min_bq) return true;
+        return false;
+    };
+    if (d.kind == 1) return run(d.pos, d.q_start, (uint32_t)(d.end - d.pos));
+    int64_t rp = d.pos;
+    uint32_t qp = 0;
+    for (uint32_t k = 0; k < d.n_cigar; ++k) {
+        uint32_t op = ld32r(cig + 4 * k);
+        uint32_t ty = (kCigarType >> ((op & 15u) * 2u)) & 3u, len = op >> 4;
+        if (ty & 2u) {
+            if (len == 0) len = 1;
+            int64_t room = (int64_t)d.end - rp;
+            if ((int64_t)len > room) len = (uint32_t)(room > 0 ? room : 0);
+        }
+        if (ty == 3) {
+            if (run(rp, qp, len)) return true;
+            rp += len;
+            qp += len;
+        } else if (ty == 2) {
+            rp += len;
+        } else if (ty == 1) {
+            qp += len;
+        }
+        if (rp >= re || rp >= d.end) break;
+    }
+    return false;
+}
+
+// window mode: windows [k*w, (k+1)*w), k < n_win[ref]; id = win_base[ref] + k
+__global__ __launch_bounds__(kRedThreads) void k_count_reads_windows(
+    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, uint64_t n_records, const int32_t* __restrict__ rec_ref,
+    uint32_t window, const uint64_t* __restrict__ win_base, const uint64_t* __restrict__ n_win, uint32_t S, uint32_t min_bq,
+    uint32_t* n_reads /*[id][S]*/) {
+    const uint64_t i = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    if (i >= n_records) return;
+    const RecDesc d = desc[i];
+    if (d.kind == 0) return;
+    const int32_t ref = rec_ref[i];
+    const uint64_t k0 = (uint64_t)d.pos / window, k1 = (uint64_t)(d.end - 1) / window;
+    const uint32_t s = S > 1 ? d.sample : 0u;
+    for (uint64_t k = k0; k <= k1 && k < n_win[ref]; ++k)
+        if (has_good_base(U, d, min_bq, (int64_t)(k * window), (int64_t)((k + 1) * window)))
+            atomicAdd(&n_reads[(size_t)(win_base[ref] + k) * S + s], 1u);
+}
+
+// region mode: regions sorted by (ref, start); pmax_end[j] = max end over the contig's regions 0..j
+__global__ __launch_bounds__(kRedThreads) void k_count_reads_regions(
+    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, uint64_t n_records, const int32_t* __restrict__ rec_ref,
+    const SortedRegion* __restrict__ regs, const uint32_t* __restrict__ pmax_end, const uint32_t* __restrict__ ref_first /*[n_ref+1]*/,
+    uint32_t S, uint32_t min_bq, uint32_t* n_reads /*[id][S]*/) {
+    const uint64_t i = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    if (i >= n_records) return;
+    const RecDesc d = desc[i];
+    if (d.kind == 0) return;
+    const int32_t ref = rec_ref[i];
+    const uint32_t lo0 = ref_first[ref], hi0 = ref_first[ref + 1];
+    if (lo0 >= hi0) return;
+    // last region with start < d.end
+    uint32_t a = lo0, c = hi0;
+    while (a < c) { uint32_t m = (a + c) >> 1; if ((int64_t)regs[m].start < (int64_t)d.end) a = m + 1; else c = m; }
+    const uint32_t s = S > 1 ? d.sample : 0u;
+    for (uint32_t j = a; j > lo0;) {
+        --j;
+        if ((int64_t)pmax_end[j] <= (int64_t)d.pos) break;      // nothing at or before j reaches the read
+        if ((int64_t)regs[j].end > (int64_t)d.pos &&
+            has_good_base(U, d, min_bq, (int64_t)regs[j].start, (int64_t)regs[j].end))
+            atomicAdd(&n_reads[(size_t)regs[j].id * S + s], 1u);
+    }
+}
+
+}  // namespace
+
+void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_counters, const uint32_t* d_span,
+                         const uint32_t* d_slot_of, const uint32_t* d_tile_base, uint32_t T, uint32_t S,
+                         const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases, uint32_t* d_cov_counts,
+                         uint32_t* d_seen, hipStream_t stream) {
+    if (!n_chunks) return;
+    const uint32_t per = kRedThreads / 64;
+    hipLaunchKernelGGL(k_range_reduce, dim3((n_chunks + per - 1) / per), dim3(kRedThreads), 0, stream, d_chunks, n_chunks,
+                       d_counters, d_span, d_slot_of, d_tile_base, T, S, d_thresholds, n_thr, d_n_bases, d_cov_counts, d_seen);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_count_reads_windows(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
+                                uint32_t window, const uint64_t* d_win_base, const uint64_t* d_n_win, uint32_t S,
+                                uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream) {
+    if (!n_records) return;
+    hipLaunchKernelGGL(k_count_reads_windows, dim3((uint32_t)((n_records + kRedThreads - 1) / kRedThreads)), dim3(kRedThreads), 0,
+                       stream, d_U, d_desc, n_records, d_rec_ref, window, d_win_base, d_n_win, S, min_bq, d_n_reads);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
+                                const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first, uint32_t S,
+                                uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream) {
+    if (!n_records) return;
+    hipLaunchKernelGGL(k_count_reads_regions, dim3((uint32_t)((n_records + kRedThreads - 1) / kRedThreads)), dim3(kRedThreads), 0,
+                       stream, d_U, d_desc, n_records, d_rec_ref, d_regs, d_pmax_end, d_ref_first, S, min_bq, d_n_reads);
+    SBX_HIP(hipGetLastError());
+}
+
+}  // namespace sbx

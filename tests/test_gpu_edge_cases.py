@@ -19,7 +19,15 @@ pytestmark = pytest.mark.gpu
 def _check(path, refs, min_bq_list=(0, 20), extra_cli=()):
     import sambamba_amd
     for args in [["base"], ["base", "-c", "0"], ["base", "-q", "20", "-a"]] + [list(a) for a in extra_cli]:
-        assert run_cli(args + [path]) == run_oracle(args + [path]), args
+        got, want = run_cli(args + [path]), run_oracle(args + [path])
+        if got != want:
+            gl, wl = got.decode().splitlines(), want.decode().splitlines()
+            for k in range(max(len(gl), len(wl))):
+                a = gl[k] if k < len(gl) else "<missing>"
+                b = wl[k] if k < len(wl) else "<missing>"
+                if a != b:
+                    raise AssertionError("%s: first difference at line %d:\n  device: %r\n  oracle: %r\n  (%d vs %d lines)" % (
+                        args, k, a, b, len(gl), len(wl)))
     for q in min_bq_list:
         with sambamba_amd.Depth(path) as d:
             d.set_params(min_bq=q)
@@ -46,7 +54,9 @@ def test_cigar_zoo(tmp_path):
         cig = bg.parse_cigar(sh)
         l_seq = sum(n for op, n in cig if op in "MIS=X")
         qual = [rng.choice([2, 12, 23, 37]) for _ in range(l_seq)]
-        recs.append((0 if i < 40 else 1, pos if i < 40 else pos - 2000, sh, _rand_seq(rng, l_seq), qual, "q%d" % i))
+        if i == 40:
+            pos = 3       # second contig starts over near its beginning
+        recs.append((0 if i < 40 else 1, pos, sh, _rand_seq(rng, l_seq), qual, "q%d" % i))
         pos += rng.randint(0, 60)
     recs.sort(key=lambda r: (r[0], r[1]))
     raw = [bg.make_record(r[0], r[1], r[2], r[3], r[4], name=r[5], flag=rng.choice([0, 16, 99, 147])) for r in recs]
