@@ -12,9 +12,12 @@
 //      mapping is ONE LANE PER BGZF BLOCK: 64 independent decoders per wavefront, every VALU
 //      instruction doing useful work in all lanes.  No lookup tables in memory for the code
 //      lengths: the 15 left-justified limits of the literal/length and the distance code live in
-//      VGPRs and the code length is 1 + sum_l (peek >= limit[l]) -- 14 compares, branch-free and
+//      VGPRs (two 16-bit limits per register) and the code length is 1 + sum_l (peek >= limit[l]),
+//      the symbol-index delta sum_l mask_l * ddelta_l -- packed 16-bit VALU ops, branch-free and
 //      identical for every lane.  The per-lane symbol permutations (288 + 32 entries) sit in LDS
-//      at a 105-dword lane stride (odd => conflict-free for equal offsets).  The decoder does NOT
+//      at a 105-dword lane stride (odd => conflict-free for equal offsets), next to a 32-byte ring of
+//      the lane's compressed input that the whole wave tops up in synchronous events, so that the
+//      decode loops never wait on a global load.  The decoder does NOT
 //      touch the LZ77 window: it emits the literal bytes (packed 4 per store) and one 32-bit
 //      entry {literals-before:8, distance-1:15, length:9} per match.  Nothing it loads depends on
 //      anything it stored, so the lane never waits on the LZ77 window's memory latency.
@@ -42,8 +45,8 @@ constexpr int kLaneLds = 420;                // bytes of LDS per lane (105 dword
 constexpr int kLitSymOff = 0;                // u8[288]  low 8 bits of literal/length symbols, canonical order
 constexpr int kLitHiOff = 288;               // u8[36]   bit 8 of those symbols, bit-packed
 constexpr int kDistSymOff = 324;             // u8[32]   distance symbols, canonical order
-constexpr int kLitDeltaOff = 356;            // i16[16]  symbol-index delta per code length (lit/len)
-constexpr int kDistDeltaOff = 388;           // i16[16]  same for distances
+constexpr int kTmpOff = 356;                 // u16[16]  scratch of build_code (counting sort positions)
+constexpr int kRingOff = 388;                // u32[8]   input ring (32 bytes of this lane's compressed payload)
 constexpr int kLensScratch = 320;            // bytes of global scratch per lane: code lengths being built
 
 enum : uint32_t {
@@ -62,6 +65,10 @@ __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// unaligned dword access (byte-aligned pointers: never cast to uint32_t*)
+__device__ __forceinline__ uint32_t ldu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
 // ---- token streams between K1a and K1b -----------------------------------------------------------
 // literal stream of block b: bytes at lit[lit_off(b) ..], 16-byte aligned, capacity isize[b] (+pad)
 // entry stream of block b  : u32 at ent[ent_off(b) ..], capacity isize/3 + isize/255 + 4
@@ -73,10 +80,28 @@ __device__ __forceinline__ uint32_t make_entry(uint32_t lit_run, uint32_t len, u
     return (lit_run << 24) | ((dist - 1) << 9) | len;      // len == 0: literal-run-only entry
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// ---- per-lane input: a 32-byte ring in LDS, refilled by wave-synchronous events --------------------
+// A lane never waits for the word it needs next (it sits in a register, and the word after that is
+// already being read from the LDS ring); the ring itself is topped up 16 bytes at a time by global
+// loads that ALL lanes issue in the same iteration (`service`), and a chunk loaded at one event is
+// only written to the ring at the next one -- so the vmcnt wait the compiler puts in front of that
+// write finds the load long finished, and no other VMEM result is ever consumed in the decode loops.
+constexpr int kLitPerIter = 3;       // literal/length symbols decoded per lane and loop iteration (K1a)
+constexpr int kRingDwords = 8;
+constexpr int kRingLow = 3;          // an event is triggered when some lane has <= this many dwords left
+
 struct BitReader {
-    const uint8_t* cp;    // next 16-byte chunk to prefetch (4-byte aligned)
-    u32x4 cur, nxt;       // words being consumed / prefetched chunk
-    int widx;             // next word of `cur` (0..3)
+    const uint8_t* gp;    // next 16-byte chunk of this lane's payload to fetch from HBM (4-byte aligned)
+    uint32_t* ring;       // this lane's 16-dword ring in LDS
+    u32x4 pend;           // chunk loaded at the previous event, not yet in the ring
+    uint32_t pend_valid;
+    uint32_t rpos;        // ring index of the dword AFTER wnext
+    uint32_t wpos;        // ring index where the next chunk goes (multiple of 4)
+    uint32_t ravail;      // dwords available: wnext + unread ring dwords
+    uint32_t wnext;       // next dword of the stream (already in a register)
     uint64_t buf;
     int cnt;              // valid bits in buf
     uint32_t consumed;    // bits consumed so far (relative to payload start)
@@ -86,32 +111,49 @@ struct BitReader {
         __builtin_memcpy(&v, p, 16);
         return v;
     }
-    __device__ __forceinline__ uint32_t next_word() {
-        uint32_t w = widx == 0 ? cur.x : widx == 1 ? cur.y : widx == 2 ? cur.z : cur.w;
-        if (++widx == 4) {
-            cur = nxt;
-            widx = 0;
-            nxt = load16(cp);
-            cp += 16;
-        }
-        return w;
+    __device__ __forceinline__ void put_chunk(u32x4 v) {
+        ring[wpos] = v.x; ring[wpos + 1] = v.y; ring[wpos + 2] = v.z; ring[wpos + 3] = v.w;
+        wpos = (wpos + 4) & (kRingDwords - 1);
     }
-    __device__ __forceinline__ void init(const uint8_t* p) {
-        int lead = (int)((uintptr_t)p & 3);
+    __device__ __forceinline__ void init(const uint8_t* p, uint32_t* ring_) {
+        ring = ring_;
+        const int lead = (int)((uintptr_t)p & 3);
         const uint8_t* a = p - lead;
-        cur = load16(a);
-        nxt = load16(a + 16);
-        cp = a + 32;
-        widx = 0;
-        uint32_t w0 = next_word();
-        buf = (uint64_t)(w0 >> (8 * lead));
+        wpos = 0;
+        u32x4 c0 = load16(a), c1 = load16(a + 16);
+        put_chunk(c0); put_chunk(c1);
+        pend = load16(a + 32);
+        pend_valid = 1;
+        gp = a + 48;
+        buf = (uint64_t)(ring[0] >> (8 * lead));
         cnt = 32 - 8 * lead;
+        wnext = ring[1];
+        rpos = 2;
+        ravail = kRingDwords - 1;
         consumed = 0;
+    }
+    // wave-synchronous: call with all lanes of the wave converged, once per loop iteration
+    __device__ __forceinline__ void service() {
+        if (__any(ravail <= (uint32_t)kRingLow)) {
+            if (pend_valid && ravail + 4 <= (uint32_t)kRingDwords) {
+                put_chunk(pend);
+                ravail += 4;
+                pend_valid = 0;
+            }
+            if (!pend_valid) {
+                pend = load16(gp);
+                gp += 16;
+                pend_valid = 1;
+            }
+        }
     }
     __device__ __forceinline__ void refill() {   // guarantees cnt > 32 afterwards
         if (cnt <= 32) {
-            buf |= (uint64_t)next_word() << cnt;
+            buf |= (uint64_t)wnext << cnt;
             cnt += 32;
+            wnext = ring[rpos];
+            rpos = (rpos + 1) & (kRingDwords - 1);
+            --ravail;
         }
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); }
@@ -119,26 +161,39 @@ struct BitReader {
     __device__ __forceinline__ uint32_t take(int n) { uint32_t v = peek(n); drop(n); return v; }
 };
 
-// Per-code decode state held in registers: left-justified (15-bit) exclusive upper limits.
-struct Limits {
-    uint32_t lim[16];   // lim[l], l = 1..15 ; lim[0] unused
+// Canonical code held in registers, two 16-bit lanes per VGPR:
+//   lim1[j] = { limit[2j+1] - 1, limit[2j+2] - 1 }   limit[l] = left-justified (15-bit) exclusive upper
+//                                                    bound of the codes of length <= l
+//   dd[j]   = { D[2j+2] - D[2j+1], D[2j+3] - D[2j+2] } (mod 2^16), D[l] = first symbol index of
+//                                                    length l minus first code of length l
+// For the 15-bit prefix v:  mask_l = (v >= limit[l]) ; len = 1 + sum mask_l ; D[len] = D[1] + sum mask_l*dd_l.
+// All of it is packed 16-bit VALU work: no memory, no VCC chains, identical in every lane.
+struct Code {
+    s16x2 lim1[8];
+    u16x2 dd[8];
+    uint32_t d1;
 };
 
-// length of the canonical code whose left-justified 15-bit prefix is v (1..16; 16 = invalid)
-__device__ __forceinline__ int code_length(const Limits& L, uint32_t v) {
-    int len = 1;
+__device__ __forceinline__ void decode_len(const Code& C, uint32_t v, int* len, uint32_t* delta) {
+    const s16x2 vv = {(short)v, (short)v};
+    s16x2 cnt = {0, 0};
+    u16x2 acc = {0, 0};
 #pragma unroll
-    for (int l = 1; l <= 15; ++l) len += (v >= L.lim[l]) ? 1 : 0;
-    return len;
+    for (int j = 0; j < 8; ++j) {
+        const s16x2 m = (C.lim1[j] - vv) >> 15;          // 0xFFFF where v >= limit
+        cnt -= m;
+        acc += (u16x2)m & C.dd[j];
+    }
+    *len = 1 + (int)cnt.x + (int)cnt.y;
+    *delta = (C.d1 + (uint32_t)acc.x + (uint32_t)acc.y) & 0xFFFFu;
 }
 
 // Build one canonical code from `n` code lengths in lens[] (global scratch, 1 byte each): symbol
-// permutation + per-length deltas to LDS, limits to L.  Returns false on an over-subscribed code.
+// permutation to LDS, limits/deltas to registers.  Returns false on an over-subscribed code.
 // (Incomplete codes are accepted, as zlib accepts the single-code distance tree; an unused code
 // decodes as "invalid symbol".)
 template <bool kIsLit>
-__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* lds, Limits& L) {
-    uint16_t* tmp = (uint16_t*)(lds + (kIsLit ? kLitDeltaOff : kDistDeltaOff));
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* lds, uint16_t* tmp, Code& C) {
 #pragma unroll
     for (int l = 0; l < 16; ++l) tmp[l] = 0;
     for (int s = 0; s < n; ++s) tmp[lens[s]] += 1;
@@ -148,18 +203,26 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
     uint32_t first = 0, offs = 0;
     int32_t left = 1;
     bool ok = true;
-    uint32_t firstc[16];
+    uint32_t lim[17], D[18];
 #pragma unroll
     for (int l = 1; l <= 15; ++l) {
         left = (left << 1) - (int32_t)cnt[l];
         if (left < 0) ok = false;
-        firstc[l] = first;
-        L.lim[l] = (first + cnt[l]) << (15 - l);
-        tmp[l] = (uint16_t)offs;            // running insert position during the sort below
+        lim[l] = (first + cnt[l]) << (15 - l);
+        D[l] = offs - first;                   // delta of length l (mod 2^16 is all that matters)
+        tmp[l] = (uint16_t)offs;               // running insert position during the sort below
         offs += cnt[l];
         first = (first + cnt[l]) << 1;
     }
-    L.lim[0] = 0;
+    lim[16] = 32768;                           // sentinel: never reached by a 15-bit prefix
+    D[16] = D[15];
+    D[17] = D[15];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        C.lim1[j] = s16x2{(short)(lim[2 * j + 1] - 1), (short)(lim[2 * j + 2] - 1)};
+        C.dd[j] = u16x2{(unsigned short)(D[2 * j + 2] - D[2 * j + 1]), (unsigned short)(D[2 * j + 3] - D[2 * j + 2])};
+    }
+    C.d1 = D[1] & 0xFFFFu;
     if (!ok) return false;
     if (kIsLit) {
 #pragma unroll
@@ -177,12 +240,6 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
                 lds[kDistSymOff + idx] = (uint8_t)s;
             }
         }
-    }
-    // delta[l] = (start index of length-l symbols) - (first code of length l)
-#pragma unroll
-    for (int l = 1; l <= 15; ++l) {
-        uint32_t start = (uint32_t)tmp[l] - cnt[l];
-        tmp[l] = (uint16_t)(start - firstc[l]);
     }
     return true;
 }
@@ -215,10 +272,14 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     uint8_t* __restrict__ lit_stream, uint32_t* __restrict__ ent_stream, uint32_t* __restrict__ n_entries,
     uint8_t* __restrict__ lens_scratch, uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t b = blockIdx.x * kInfThreads + threadIdx.x;
-    if (b >= n_blocks) return;
+    // Lanes past the last block shadow block n_blocks-1 but stay inactive: every lane of the wave
+    // must take part in the wave-synchronous input service.
+    const uint32_t b_raw = blockIdx.x * kInfThreads + threadIdx.x;
+    const bool live = b_raw < n_blocks;
+    const uint32_t b = live ? b_raw : n_blocks - 1;
     uint8_t* lds = smem + threadIdx.x * kLaneLds;
     uint8_t* lens = lens_scratch + (size_t)b * kLensScratch;
+    uint16_t* tmp = (uint16_t*)(lds + kTmpOff);
 
     const uint8_t* in = comp + comp_off[b];
     const uint32_t in_bits = comp_len[b] * 8u;
@@ -227,182 +288,234 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     uint32_t opos = 0;
     uint32_t err = INF_OK;
 
-    Emitter em;
+    Emitter em;   // (lanes past the last block stay inactive and never emit)
     em.init(lit_stream + lit_off(oo, block0 + b), ent_stream + ent_off(oo, block0 + b));
     BitReader br;
-    br.init(in);
-    Limits LL, LD;
+    br.init(in, (uint32_t*)(lds + kRingOff));
+    Code CL, CD;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) { LL.lim[l] = 0; LD.lim[l] = 0; }
+    for (int j = 0; j < 8; ++j) { CL.lim1[j] = s16x2{0, 0}; CL.dd[j] = u16x2{0, 0}; CD.lim1[j] = s16x2{0, 0}; CD.dd[j] = u16x2{0, 0}; }
+    CL.d1 = CD.d1 = 0;
 
-    bool last = (osize == 0 && comp_len[b] == 0);   // nothing to do for an empty payload
-    while (!last && err == INF_OK) {
-        br.refill();
-        last = br.take(1) != 0;
-        uint32_t btype = br.take(2);
-        if (btype == 0) {
-            // stored block: skip to the byte boundary, LEN, NLEN, raw bytes
+    // The control flow below keeps all 64 lanes inside the same loops (a lane that is done or has
+    // failed idles with `active == false`) so that br.service() is always executed converged.
+    bool active = live && !(osize == 0 && comp_len[b] == 0);   // nothing to do for an empty payload
+    bool last = false;
+    while (__any(active)) {
+        // ---- block header ---------------------------------------------------------------
+        uint32_t btype = 3;
+        if (active) {
+            br.refill();
+            last = br.take(1) != 0;
+            btype = br.take(2);
+            if (btype == 3) { err = INF_BAD_BTYPE; active = false; }
+        }
+        br.service();
+        // stored block: skip to the byte boundary, LEN, NLEN, raw bytes
+        uint32_t stored_left = 0;
+        if (active && btype == 0) {
             br.drop(br.cnt & 7);
             br.refill();
             uint32_t len = br.take(16);
             br.refill();
             uint32_t nlen = br.take(16);
-            if ((len ^ 0xFFFFu) != nlen) { err = INF_BAD_STORED; break; }
-            if (opos + len > osize) { err = INF_OUTPUT_OVERRUN; break; }
-            for (uint32_t i = 0; i < len; ++i) {
+            if ((len ^ 0xFFFFu) != nlen) { err = INF_BAD_STORED; active = false; }
+            else if (opos + len > osize) { err = INF_OUTPUT_OVERRUN; active = false; }
+            else { stored_left = len; opos += len; }
+        }
+        while (__any(stored_left != 0)) {
+            if (stored_left) {
                 br.refill();
                 em.literal(br.take(8));
+                --stored_left;
             }
-            opos += len;
-            continue;
+            br.service();
         }
-        if (btype == 3) { err = INF_BAD_BTYPE; break; }
-        int nlit, ndist;
-        if (btype == 1) {
+        int nlit = 0, ndist = 0;
+        const bool huff = active && btype != 0;
+        if (active && btype == 1) {
             // fixed code (RFC 1951 3.2.6)
             for (int s = 0; s < 288; ++s) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
             for (int s = 0; s < 30; ++s) lens[288 + s] = 5;
             nlit = 288;
             ndist = 30;
-        } else {
+        }
+        // dynamic code: code-length code, then nlit + ndist lengths
+        uint32_t ccnt[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) ccnt[l] = 0;
+        uint8_t* cl_len = lds + kDistSymOff;   // [19] parked in the symbol areas (rebuilt below)
+        uint8_t* cl_sym = lds + kLitSymOff;    // [19] symbols sorted by (length, value)
+        int ncl_left = 0, cl_i = 0;
+        bool dyn = active && btype == 2;
+        if (dyn) {
             br.refill();
             nlit = (int)br.take(5) + 257;
             ndist = (int)br.take(5) + 1;
-            int ncl = (int)br.take(4) + 4;
-            if (nlit > 286 || ndist > 30) { err = INF_BAD_CODELENS; break; }
-            // code-length code: 19 symbols, 3-bit lengths, in the RFC's permuted order.  Its
-            // lengths (19 bytes) and canonical symbol order (19 bytes) are parked in the lane's
-            // LDS symbol areas, which are rebuilt right after the header anyway.
-            uint8_t* cl_len = lds + kDistSymOff;   // [19]
-            uint8_t* cl_sym = lds + kLitSymOff;    // [19] symbols sorted by (length, value)
+            ncl_left = (int)br.take(4) + 4;
+            if (nlit > 286 || ndist > 30) { err = INF_BAD_CODELENS; active = false; dyn = false; ncl_left = 0; }
             for (int s = 0; s < 19; ++s) cl_len[s] = 0;
-            for (int i = 0; i < ncl; ++i) {
+        }
+        while (__any(ncl_left != 0)) {
+            if (ncl_left) {
                 br.refill();
-                cl_len[kClOrder[i]] = (uint8_t)br.take(3);
+                cl_len[kClOrder[cl_i++]] = (uint8_t)br.take(3);
+                --ncl_left;
             }
-            uint32_t ccnt[8];
+            br.service();
+        }
+        if (dyn) {
+            int k = 0;
+            for (int l = 1; l <= 7; ++l)
+                for (int s2 = 0; s2 < 19; ++s2)
+                    if (cl_len[s2] == l) cl_sym[k++] = (uint8_t)s2;
+            for (int s2 = 0; s2 < 19; ++s2) {
+                uint32_t l = cl_len[s2];
 #pragma unroll
-            for (int l = 0; l < 8; ++l) ccnt[l] = 0;
-            {
-                int k = 0;
-                for (int l = 1; l <= 7; ++l)
-                    for (int s2 = 0; s2 < 19; ++s2)
-                        if (cl_len[s2] == l) cl_sym[k++] = (uint8_t)s2;
-                for (int s2 = 0; s2 < 19; ++s2) {
-                    uint32_t l = cl_len[s2];
-#pragma unroll
-                    for (int q = 1; q < 8; ++q) ccnt[q] += (l == (uint32_t)q) ? 1u : 0u;
-                }
-                int32_t left = 1;
-                bool ok = true;
-#pragma unroll
-                for (int l = 1; l <= 7; ++l) { left = (left << 1) - (int32_t)ccnt[l]; if (left < 0) ok = false; }
-                if (!ok) { err = INF_BAD_CODELENS; break; }
+                for (int q = 1; q < 8; ++q) ccnt[q] += (l == (uint32_t)q) ? 1u : 0u;
             }
-            // decode nlit + ndist code lengths
+            int32_t left = 1;
+            bool ok = true;
+#pragma unroll
+            for (int l = 1; l <= 7; ++l) { left = (left << 1) - (int32_t)ccnt[l]; if (left < 0) ok = false; }
+            if (!ok) { err = INF_BAD_CODELENS; active = false; dyn = false; }
+        }
+        {
             int i = 0;
             uint32_t prev = 0;
             const int total = nlit + ndist;
-            while (i < total && err == INF_OK) {
-                br.refill();
-                // canonical walk over lengths 1..7 with the counts in registers
-                uint32_t code = 0, first = 0, index = 0, sym = 0xFFFFFFFFu;
-                int used = 0;
+            bool more = dyn;
+            while (__any(more)) {
+                if (more) {
+                    br.refill();
+                    // canonical walk over lengths 1..7 with the counts in registers
+                    uint32_t code = 0, first = 0, index = 0, sym = 0xFFFFFFFFu;
+                    int used = 0;
 #pragma unroll
-                for (int l = 1; l <= 7; ++l) {
-                    code |= (uint32_t)(br.buf >> (l - 1)) & 1u;
-                    uint32_t c = ccnt[l];
-                    if (used == 0 && code < first + c) {
-                        sym = cl_sym[index + (code - first)];
-                        used = l;
+                    for (int l = 1; l <= 7; ++l) {
+                        code |= (uint32_t)(br.buf >> (l - 1)) & 1u;
+                        uint32_t c = ccnt[l];
+                        if (used == 0 && code < first + c) {
+                            sym = cl_sym[index + (code - first)];
+                            used = l;
+                        }
+                        index += c;
+                        first = (first + c) << 1;
+                        code <<= 1;
                     }
-                    index += c;
-                    first = (first + c) << 1;
-                    code <<= 1;
-                }
-                if (sym >= 19) { err = INF_BAD_CODELENS; break; }
-                br.drop(used);
-                if (sym < 16) {
-                    lens[i++] = (uint8_t)sym;
-                    prev = sym;
-                } else {
-                    uint32_t rep, val;
-                    if (sym == 16) {
-                        if (i == 0) { err = INF_BAD_CODELENS; break; }
-                        val = prev;
-                        rep = 3 + br.take(2);
-                    } else if (sym == 17) {
-                        val = 0;
-                        rep = 3 + br.take(3);
-                    } else {
-                        val = 0;
-                        rep = 11 + br.take(7);
+                    if (sym >= 19) { err = INF_BAD_CODELENS; more = false; }
+                    else {
+                        br.drop(used);
+                        if (sym < 16) {
+                            lens[i++] = (uint8_t)sym;
+                            prev = sym;
+                        } else {
+                            uint32_t rep, val;
+                            if (sym == 16) { val = prev; rep = 3 + br.take(2); if (i == 0) { err = INF_BAD_CODELENS; more = false; rep = 0; } }
+                            else if (sym == 17) { val = 0; rep = 3 + br.take(3); }
+                            else { val = 0; rep = 11 + br.take(7); }
+                            if (i + (int)rep > total) { err = INF_BAD_CODELENS; more = false; }
+                            else {
+                                for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
+                                prev = val;   // (after 17/18 a following 16 repeats 0, as in zlib)
+                            }
+                        }
+                        if (i >= total) more = false;
                     }
-                    if (i + (int)rep > total) { err = INF_BAD_CODELENS; break; }
-                    for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
-                    prev = val;   // (after 17/18 a following 16 repeats 0, as in zlib)
                 }
+                br.service();
             }
-            if (err != INF_OK) break;
-            if (lens[256] == 0) { err = INF_BAD_CODELENS; break; }   // no end-of-block code
+            if (dyn && err == INF_OK && lens[256] == 0) err = INF_BAD_CODELENS;   // no end-of-block code
+            if (err != INF_OK) active = false;
         }
-        if (!build_code<true>(lens, nlit, lds, LL)) { err = INF_BAD_CODELENS; break; }
-        if (!build_code<false>(lens + nlit, ndist, lds, LD)) { err = INF_BAD_CODELENS; break; }
-        const int16_t* ldelta = (const int16_t*)(lds + kLitDeltaOff);
-        const int16_t* ddelta = (const int16_t*)(lds + kDistDeltaOff);
+        bool sym_loop = huff && active;
+        if (sym_loop) {
+            if (!build_code<true>(lens, nlit, lds, tmp, CL)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
+            else if (!build_code<false>(lens + nlit, ndist, lds, tmp, CD)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
+        }
 
         // ---- symbol loop -----------------------------------------------------------------
-        for (;;) {
-            br.refill();
-            uint32_t v = __brev(br.peek(15)) >> 17;
-            int len = code_length(LL, v);
-            if (len > 15) { err = INF_BAD_SYMBOL; break; }
-            uint32_t idx = (uint32_t)((int32_t)ldelta[len] + (int32_t)(v >> (15 - len))) & 0x1FFu;
-            if (idx >= 288) { err = INF_BAD_SYMBOL; break; }
-            uint32_t sym = (uint32_t)lds[kLitSymOff + idx] | (((uint32_t)lds[kLitHiOff + (idx >> 3)] >> (idx & 7)) & 1u) << 8;
-            br.drop(len);
-            if (sym < 256) {
-                if (opos >= osize) { err = INF_OUTPUT_OVERRUN; break; }
-                ++opos;
-                em.literal(sym);
-                continue;
+        // Under SIMT the (long) match path is paid by the whole wave in every iteration in which any
+        // lane has a match, so each iteration first decodes up to kLitPerIter literal/length symbols
+        // per lane -- literals are emitted on the spot, the first length symbol (or end-of-block) stops
+        // the lane's run -- and then handles at most one match per lane.
+        while (__any(sym_loop)) {
+            uint32_t msym = 0;          // pending length symbol (257..285) of this lane, 0 = none
+            uint32_t bad = INF_OK;
+#pragma unroll
+            for (int r = 0; r < kLitPerIter; ++r) {
+                if (sym_loop && msym == 0 && bad == INF_OK) {
+                    br.refill();
+                    const uint32_t v = __brev(br.peek(15)) >> 17;
+                    int len;
+                    uint32_t delta;
+                    decode_len(CL, v, &len, &delta);
+                    const int lc = len > 15 ? 15 : len;
+                    uint32_t idx = (delta + (v >> (15 - lc))) & 0x1FFu;
+                    if (len > 15 || idx >= 288) bad = INF_BAD_SYMBOL;
+                    if (idx > 287) idx = 287;
+                    const uint32_t sym = (uint32_t)lds[kLitSymOff + idx] | (((uint32_t)lds[kLitHiOff + (idx >> 3)] >> (idx & 7)) & 1u) << 8;
+                    br.drop(lc);
+                    if (bad == INF_OK) {
+                        if (sym < 256) {
+                            if (opos >= osize) bad = INF_OUTPUT_OVERRUN;
+                            else { ++opos; em.literal(sym); }
+                        } else if (sym == 256) {
+                            sym_loop = false;
+                        } else if (sym > 285) {
+                            bad = INF_BAD_SYMBOL;
+                        } else {
+                            msym = sym;
+                        }
+                    }
+                }
             }
-            if (sym == 256) break;
-            if (sym > 285) { err = INF_BAD_SYMBOL; break; }
-            // match length (RFC 1951 3.2.5), computed arithmetically
-            uint32_t mlen;
-            if (sym < 265) mlen = sym - 254;
-            else if (sym == 285) mlen = 258;
-            else {
-                uint32_t e = (sym - 261) >> 2;
-                mlen = ((4 + ((sym - 261) & 3)) << e) + 3 + br.take((int)e);
+            if (msym != 0) {
+                // match length (RFC 1951 3.2.5), computed arithmetically
+                uint32_t mlen;
+                if (msym < 265) mlen = msym - 254;
+                else if (msym == 285) mlen = 258;
+                else {
+                    const uint32_t e = (msym - 261) >> 2;
+                    br.refill();
+                    mlen = ((4 + ((msym - 261) & 3)) << e) + 3 + br.take((int)e);
+                }
+                br.refill();
+                const uint32_t dv = __brev(br.peek(15)) >> 17;
+                int dl;
+                uint32_t ddelta;
+                decode_len(CD, dv, &dl, &ddelta);
+                const int dc = dl > 15 ? 15 : dl;
+                uint32_t didx = (ddelta + (dv >> (15 - dc))) & 0x1FFu;
+                if (dl > 15 || didx >= 30) bad = INF_BAD_DISTANCE;
+                if (didx > 31) didx = 31;
+                const uint32_t dsym = lds[kDistSymOff + didx];
+                br.drop(dc);
+                if (dsym > 29) bad = INF_BAD_DISTANCE;
+                uint32_t dist;
+                if (dsym < 4) dist = dsym + 1;
+                else {
+                    const uint32_t e = ((dsym >> 1) - 1) & 15u;
+                    dist = ((2 + (dsym & 1)) << e) + 1 + br.take((int)e);
+                }
+                if (bad == INF_OK) {
+                    if (dist > opos) bad = INF_BAD_DISTANCE;
+                    else if (opos + mlen > osize) bad = INF_OUTPUT_OVERRUN;
+                    else { opos += mlen; em.match(mlen, dist); }
+                }
             }
-            br.refill();
-            uint32_t dv = __brev(br.peek(15)) >> 17;
-            int dl = code_length(LD, dv);
-            if (dl > 15) { err = INF_BAD_DISTANCE; break; }
-            uint32_t didx = (uint32_t)((int32_t)ddelta[dl] + (int32_t)(dv >> (15 - dl))) & 0x1FFu;
-            if (didx >= 30) { err = INF_BAD_DISTANCE; break; }
-            uint32_t dsym = lds[kDistSymOff + didx];
-            br.drop(dl);
-            if (dsym > 29) { err = INF_BAD_DISTANCE; break; }
-            uint32_t dist;
-            if (dsym < 4) dist = dsym + 1;
-            else {
-                uint32_t e = (dsym >> 1) - 1;
-                dist = ((2 + (dsym & 1)) << e) + 1 + br.take((int)e);
-            }
-            if (dist > opos) { err = INF_BAD_DISTANCE; break; }
-            if (opos + mlen > osize) { err = INF_OUTPUT_OVERRUN; break; }
-            opos += mlen;
-            em.match(mlen, dist);
+            if (bad != INF_OK) { err = bad; active = false; sym_loop = false; }
+            br.service();
         }
+        if (active && last) active = false;
     }
     em.finish();
     if (err == INF_OK && opos != osize) err = INF_SIZE_MISMATCH;
     if (err == INF_OK && br.consumed > in_bits) err = INF_INPUT_OVERRUN;
-    status[b] = err;
-    n_entries[b] = em.n_ent;
+    if (live) {
+        status[b] = err;
+        n_entries[b] = em.n_ent;
+    }
 }
 
 // ---- K1b -----------------------------------------------------------------------------------------
@@ -417,7 +530,28 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-__global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
+// copy n bytes (n >= 4) as unaligned dwords, the last one overlapping: exact, never writes outside [d, d+n)
+__device__ __forceinline__ void copy_dwords(uint8_t* d, const uint8_t* s, uint32_t n) {
+    uint32_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = ldu32(s + i + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stu32(d + i + 4 * k, w[k]);
+    }
+    uint32_t w[8];
+    const uint32_t rem = n - i, nf = rem >> 2;   // rem < 32
+    uint32_t wt = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) if ((uint32_t)k < nf) w[k] = ldu32(s + i + 4 * k);
+    if (rem & 3u) wt = ldu32(s + n - 4);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) if ((uint32_t)k < nf) stu32(d + i + 4 * k, w[k]);
+    if (rem & 3u) stu32(d + n - 4, wt);
+}
+
+__global__ __launch_bounds__(kResThreads, 6) void k_lz77_resolve(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
     uint8_t* out, const uint32_t* __restrict__ status) {
@@ -433,10 +567,11 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
     const uint32_t ne = n_entries[b];
     uint32_t opos = 0, lpos = 0;   // wave-uniform running positions
     uint32_t* end_arr = s_end[wv];
-    const uint32_t grp = lane >> 3, k8 = lane & 7u;
 
+    uint32_t e_next = lane < ne ? ent[lane] : 0u;
     for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
-        const uint32_t e = (e0 + lane < ne) ? ent[e0 + lane] : 0u;
+        const uint32_t e = e_next;
+        e_next = (e0 + 64 + lane < ne) ? ent[e0 + 64 + lane] : 0u;      // prefetch the next batch of entries
         const uint32_t lr = e >> 24, len = e & 511u, dist = ((e >> 9) & 0x7FFFu) + 1u;
         const uint32_t tot = lr + len;
         const uint32_t incl = wave_incl_scan(tot, lane);
@@ -446,12 +581,13 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
         const uint32_t dst = eo + lr;                 // first byte of the match
         const uint32_t src = dst - dist;
         end_arr[lane] = eo + tot;
-        // ---- literal runs: 8 lanes per entry, no dependencies (source = literal stream) ----
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int x = g * 8 + (int)grp;
-            const uint32_t lr_x = __shfl(lr, x, 64), eo_x = __shfl(eo, x, 64), el_x = __shfl(el, x, 64);
-            for (uint32_t kk = k8; kk < lr_x; kk += 8) o[eo_x + kk] = lit[el_x + kk];
+        // ---- literal run of my entry (source = literal stream: no dependencies) ----------
+        if (lr >= 4) copy_dwords(o + eo, lit + el, lr);
+        else if (lr) {
+            const uint8_t a0 = lit[el], a1 = lr > 1 ? lit[el + 1] : 0, a2 = lr > 2 ? lit[el + 2] : 0;
+            o[eo] = a0;
+            if (lr > 1) o[eo + 1] = a1;
+            if (lr > 2) o[eo + 2] = a2;
         }
         // ---- which earlier entries of this batch does my source range touch? -------------
         // entry i occupies [end[i-1], end[i]); ends are non-decreasing.  lo = lowest i with
@@ -473,39 +609,25 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
             }
             if (hi > lo) dep = (hi - lo >= 64 ? ~0ULL : ((1ULL << (hi - lo)) - 1ULL)) << lo;
         }
-        // ---- match rounds ---------------------------------------------------------------
+        // ---- match rounds: every ready lane copies its own match -------------------------
         uint64_t pending = __ballot(len != 0);
         while (pending) {
             const bool ready = len != 0 && ((pending >> lane) & 1ULL) && (dep & pending) == 0ULL;
             const uint64_t rmask = __ballot(ready);
-            // 8 lanes per entry; byte k of a match is out[src + k mod dist] (periodic extension:
-            // every byte of an entry only depends on bytes before the entry)
-            uint32_t v0[8], v1[8];
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int x = g * 8 + (int)grp;
-                const uint32_t len_x = __shfl(len, x, 64), src_x = __shfl(src, x, 64), dist_x = __shfl(dist, x, 64);
-                const bool on = (rmask >> x) & 1ULL;
-                v0[g] = 0; v1[g] = 0;
-                if (on && k8 < len_x) v0[g] = o[src_x + (k8 < dist_x ? k8 : k8 % dist_x)];
-                if (on && k8 + 8 < len_x) v1[g] = o[src_x + (k8 + 8 < dist_x ? k8 + 8 : (k8 + 8) % dist_x)];
-            }
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int x = g * 8 + (int)grp;
-                const uint32_t len_x = __shfl(len, x, 64), dst_x = __shfl(dst, x, 64);
-                const bool on = (rmask >> x) & 1ULL;
-                if (on && k8 < len_x) o[dst_x + k8] = (uint8_t)v0[g];
-                if (on && k8 + 8 < len_x) o[dst_x + k8 + 8] = (uint8_t)v1[g];
-            }
-            // tails of long matches (> 16 bytes)
-            uint64_t lm = __ballot(ready && len > 16);
-            while (lm) {
-                const int x = __builtin_ctzll(lm);
-                lm &= lm - 1;
-                const uint32_t len_x = __shfl(len, x, 64), src_x = __shfl(src, x, 64), dist_x = __shfl(dist, x, 64),
-                               dst_x = __shfl(dst, x, 64);
-                for (uint32_t kk = 16 + lane; kk < len_x; kk += 64) o[dst_x + kk] = o[src_x + (kk < dist_x ? kk : kk % dist_x)];
+            if (ready) {
+                uint8_t* d = o + dst;
+                const uint8_t* sp = o + src;
+                if (dist >= len) {
+                    if (len >= 4) copy_dwords(d, sp, len);
+                    else { const uint8_t a0 = sp[0], a1 = sp[1], a2 = sp[2]; d[0] = a0; d[1] = a1; d[2] = a2; }   // len == 3
+                } else {
+                    // self-overlapping match: byte k is src[k mod dist] (all inside [src, dst), final)
+                    uint32_t m = 0;
+                    for (uint32_t k = 0; k < len; ++k) {
+                        d[k] = sp[m];
+                        if (++m == dist) m = 0;
+                    }
+                }
             }
             pending &= ~rmask;
         }
