@@ -204,6 +204,23 @@ class Depth:
         self._check(self._L.sbx_last_run_stats(self._ctx, C.byref(st)))
         return st.as_dict()
 
+    def region_stats(self, regions, n_thresholds=0):
+        """sbx_depth_region_stats: returns (n_reads[n][S], n_bases[n][S], cov[n][S][n_thr], seen[n])."""
+        n, S = len(regions), self.n_samples_eff
+        arr = (Region * max(1, n))(*[Region(*r) for r in regions])
+        st = np.zeros((n, S, 2), dtype=np.uint32)
+        cov = np.zeros((n, S, max(1, n_thresholds)), dtype=np.uint32)
+        seen = np.zeros(n, dtype=np.uint8)
+        self._check(self._L.sbx_depth_region_stats(self._ctx, arr, n, st.ctypes.data, cov.ctypes.data, seen.ctypes.data))
+        return st[:, :, 0].copy(), st[:, :, 1].copy(), cov[:, :, :n_thresholds].copy(), seen
+
+    def window_stats(self, ref_id, first, count, n_thresholds=0):
+        S = self.n_samples_eff
+        st = np.zeros((count, S, 2), dtype=np.uint32)
+        cov = np.zeros((count, S, max(1, n_thresholds)), dtype=np.uint32)
+        self._check(self._L.sbx_depth_window_stats(self._ctx, ref_id, first, count, st.ctypes.data, cov.ctypes.data))
+        return st[:, :, 0].copy(), st[:, :, 1].copy(), cov[:, :, :n_thresholds].copy()
+
     def base_counters(self, ref_id, beg, end, with_covered=False):
         S = self.n_samples_eff
         out = np.zeros((end - beg, S, NCOUNTERS), dtype=np.uint32)

@@ -358,17 +358,63 @@ int sbx_run(sbx_ctx* c) {
         upload_tables(c);
         upload_file(c);
         if (c->stats.ms_h2d == 0) c->stats.ms_h2d = ms_h2d;
-        const uint32_t nb = (uint32_t)c->blocks.size();
-        const uint64_t total = c->blocks.out_off.back();
+        const uint32_t nb_file = (uint32_t)c->blocks.size();
+        const uint64_t total_file = c->blocks.out_off.back();
+        // ---- work list: the whole file, or (with -L) the contiguous run of BGZF blocks that holds every
+        // BAI chunk of the requested regions (RandomAccessManager.getGroupChunks, randomaccessmanager.d:247-294;
+        // chunk boundaries are record boundaries, so the record chain of the sub-stream is exact).  Records of
+        // the run that lie outside the regions cannot change any reported number.
+        uint32_t blk0 = 0, blk1 = nb_file;
+        uint64_t first_off = c->hdr.first_record_off, total = total_file;
+        if (!c->regions.empty()) {
+            std::vector<sbx_region> regs = c->regions;
+            std::sort(regs.begin(), regs.end(), [](const sbx_region& a, const sbx_region& b) {
+                if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+                if (a.start != b.start) return a.start < b.start;
+                return a.end < b.end;
+            });
+            uint64_t vbeg = ~0ull, vend = 0;
+            for (size_t i = 0; i < regs.size();) {
+                size_t j = i;
+                std::vector<sbx_region> group;
+                while (j < regs.size() && regs[j].ref_id == regs[i].ref_id) {
+                    if (!group.empty() && group.back().end >= regs[j].start) group.back().end = std::max(group.back().end, regs[j].end);
+                    else group.push_back(regs[j]);
+                    ++j;
+                }
+                if (regs[i].ref_id < c->bai.refs.size())
+                    for (auto& ch : group_chunks(c->bai, group)) { vbeg = std::min(vbeg, ch.beg); vend = std::max(vend, ch.end); }
+                i = j;
+            }
+            auto to_u = [&](uint64_t v, uint32_t* blk) -> uint64_t {   // virtual offset -> offset in the inflated stream
+                uint64_t co = v >> 16, uo = v & 0xFFFF;
+                size_t bi = (size_t)(std::lower_bound(c->blocks.coffset.begin(), c->blocks.coffset.end(), co) - c->blocks.coffset.begin());
+                if (bi >= nb_file) { *blk = nb_file; return total_file; }     // at / beyond the EOF block
+                if (c->blocks.coffset[bi] != co) throw Error(SBX_EFORMAT, "BAI virtual offset does not point at a BGZF block");
+                *blk = (uint32_t)bi;
+                return c->blocks.out_off[bi] + uo;
+            };
+            if (vbeg >= vend) { blk0 = blk1 = 0; first_off = total = c->hdr.first_record_off; }
+            else {
+                uint32_t bb = 0, be = 0;
+                uint64_t ub = to_u(vbeg, &bb), ue = to_u(vend, &be);
+                first_off = std::max(ub, c->hdr.first_record_off);
+                total = std::max(first_off, std::min(ue, total_file));
+                blk0 = bb;
+                blk1 = (be < nb_file && total > c->blocks.out_off[be]) ? be + 1 : be;
+                if (blk1 < blk0) blk1 = blk0;
+            }
+        }
+        const uint32_t nb = blk1 - blk0;
         EventTimer t_all, t1, t1m, t2, t3;
         t_all.start(s);
 
         // ---- K1 ----
-        c->d_U.ensure(total + 64);
+        c->d_U.ensure(total_file + 64);
         t1.start(s);
-        inflate_blocks(c, 0, nb, t1m.b);
+        inflate_blocks(c, blk0, blk1, t1m.b);
         t1.stop(s);
-        check_inflate_status(c, 0, nb);
+        check_inflate_status(c, blk0, blk1);
 
         // ---- K2 ----
         const int32_t n_ref = (int32_t)c->hdr.refs.size();
@@ -408,7 +454,7 @@ int sbx_run(sbx_ctx* c) {
         };
         lap("start-index");
         t2.start(s);
-        launch_block_walk(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, refs, c->d_entry.p,
+        launch_block_walk(c->d_U.p, total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, refs, c->d_entry.p,
                           c->d_exit.p, c->d_count.p, s);
         lap("block_walk");
         uint32_t verify_iters = 0;   // number of blocks whose guessed entry had to be re-walked
@@ -421,14 +467,14 @@ int sbx_run(sbx_ctx* c) {
             for (int round = 0;; ++round) {
                 uint32_t first_bad = 0xFFFFFFFFu;
                 SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 4, s));
-                launch_chain_check(c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, c->d_entry.p, c->d_exit.p, c->d_flag.p, s);
+                launch_chain_check(c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, c->d_entry.p, c->d_exit.p, c->d_flag.p, s);
                 SBX_HIP(hipMemcpyAsync(&first_bad, c->d_flag.p, 4, hipMemcpyDeviceToHost, s));
                 SBX_HIP(hipStreamSynchronize(s));
                 bool forced = false;
                 if (force && round == 0) { uint32_t f = (uint32_t)atoi(force); if (f < first_bad && f < nb) { first_bad = f; forced = true; } }
                 if (first_bad == 0xFFFFFFFFu || first_bad >= nb) break;
                 const bool to_the_end = forced || round >= 16;
-                launch_chain_repair(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->hdr.first_record_off, first_bad,
+                launch_chain_repair(c->d_U.p, total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, first_bad,
                                     !to_the_end, c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_flag.p + 1, s);
                 if (round > 64) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
             }
@@ -444,43 +490,19 @@ int sbx_run(sbx_ctx* c) {
             SBX_HIP(hipMemcpy(hc.data(), c->d_count.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
             uint64_t bad = 0, first = ~0ull, passthru = 0, sum = 0;
             for (uint32_t b = 0; b < nb; ++b) {
-                uint64_t end = c->blocks.out_off[b] + c->blocks.isize[b];
-                uint64_t want = b ? hx[b - 1] : c->hdr.first_record_off;
+                uint64_t end = c->blocks.out_off[blk0 + b] + c->blocks.isize[blk0 + b];
+                uint64_t want = b ? hx[b - 1] : first_off;
                 sum += hc[b];
-                if (end <= c->hdr.first_record_off) continue;
+                if (end <= first_off) continue;
                 if (he[b] >= end) ++passthru;
                 if (he[b] != want) { ++bad; if (first == ~0ull) first = b; }
             }
             fprintf(stderr, "[sbx]   chain: inconsistent=%llu first=%lld passthrough=%llu sum_count=%llu\n", (unsigned long long)bad,
                     (long long)first, (unsigned long long)passthru, (unsigned long long)sum);
-            for (uint32_t b = 1; b < nb; ++b) {
-                uint64_t end = c->blocks.out_off[b] + c->blocks.isize[b];
-                if (end <= c->hdr.first_record_off || he[b] < end) continue;
-                uint32_t q = b - 1;
-                fprintf(stderr, "[sbx]   first passthrough block %u entry=%llu end=%llu | prev: entry=%llu exit=%llu count=%u beg=%llu isize=%u total=%llu\n",
-                        b, (unsigned long long)he[b], (unsigned long long)end, (unsigned long long)he[q], (unsigned long long)hx[q], hc[q],
-                        (unsigned long long)c->blocks.out_off[q], c->blocks.isize[q], (unsigned long long)total);
-                // walk block q on the host
-                std::vector<uint8_t> buf(c->blocks.isize[q] + 65536 + 64);
-                uint64_t beg = c->blocks.out_off[q];
-                size_t nbytes = (size_t)std::min<uint64_t>(buf.size(), total - beg);
-                SBX_HIP(hipMemcpy(buf.data(), c->d_U.p + beg, nbytes, hipMemcpyDeviceToHost));
-                uint64_t o = he[q];
-                int k = 0;
-                while (o < beg + c->blocks.isize[q] && o - beg + 4 <= nbytes && k < 400) {
-                    int32_t bs; memcpy(&bs, buf.data() + (o - beg), 4);
-                    int32_t pos; memcpy(&pos, buf.data() + (o - beg) + 8, 4);
-                    if (k < 3 || bs < 32 || bs > 1000) fprintf(stderr, "[sbx]     rec %d at %llu bs=%d pos=%d\n", k, (unsigned long long)o, bs, pos);
-                    if (bs < 32) break;
-                    o += 4 + (uint64_t)bs; ++k;
-                }
-                fprintf(stderr, "[sbx]     host walk: %d records, exit=%llu\n", k, (unsigned long long)o);
-                break;
-            }
             if (first != ~0ull)
                 fprintf(stderr, "[sbx]   block %llu: entry=%llu want=%llu exit=%llu count=%u beg=%llu\n", (unsigned long long)first,
                         (unsigned long long)he[first], (unsigned long long)(first ? hx[first - 1] : 0), (unsigned long long)hx[first],
-                        hc[first], (unsigned long long)c->blocks.out_off[first]);
+                        hc[first], (unsigned long long)c->blocks.out_off[blk0 + first]);
         }
         if (nb) {
             // the chain must end exactly at the end of the stream
@@ -525,7 +547,7 @@ int sbx_run(sbx_ctx* c) {
         c->d_stats.ensure(1);
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
         lap("scan+setup");
-        launch_describe(c->d_U.p, total, c->d_out_off.p, c->d_isize.p, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
+        launch_describe(c->d_U.p, total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
                         T, c->d_desc.p, c->d_rec_ref.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_stats.p, s);
         lap("describe");
         launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
@@ -575,8 +597,8 @@ int sbx_run(sbx_ctx* c) {
         c->stats.n_records = ist.n_records;
         c->stats.n_admitted = ist.n_admitted;
         c->stats.n_bgzf_blocks = nb;
-        c->stats.compressed_bytes = c->file.size;
-        c->stats.uncompressed_bytes = total;
+        c->stats.compressed_bytes = nb == nb_file ? c->file.size : (nb ? c->blocks.coffset[blk1 - 1] - c->blocks.coffset[blk0] + c->blocks.comp_len[blk1 - 1] + 26 : 0);
+        c->stats.uncompressed_bytes = nb ? c->blocks.out_off[blk1] - c->blocks.out_off[blk0] : 0;
         c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4;
         c->stats.covered_positions = (uint64_t)n_active * T;
         c->stats.launches_inflate = 1;

@@ -70,11 +70,11 @@ __device__ __forceinline__ uint32_t ldu32(const uint8_t* p) { uint32_t v; __buil
 __device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
 // ---- token streams between K1a and K1b -----------------------------------------------------------
-// literal stream of block b: bytes at lit[lit_off(b) ..], 16-byte aligned, capacity isize[b] (+pad)
-// entry stream of block b  : u32 at ent[ent_off(b) ..], capacity isize/3 + isize/255 + 4
+// literal stream of block b: bytes at lit[lit_off(b) ..], 16-byte aligned, capacity isize[b] rounded up to 16
+// entry stream of block b  : u32 at ent[ent_off(b) ..], 16-byte aligned, capacity isize/3 + isize/255 + 7
 // Both offsets are pure functions of (out_off[b], b) so that no extra table is needed.
-__host__ __device__ __forceinline__ uint64_t lit_off(uint64_t out_off_b, uint32_t b) { return (out_off_b + 16ull * b + 15ull) & ~15ull; }
-__host__ __device__ __forceinline__ uint64_t ent_off(uint64_t out_off_b, uint32_t b) { return out_off_b / 3 + out_off_b / 255 + 8ull * b; }
+__host__ __device__ __forceinline__ uint64_t lit_off(uint64_t out_off_b, uint32_t b) { return (out_off_b + 32ull * b + 15ull) & ~15ull; }
+__host__ __device__ __forceinline__ uint64_t ent_off(uint64_t out_off_b, uint32_t b) { return (out_off_b / 3 + out_off_b / 255 + 12ull * b + 3ull) & ~3ull; }
 
 __device__ __forceinline__ uint32_t make_entry(uint32_t lit_run, uint32_t len, uint32_t dist) {
     return (lit_run << 24) | ((dist - 1) << 9) | len;      // len == 0: literal-run-only entry
@@ -244,25 +244,54 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
     return true;
 }
 
-// Token emitter of one lane (K1a): literal bytes packed four per store, one u32 per match.
+// Token emitter of one lane (K1a).  Scattered 4-byte stores from 64 lanes are 64 partial-line write
+// requests each; the emitter therefore keeps the last 16 literal bytes and the last 4 match entries in
+// registers (byte / dword shift registers) and writes both streams with aligned 16-byte stores only.
 struct Emitter {
     uint8_t* lit;         // 16-byte aligned literal stream of this block
-    uint32_t* ent;
-    uint32_t n_lit, n_ent, acc, run;
-    __device__ __forceinline__ void init(uint8_t* l, uint32_t* e) { lit = l; ent = e; n_lit = n_ent = acc = run = 0; }
+    uint32_t* ent;        // 16-byte aligned entry stream of this block
+    u32x4 la, ea;
+    uint32_t n_lit, n_ent, run;
+    __device__ __forceinline__ static void store16(void* p, u32x4 v) { *(u32x4*)p = v; }
+    __device__ __forceinline__ void init(uint8_t* l, uint32_t* e) {
+        lit = l; ent = e; n_lit = n_ent = run = 0;
+        la = u32x4{0, 0, 0, 0};
+        ea = u32x4{0, 0, 0, 0};
+    }
+    __device__ __forceinline__ void push_byte(uint32_t byte) {      // la = (la >> 8) | byte << 120
+        la.x = __builtin_amdgcn_alignbit(la.y, la.x, 8);
+        la.y = __builtin_amdgcn_alignbit(la.z, la.y, 8);
+        la.z = __builtin_amdgcn_alignbit(la.w, la.z, 8);
+        la.w = (la.w >> 8) | (byte << 24);
+    }
+    __device__ __forceinline__ void push_entry(uint32_t e) {
+        ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = e;
+        ++n_ent;
+        if ((n_ent & 3u) == 0) store16(ent + n_ent - 4, ea);
+    }
     __device__ __forceinline__ void literal(uint32_t byte) {
-        acc |= byte << (8u * (n_lit & 3u));
+        push_byte(byte);
         ++n_lit;
-        if ((n_lit & 3u) == 0) { *(uint32_t*)(lit + n_lit - 4) = acc; acc = 0; }
-        if (++run == 255) { ent[n_ent++] = make_entry(255, 0, 1); run = 0; }
+        if ((n_lit & 15u) == 0) store16(lit + n_lit - 16, la);
+        if (++run == 255) { push_entry(make_entry(255, 0, 1)); run = 0; }
     }
     __device__ __forceinline__ void match(uint32_t len, uint32_t dist) {
-        ent[n_ent++] = make_entry(run, len, dist);
+        push_entry(make_entry(run, len, dist));
         run = 0;
     }
     __device__ __forceinline__ void finish() {
-        if (n_lit & 3u) *(uint32_t*)(lit + (n_lit & ~3u)) = acc;
-        if (run) { ent[n_ent++] = make_entry(run, 0, 1); run = 0; }
+        if (run) { push_entry(make_entry(run, 0, 1)); run = 0; }
+        const uint32_t rl = n_lit & 15u;
+        if (rl) {
+            for (uint32_t k = rl; k < 16; ++k) push_byte(0);
+            store16(lit + (n_lit & ~15u), la);
+        }
+        const uint32_t re = n_ent & 3u;
+        if (re) {
+            const uint32_t keep = n_ent;
+            for (uint32_t k = re; k < 4; ++k) { ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = 0; }
+            store16(ent + (keep & ~3u), ea);
+        }
     }
 };
 
@@ -442,7 +471,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         while (__any(sym_loop)) {
             uint32_t msym = 0;          // pending length symbol (257..285) of this lane, 0 = none
             uint32_t bad = INF_OK;
-#pragma unroll
+#pragma unroll 1
             for (int r = 0; r < kLitPerIter; ++r) {
                 if (sym_loop && msym == 0 && bad == INF_OK) {
                     br.refill();
@@ -642,7 +671,7 @@ size_t inflate_scratch_bytes(uint32_t n_blocks) { return (size_t)n_blocks * kLen
 
 // sizes of the two token streams for n_blocks blocks producing `total` output bytes
 size_t inflate_lit_bytes(uint64_t total, uint32_t n_blocks) { return (size_t)(lit_off(total, n_blocks) + 65536 + 64); }
-size_t inflate_ent_words(uint64_t total, uint32_t n_blocks) { return (size_t)(ent_off(total, n_blocks) + 65536 / 3 + 65536 / 255 + 64); }
+size_t inflate_ent_words(uint64_t total, uint32_t n_blocks) { return (size_t)(ent_off(total, n_blocks) + 65536 / 3 + 65536 / 255 + 64); }   // (slack covers the padded last slice)
 
 void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
                          const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,

@@ -92,3 +92,42 @@ def test_region_quality_threshold_edge(tmp_path):
 def test_window_overlap_is_rejected_loudly():
     r = run_cli(["window", "-w", "100", "--overlap", "10", os.path.join(GOLDEN, "issue225.bam")], check=False)
     assert r.returncode == 1 and b"overlap" in r.stderr
+
+
+def test_contig_shards_reproduce_the_whole_run(synth):
+    """Multi-GPU sharding (sambamba_amd/shard.py): a rank restricted to its contigs (sbx_set_regions ->
+    only the BAI-listed BGZF block range is inflated) must produce exactly the whole-file numbers for
+    the regions / windows / positions it owns."""
+    import numpy as np
+    import sambamba_amd
+    from sambamba_amd.shard import plan_contig_shards, regions_of_shard, owner_of_region
+    thr = (5, 20)
+    with sambamba_amd.Depth(synth) as d:
+        lens = d.ref_lengths
+        rng = np.random.default_rng(5)
+        bed = []
+        for _ in range(200):
+            r = int(rng.integers(0, len(lens)))
+            a = int(rng.integers(0, max(1, lens[r] - 10)))
+            bed.append((r, a, min(lens[r], a + int(rng.choice([5, 100, 3000])))))
+        d.set_params(mode=sambamba_amd.SBX_MODE_REGION, thresholds=thr)
+        whole_stats = d.run()
+        w_reads, w_bases, w_cov, w_seen = d.region_stats(bed, len(thr))
+        w_counts = {r: d.base_counters(r, 0, lens[r]) for r in range(len(lens))}
+    for world in (2, 3):
+        shards = plan_contig_shards(lens, world)
+        for rank, sh in enumerate(shards):
+            regs = regions_of_shard(lens, sh)
+            if not regs:
+                continue
+            with sambamba_amd.Depth(synth) as d:
+                d.set_params(mode=sambamba_amd.SBX_MODE_REGION, thresholds=thr)
+                d.set_regions(regs)
+                st = d.run()
+                assert st["uncompressed_bytes"] <= whole_stats["uncompressed_bytes"]
+                mine = [i for i, b in enumerate(bed) if owner_of_region(shards, b[0]) == rank]
+                reads, bases, cov, seen = d.region_stats([bed[i] for i in mine], len(thr))
+                assert np.array_equal(reads, w_reads[mine]) and np.array_equal(bases, w_bases[mine])
+                assert np.array_equal(cov, w_cov[mine]) and np.array_equal(seen, w_seen[mine])
+                for r in range(sh[0], sh[1]):
+                    assert np.array_equal(d.base_counters(r, 0, lens[r]), w_counts[r])
