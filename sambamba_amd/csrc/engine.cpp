@@ -135,7 +135,10 @@ void upload_file(sbx_ctx* c) {
 
 // inflate blocks [b0,b1) into d_U (which is laid out for the whole file) and check their status
 void inflate_blocks(sbx_ctx* c, uint32_t b0, uint32_t b1, hipEvent_t ev_mid = nullptr) {
-    if (b1 <= b0) return;
+    if (b1 <= b0) {
+        if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, c->stream));
+        return;
+    }
     uint32_t n = b1 - b0;
     const uint32_t nb = (uint32_t)c->blocks.size();
     const uint64_t total = c->blocks.out_off.back();

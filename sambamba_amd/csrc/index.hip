@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_block_walk(const uint8_t* __re
     uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
     if (b >= n_blocks) return;
     uint64_t beg = out_off[b], end = beg + isize[b];
+    if (end > total) end = total;     // the sub-stream of a -L run stops at a record boundary inside its last block
     uint64_t e;
     if (end <= first_record_off) {
         // block lies entirely inside the BAM header: the chain enters the next block at first_record_off
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
         const uint32_t b = b0 + lane;
         uint64_t e = kOffUnknown, x = kOffUnknown, end = 0;
         uint32_t n = 0;
-        if (b < n_blocks) { e = entry[b]; x = exit_[b]; n = count[b]; end = out_off[b] + isize[b]; }
+        if (b < n_blocks) { e = entry[b]; x = exit_[b]; n = count[b]; end = out_off[b] + isize[b]; if (end > total) end = total; }
         const uint32_t lim = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
         bool dirty = false;
         for (uint32_t i = 0; i < lim; ++i) {
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
     uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
     if (b >= n_blocks) return;
     uint64_t end = out_off[b] + isize[b];
+    if (end > total) end = total;
     uint64_t o = entry[b];
     uint64_t idx = base[b];
     unsigned long long n_rec = 0, n_adm = 0, n_bad = 0, n_urg = 0;
