@@ -67,6 +67,8 @@ struct sbx_ctx {
     DevBuf<uint32_t> d_count, d_flag;
     DevBuf<RecDesc> d_desc;
     DevBuf<int32_t> d_rec_ref;
+    DevBuf<uint64_t> d_name_hash;
+    DevBuf<uint32_t> d_mate, d_n_partners;
     DevBuf<int32_t> d_ref_len;
     DevBuf<uint32_t> d_tile_base, d_tile_lo, d_tile_hi, d_active, d_slot_of, d_n_active;
     DevBuf<uint32_t> d_counters, d_span;
@@ -352,7 +354,9 @@ int sbx_run(sbx_ctx* c) {
         if (!c) throw Error(SBX_EINVAL, "null context");
         if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
         if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
-        if (c->fix_mate) throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps is not on the device path yet");
+        if (c->fix_mate && c->mode != SBX_MODE_BASE)
+            throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps is only on the device path in base mode (the region/window bookkeeping of "
+                                          "depth.d:717-845 is history dependent, see DESIGN.md)");
         SBX_HIP(hipSetDevice(c->device));
         hipStream_t s = c->stream;
         c->have_run = false;
@@ -520,6 +524,7 @@ int sbx_run(sbx_ctx* c) {
         if (n_records > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "more than 2^32 records in one batch");
         c->d_desc.ensure((size_t)n_records + 64);
         c->d_rec_ref.ensure((size_t)n_records + 64);
+        if (c->fix_mate) c->d_name_hash.ensure((size_t)n_records + 64);
         c->d_tile_lo.ensure((size_t)nt + 1);
         c->d_tile_hi.ensure((size_t)nt + 1);
         c->d_active.ensure((size_t)nt + 1);
@@ -551,7 +556,8 @@ int sbx_run(sbx_ctx* c) {
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
         lap("scan+setup");
         launch_describe(c->d_U.p, total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
-                        T, c->d_desc.p, c->d_rec_ref.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_stats.p, s);
+                        T, c->d_desc.p, c->d_rec_ref.p, c->fix_mate ? c->d_name_hash.p : nullptr, c->d_tile_lo.p, c->d_tile_hi.p,
+                        c->d_stats.p, s);
         lap("describe");
         launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
         lap("tile_compact");
@@ -572,7 +578,26 @@ int sbx_run(sbx_ctx* c) {
         size_t per_tile = (size_t)T * S * SBX_NCOUNTERS;
         c->d_counters.ensure((size_t)n_active * per_tile + 4);
         if (want_span) c->d_span.ensure((size_t)n_active * T + 4);
+        if (c->fix_mate) {
+            c->d_mate.ensure((size_t)n_records + 64);
+            c->d_n_partners.ensure((size_t)n_records + 64);
+            SBX_HIP(hipMemsetAsync(c->d_mate.p, 0xFF, (size_t)n_records * 4, s));
+            SBX_HIP(hipMemsetAsync(c->d_n_partners.p, 0, (size_t)n_records * 4, s));
+            SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 4, s));
+        }
         t3.start(s);
+        if (c->fix_mate) {
+            launch_find_mates(c->d_desc.p, c->d_name_hash.p, c->d_rec_ref.p, n_records, c->d_mate.p, c->d_n_partners.p, s);
+            launch_max_u32(c->d_n_partners.p, n_records, c->d_flag.p + 2, s);
+            uint32_t max_partners = 0;
+            SBX_HIP(hipMemcpyAsync(&max_partners, c->d_flag.p + 2, 4, hipMemcpyDeviceToHost, s));
+            SBX_HIP(hipStreamSynchronize(s));
+            if (max_partners > 1)
+                throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps: a read overlaps two or more records with the same name; the reference's "
+                                              "result then depends on per-column status history (depth.d:343-377) and is not on the device path");
+            launch_accumulate_mates(c->d_U.p, c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
+                                    c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+        } else
         launch_accumulate(c->d_U.p, c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, c->d_tile_base.p,
                           n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
         t3.stop(s);

@@ -24,6 +24,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace sbx {
 
 namespace {
@@ -332,8 +334,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
                                                             const uint64_t* __restrict__ base, RefTable refs,
                                                             const DeviceFilter* __restrict__ filt, RgTable rg,
                                                             uint32_t tile_pos, RecDesc* __restrict__ desc,
-                                                            int32_t* __restrict__ rec_ref, uint32_t* tile_lo, uint32_t* tile_hi,
-                                                            IndexStats* stats) {
+                                                            int32_t* __restrict__ rec_ref, uint64_t* __restrict__ name_hash,
+                                                            uint32_t* tile_lo, uint32_t* tile_hi, IndexStats* stats) {
     uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
     if (b >= n_blocks) return;
     uint64_t end = out_off[b] + isize[b];
@@ -437,6 +439,12 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
         }
         desc[idx] = d;
         rec_ref[idx] = ref;
+        if (name_hash) {   // FNV-1a over the read name without its NUL (CustomBamRead, depth.d:252-258)
+            uint64_t h = 14695981039346656037ULL;
+            const uint8_t* nm = r + 32;
+            for (uint32_t k = 0; k + 1 < l_name; ++k) { h ^= nm[k]; h *= 1099511628211ULL; }
+            name_hash[idx] = h;
+        }
         ++idx;
         if (bs < 32) break;
         o += 4 + (uint64_t)bs;
@@ -482,6 +490,22 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* _
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(1024) void k_max_u32(const uint32_t* __restrict__ in, uint64_t n, uint32_t* out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 1024) m = in[i] > m ? in[i] : m;
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_down(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+}  // namespace
+
+void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream_t stream) {
+    if (!n) return;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (n + 1023) / 1024);
+    hipLaunchKernelGGL(k_max_u32, dim3(grid), dim3(1024), 0, stream, d_in, n, d_out);
+    SBX_HIP(hipGetLastError());
+}
+
 void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                        uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry, uint64_t* d_exit,
                        uint32_t* d_count, hipStream_t stream) {
@@ -519,11 +543,11 @@ void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_b
 void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                      uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
                      const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
-                     uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream) {
+                     uint64_t* d_name_hash, uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream) {
     if (!n_blocks) return;
     dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
     hipLaunchKernelGGL(k_describe, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, d_entry, d_base,
-                       refs, d_filter, rg, tile_pos, d_desc, d_rec_ref, d_tile_lo, d_tile_hi, d_stats);
+                       refs, d_filter, rg, tile_pos, d_desc, d_rec_ref, d_name_hash, d_tile_lo, d_tile_hi, d_stats);
     SBX_HIP(hipGetLastError());
 }
 

@@ -104,7 +104,8 @@ struct IndexStats {         // device-side accumulators of the describe pass
 void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                      uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
                      const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
-                     uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream);
+                     uint64_t* d_name_hash /* may be null */, uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats,
+                     hipStream_t stream);
 // compact the tiles that have work: active[] = tile ids, slot_of[t] = index into active or ~0u
 void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t* d_active,
                          uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream);
@@ -114,6 +115,18 @@ void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t
                        const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base, int32_t n_ref,
                        uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
                        hipStream_t stream);
+
+// ---- K7: --fix-mate-overlaps, base mode (mates.hip) ---------------------------------------
+// d_mate[i] = index of the single overlapping same-name record of i (0xFFFFFFFF: none),
+// d_n_partners[i] = how many were found (> 1 is outside the supported scope)
+void launch_find_mates(const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
+                       uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream);
+void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,
+                             const uint32_t* d_tile_hi, const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base,
+                             int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters,
+                             uint32_t* d_span, hipStream_t stream);
+// max over records of n_partners (single block reduction into *d_out)
+void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream_t stream);
 
 // ---- K5: region / window statistics (reduce.hip) --------------------------------------------
 void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_counters, const uint32_t* d_span,

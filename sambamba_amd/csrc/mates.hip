@@ -1,0 +1,208 @@
+// mates.hip -- K7: `depth base --fix-mate-overlaps` on the device.
+//
+// Replaces ColumnPrinter.detectOverlappingMates / selectBetterMate and the pair handling of
+// PerBasePrinter.writeColumn (sambamba/depth.d:319-399,520-532).  In the reference, per pileup column,
+// reads are sorted by the FNV-1a hash of their name (depth.d:252-258,338); two adjacent reads with the
+// same hash, name and sample form a pair and only the *better* mate is counted at that column: if
+// either is inside a D/N operation the higher mapping quality wins, otherwise the higher base quality;
+// ties go to the second one (depth.d:391-399).  As a histogram over reads this reads: a read A with one
+// same-name partner B contributes at position p iff B does not span p, or A wins at p.
+//   * `find_mates`      one lane per record scans forward over the records that start inside its span
+//                       (coordinate order => a contiguous index range; consecutive lanes read consecutive
+//                       hashes => coalesced) and links same-hash, same-sample, overlapping records.
+//   * `accumulate_mates` the tile kernel of depth.hip with a per-position path for linked reads: each
+//                       lane takes one reference position, evaluates both mates' CIGAR cursors there
+//                       and applies the reference's rule.
+// Scope: name groups of exactly two overlapping records.  A record with two or more overlapping
+// same-name partners (the reference's behaviour then depends on per-column status history and on the
+// order produced by an unstable sort) raises SBX_EUNSUPPORTED.  Ties are
+// resolved as in the oracle: the record later in the file wins (column order; parity unpinned).
+// Equality of names is decided by the 64-bit hash.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace sbx {
+
+namespace {
+
+constexpr int kMateThreads = 256;
+constexpr uint32_t kCigarTypeM = 0x3C1A7u;
+
+__device__ __forceinline__ uint32_t ld32m(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint32_t base5_m(uint32_t nib) {
+    const uint64_t lut = (4ULL << 0) | (0ULL << 3) | (1ULL << 6) | (4ULL << 9) | (2ULL << 12) | (4ULL << 15) |
+                         (4ULL << 18) | (4ULL << 21) | (3ULL << 24) | (4ULL << 27) | (4ULL << 30) | (4ULL << 33) |
+                         (4ULL << 36) | (4ULL << 39) | (4ULL << 42) | (4ULL << 45);
+    return (uint32_t)(lut >> (nib * 3)) & 7u;
+}
+__device__ __forceinline__ uint32_t pos_dw_m(uint32_t p, uint32_t sub_dw, uint32_t s7) { return (p & 3u) * sub_dw + (p >> 2) * s7; }
+
+__global__ __launch_bounds__(kMateThreads) void k_find_mates(const RecDesc* __restrict__ desc, const uint64_t* __restrict__ hash,
+                                                              const int32_t* __restrict__ rec_ref, uint64_t n, uint32_t* mate,
+                                                              uint32_t* n_partners) {
+    const uint64_t i = (uint64_t)blockIdx.x * kMateThreads + threadIdx.x;
+    if (i >= n) return;
+    const RecDesc a = desc[i];
+    if (a.kind == 0) return;
+    const uint64_t h = hash[i];
+    const int32_t ref = rec_ref[i];
+    for (uint64_t j = i + 1; j < n; ++j) {
+        const RecDesc b = desc[j];
+        if (rec_ref[j] != ref || b.pos >= a.end) break;          // coordinate sorted: nothing further can overlap A
+        if (b.kind != 0 && hash[j] == h && b.sample == a.sample && b.end > a.pos) {
+            mate[i] = (uint32_t)j;
+            mate[j] = (uint32_t)i;
+            atomicAdd(&n_partners[i], 1u);
+            atomicAdd(&n_partners[j], 1u);
+        }
+    }
+}
+
+struct Cursor {       // what PileupRead shows at one reference position (pileup.d:115-134)
+    uint32_t kind;    // 0 not spanning, 1 M/=/X base, 2 D, 3 N
+    uint32_t nib, qual;
+};
+
+// CIGAR cursor of record d at reference position p (same conventions as K3: a zero-length
+// reference-consuming op occupies one column, the read ends at d.end)
+__device__ Cursor state_at(const uint8_t* U, const RecDesc& d, int32_t p) {
+    Cursor c{0, 0, 0};
+    if (d.kind == 0 || p < d.pos || p >= d.end) return c;
+    const uint8_t* rec = U + d.rec_off;
+    const uint8_t* cig = rec + 36 + d.l_name;
+    const uint8_t* seq = cig + 4 * (uint32_t)d.n_cigar;
+    const uint8_t* qual = seq + ((d.l_seq + 1) >> 1);
+    auto at_query = [&](uint32_t q) {
+        if (q >= d.l_seq) return;
+        const uint32_t sb = seq[q >> 1];
+        c.kind = 1;
+        c.nib = (q & 1u) ? (sb & 15u) : (sb >> 4);
+        c.qual = qual[q];
+    };
+    if (d.kind == 1) { at_query((uint32_t)d.q_start + (uint32_t)(p - d.pos)); return c; }
+    int32_t rp = d.pos;
+    uint32_t qp = 0;
+    for (uint32_t k = 0; k < d.n_cigar; ++k) {
+        uint32_t op = ld32m(cig + 4 * k);
+        uint32_t ty = (kCigarTypeM >> ((op & 15u) * 2u)) & 3u, len = op >> 4;
+        if (ty & 2u) {
+            if (len == 0) len = 1;
+            const int32_t room = d.end - rp;
+            if ((int64_t)len > (int64_t)room) len = (uint32_t)(room > 0 ? room : 0);
+            if (p < rp + (int32_t)len) {
+                if (ty == 3) at_query(qp + (uint32_t)(p - rp));
+                else c.kind = (op & 15u) == 2u ? 2u : 3u;
+                return c;
+            }
+            rp += (int32_t)len;
+            if (ty == 3) qp += len;
+        } else if (ty == 1) {
+            qp += len;
+        }
+    }
+    return c;
+}
+
+template <bool kSpan>
+__global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
+    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ mate,
+    const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active,
+    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq,
+    uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t s7 = S * 7;
+    const uint32_t sub_dw = (T / 4) * s7 + 8;
+    uint32_t* cnt = lds;
+    uint32_t* spn = lds + 4 * sub_dw;
+    const uint32_t tile = active[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < 4 * sub_dw + (kSpan ? T : 0u); i += kMateThreads) lds[i] = 0;
+    int lo_r = 0, hi_r = n_ref;
+    while (hi_r - lo_r > 1) {
+        int mid = (lo_r + hi_r) >> 1;
+        if (tile_base[mid] <= tile) lo_r = mid; else hi_r = mid;
+    }
+    const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T), te = ts + (int32_t)T;
+    const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // one record per wave iteration; every lane owns one reference position of it per pass
+    for (uint32_t ri = r_lo + wave; ri < r_hi; ri += kMateThreads / 64) {
+        const RecDesc a = desc[ri];
+        if (a.kind == 0 || a.pos >= te || a.end <= ts) continue;
+        const uint32_t mi = mate[ri];
+        RecDesc b;
+        b.kind = 0; b.pos = 0; b.end = 0; b.rec_off = 0; b.l_seq = 0; b.n_cigar = 0; b.l_name = 0; b.q_start = 0; b.sample = 0; b.mapq = 0;
+        if (mi != 0xFFFFFFFFu) b = desc[mi];
+        const uint32_t sample = S > 1 ? a.sample : 0u;
+        const int32_t p0 = a.pos > ts ? a.pos : ts, p1 = a.end < te ? a.end : te;
+        for (int32_t p = p0 + (int32_t)lane; p < p1; p += 64) {
+            const Cursor ca = state_at(U, a, p);
+            if (ca.kind == 0) continue;
+            if (kSpan) atomicAdd(&spn[p - ts], 1u);
+            bool counts = true;
+            if (b.kind != 0) {
+                const Cursor cb = state_at(U, b, p);
+                if (cb.kind != 0) {
+                    // selectBetterMate(m1, m2) with m1 = the record earlier in the file; ties -> m2
+                    const bool a_first = ri < mi;
+                    const Cursor& c1 = a_first ? ca : cb;
+                    const Cursor& c2 = a_first ? cb : ca;
+                    const uint32_t q1 = a_first ? a.mapq : b.mapq, q2 = a_first ? b.mapq : a.mapq;
+                    bool first_wins;
+                    if (c1.kind != 1 || c2.kind != 1) first_wins = q1 > q2;
+                    else first_wins = c1.qual > c2.qual;
+                    counts = (first_wins == a_first);
+                }
+            }
+            if (!counts) continue;
+            uint32_t* cp = &cnt[pos_dw_m((uint32_t)(p - ts), sub_dw, s7) + sample * 7];
+            if (ca.kind == 1) { if (ca.qual >= min_bq) atomicAdd(&cp[base5_m(ca.nib)], 1u); }
+            else atomicAdd(&cp[ca.kind == 2 ? 5 : 6], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_cnt = T * s7;
+    uint32_t* out = counters + (size_t)blockIdx.x * n_cnt;
+    for (uint32_t i = threadIdx.x; i < n_cnt; i += kMateThreads) {
+        const uint32_t p = i / s7, k = i - p * s7;
+        out[i] = cnt[pos_dw_m(p, sub_dw, s7) + k];
+    }
+    if (kSpan) {
+        uint32_t* so = span_out + (size_t)blockIdx.x * T;
+        for (uint32_t i = threadIdx.x; i < T; i += kMateThreads) so[i] = spn[i];
+    }
+}
+
+}  // namespace
+
+void launch_find_mates(const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
+                       uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream) {
+    if (!n_records) return;
+    hipLaunchKernelGGL(k_find_mates, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
+                       d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,
+                             const uint32_t* d_tile_hi, const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base,
+                             int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters,
+                             uint32_t* d_span, hipStream_t stream) {
+    if (!n_active) return;
+    size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0);
+    if (d_span) {
+        SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_accumulate_mates<true>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+    } else {
+        SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_accumulate_mates<false>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+    }
+    SBX_HIP(hipGetLastError());
+}
+
+}  // namespace sbx
