@@ -116,9 +116,16 @@ def main():
         dist.barrier()
     import sambamba_amd
 
-    seed = 0x5A4D0002 + rank
+    # One seeded contig-sized BAM per node, generated once (rank 0, all host cores) and processed by every
+    # rank on its own GPU: per-GPU work is fixed as N grows (weak scaling) and ranks never exchange data.
+    seed = 0x5A4D0002
     path, key = workload_path(args.length, args.coverage, seed, args.level, args.codec)
-    info = generate(path, args.length, args.coverage, seed, args.level, args.codec)
+    if rank == 0:
+        info = generate(path, args.length, args.coverage, seed, args.level, args.codec)
+    if dist:
+        dist.barrier()
+    if rank != 0:
+        info = json.load(open(path + ".json"))
 
     d = sambamba_amd.Depth(path, device=local_rank if world > 1 else 0)
     d.set_params()             # depth base, default filter, -q 0
@@ -183,7 +190,7 @@ def main():
                                        int(args.coverage), args.length, int(last["n_records"]), read_len, args.codec,
                                        args.level, unc / max(1, comp)),
                        "baseline_config": "configs[1]" if args.length == CHR1_LEN else "configs[1] scaled down (development)",
-                       "sharding": "one contig-sized BAM per GPU, no data-path collective"},
+                       "sharding": "every GPU runs the full contig-sized workload (same seeded BAM), no data-path collective"},
             "gbases_per_s": round(total_admitted * read_len / (elapsed / args.steps) / 1e9, 3),
             "reads_total": int(total_reads), "reads_admitted": int(total_admitted),
             "roofline": roof, "kernels": per_kernel, "cpu_baseline": cpu,
