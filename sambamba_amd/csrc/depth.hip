@@ -62,10 +62,6 @@ struct RecU {   // wave-uniform view of one record (values live in SGPRs)
     uint32_t l_seq, n_cigar, kind, q_start, sample;
 };
 
-struct Pre {    // per-lane prefetched data of the first pass of a kind-1 record
-    uint32_t qw, sw;
-};
-
 template <bool kSpan>
 __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
@@ -161,36 +157,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
             R.qual = R.seq + ((R.l_seq + 1) >> 1);
             return R;
         };
-        // issue the loads of the first pass of a kind-1 record (one memory round trip per read)
-        auto prefetch = [&](const RecU& R, Pre& P) {
-            P.qw = 0; P.sw = 0;
-            if (R.kind == 1) {
-                int32_t i0, i1;
-                clip(R.pos, R.q_start, (uint32_t)(R.end - R.pos), R.l_seq, &i0, &i1);
-                const int32_t i = i0 + 4 * (int32_t)lane;
-                if (i < i1) {
-                    const uint32_t q = R.q_start + (uint32_t)i;
-                    P.qw = ld32u(R.qual + q);
-                    P.sw = ld32u(R.seq + (q >> 1));
-                }
-            }
-        };
-        auto consume = [&](const RecU& R, const Pre& P) {
-            if (kSpan) {
-                int32_t a = R.pos > ts ? R.pos : ts, b2 = R.end < te ? R.end : te;
-                for (int32_t p = a + (int32_t)lane; p < b2; p += 64) atomicAdd(&spn[p - ts], 1u);
-            }
-            if (R.kind == 1) {
-                int32_t i0, i1;
-                const uint32_t len = (uint32_t)(R.end - R.pos);
-                clip(R.pos, R.q_start, len, R.l_seq, &i0, &i1);
-                const int32_t i = i0 + 4 * (int32_t)lane;
-                if (i < i1) {
-                    const uint32_t nb = (uint32_t)(i1 - i) < 4u ? (uint32_t)(i1 - i) : 4u;
-                    add4(P.qw, P.sw, R.q_start + (uint32_t)i, nb, (uint32_t)(R.pos + i - ts), R.sample);
-                }
-                if (i1 - i0 > 256) match_run(R, R.pos, R.q_start, len, 256);   // reads longer than 256 aligned bases
-            } else {
+        auto consume_general = [&](const RecU& R) {
+            {
                 // General CIGAR walk.  Every reference-consuming op occupies max(len, 1) columns (a
                 // zero-length op still shows for one column in the reference's cursor, pileup.d:195-205)
                 // and the read leaves the pileup at end = pos + sum(len) (read.d:1380-1383), which
@@ -219,24 +187,77 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
                 }
             }
         };
-        if (mask) {
-            // software pipeline: the loads of record n+1 are in flight while record n is accumulated
-            int r = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            RecU cur = view(r);
-            Pre pc;
-            prefetch(cur, pc);
-            while (mask) {
-                r = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                RecU nxt = view(r);
-                Pre pn;
-                prefetch(nxt, pn);
-                consume(cur, pc);
-                cur = nxt;
-                pc = pn;
+        // ---- fast path: reads with a single run of aligned bases (kind 1), three per pass ----------
+        // 21 lanes x 8 bases cover a 150-base read, so a pass handles three reads with 63 lanes busy:
+        // per lane one 8-byte load of qualities, one of packed sequence, 8 LDS atomics.  The lane that
+        // holds the descriptor precomputes the clipped run; the worker lanes fetch it by cross-lane
+        // reads instead of 7 wave-uniform broadcasts per read.
+        int32_t fi0 = 0, fi1 = 0;
+        const bool fast = take && d.kind == 1;
+        if (fast) clip(d.pos, d.q_start, (uint32_t)(d.end - d.pos), d.l_seq, &fi0, &fi1);
+        const uint32_t f_n = fast && fi1 > fi0 ? (uint32_t)(fi1 - fi0) : 0u;         // bases of the run inside the tile
+        const uint32_t f_q0 = (uint32_t)d.q_start + (uint32_t)fi0;                  // query offset of the first of them
+        const uint32_t f_t0 = (uint32_t)(d.pos + fi0 - ts);                          // its tile offset
+        const uint64_t f_seq = d.rec_off + 36u + d.l_name + 4u * (uint32_t)d.n_cigar;  // offset of the packed sequence in U
+        const uint32_t f_qd = (d.l_seq + 1u) >> 1;                                   // qualities follow the sequence
+        const uint32_t f_smp = S > 1 ? (uint32_t)d.sample : 0u;
+        if (kSpan) {
+            uint64_t ms = mask;
+            while (ms) {
+                const int r = __builtin_ctzll(ms);
+                ms &= ms - 1;
+                const int32_t rp = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.pos, r);
+                const int32_t re = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.end, r);
+                const int32_t a = rp > ts ? rp : ts, b2 = re < te ? re : te;
+                for (int32_t p = a + (int32_t)lane; p < b2; p += 64) atomicAdd(&spn[p - ts], 1u);
             }
-            consume(cur, pc);
+        }
+        uint64_t m1 = __ballot(f_n != 0);
+        const uint32_t grp = lane / 21u, sub = lane - grp * 21u;     // lane 63: grp 3 = idle
+        while (m1) {
+            int r0 = __builtin_ctzll(m1); m1 &= m1 - 1;
+            int r1 = -1, r2 = -1;
+            if (m1) { r1 = __builtin_ctzll(m1); m1 &= m1 - 1; }
+            if (m1) { r2 = __builtin_ctzll(m1); m1 &= m1 - 1; }
+            const int src = grp == 0 ? r0 : grp == 1 ? r1 : grp == 2 ? r2 : -1;
+            const int sl = src < 0 ? 0 : src;
+            const uint32_t n_src = __shfl(f_n, sl, 64);     // every lane takes part: a masked-off source lane reads as 0
+            const uint32_t n = src < 0 ? 0u : n_src;
+            const uint32_t q0 = __shfl(f_q0, sl, 64), t0 = __shfl(f_t0, sl, 64), qd = __shfl(f_qd, sl, 64);
+            const uint32_t s_lo = __shfl((uint32_t)f_seq, sl, 64), s_hi = __shfl((uint32_t)(f_seq >> 32), sl, 64);
+            const uint32_t smp = S > 1 ? __shfl(f_smp, sl, 64) : 0u;
+            const uint8_t* seq = U + (((uint64_t)s_hi << 32) | s_lo);
+            const uint8_t* qual = seq + qd;
+            for (uint32_t j = 8u * sub; __any(j < n); j += 168u) {
+                if (j < n) {
+                    const uint32_t q = q0 + j;
+                    const uint32_t nb = n - j < 8u ? n - j : 8u;
+                    // 8 quality bytes and the <= 5 sequence bytes holding bases q..q+7 (reads past the run stay
+                    // inside the record / the stream's padding)
+                    const uint32_t qw0 = ld32u(qual + q), qw1 = ld32u(qual + q + 4);
+                    const uint32_t sw0 = ld32u(seq + (q >> 1)), sw1 = ld32u(seq + (q >> 1) + 4);
+                    const uint64_t qw = (uint64_t)qw0 | ((uint64_t)qw1 << 32);
+                    const uint64_t sw = (uint64_t)sw0 | ((uint64_t)sw1 << 32);
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k) {
+                        if (k < nb) {
+                            const uint32_t qi = (q & 1u) + k;                            // nibble index inside sw
+                            const uint32_t byte = (uint32_t)(sw >> (8u * (qi >> 1))) & 0xFFu;
+                            const uint32_t nib = (qi & 1u) ? (byte & 15u) : (byte >> 4);
+                            const uint32_t ql = (uint32_t)(qw >> (8u * k)) & 0xFFu;
+                            if (ql >= min_bq) atomicAdd(&cnt[pos_dw(t0 + j + k, sub_dw, s7) + smp * 7 + base5_of_nibble(nib)], 1u);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- general CIGARs (kind 2): one read at a time, wave-uniform CIGAR walk ------------------------
+        uint64_t m2 = __ballot(take && d.kind == 2);
+        while (m2) {
+            const int r = __builtin_ctzll(m2);
+            m2 &= m2 - 1;
+            const RecU R = view(r);
+            consume_general(R);
         }
     }
     __syncthreads();
