@@ -548,7 +548,20 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
 }
 
 // ---- K1b -----------------------------------------------------------------------------------------
-constexpr int kResThreads = 256;   // 4 waves per workgroup, one BGZF block per wave
+// One wave per BGZF block, four blocks per workgroup.  The wave keeps the most recent kHist..kCap
+// bytes of its output in a linear LDS buffer (offset = position - base; the buffer is slid down every
+// ~1.5 KiB of output, so there is no wrap-around anywhere):
+//   * literal runs and FAR matches (source below `base`, i.e. output this wave flushed to HBM at least
+//     a batch ago -- final, no dependency) are fetched from global memory, all loads of a batch in
+//     flight together: one memory round trip per batch;
+//   * NEAR matches -- the ones that form the long dependency chain record -> previous record ->
+//     ... of a BAM stream -- are resolved LDS -> LDS in rounds that cost an LDS round trip each;
+//   * the finished span of the batch is written to HBM once, contiguous and coalesced.
+constexpr int kResThreads = 256;
+constexpr uint32_t kHist = 2048;            // bytes of history guaranteed to be in LDS
+constexpr uint32_t kSpanMax = 1536;         // output bytes per batch (a batch is <= 64 entries AND <= this)
+constexpr uint32_t kCap = 5120;             // LDS bytes per wave: kHist + slide hysteresis + kSpanMax
+constexpr uint32_t kWaveLds = kCap + 16;
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -559,109 +572,207 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-// copy n bytes (n >= 4) as unaligned dwords, the last one overlapping: exact, never writes outside [d, d+n)
-__device__ __forceinline__ void copy_dwords(uint8_t* d, const uint8_t* s, uint32_t n) {
-    uint32_t i = 0;
-    for (; i + 32 <= n; i += 32) {
-        uint32_t w[8];
+// registers of one short copy task (n <= 16): full dwords, then a tail dword overlapping the last one
+struct Short16 {
+    uint32_t w[4], wt;
+    __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
+        const uint32_t nf = n >> 2;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = ldu32(s + i + 4 * k);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) stu32(d + i + 4 * k, w[k]);
+        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)k < nf ? ldu32(s + 4 * k) : 0u;
+        wt = n >= 4 ? ldu32(s + n - 4) : 0u;
+        if (n && n < 4) {          // 1..3 bytes: gathered into w[0]
+            w[0] = s[0];
+            if (n > 1) w[0] |= (uint32_t)s[1] << 8;
+            if (n > 2) w[0] |= (uint32_t)s[2] << 16;
+        }
     }
-    uint32_t w[8];
-    const uint32_t rem = n - i, nf = rem >> 2;   // rem < 32
-    uint32_t wt = 0;
+    __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
+        if (n >= 4) {
+            const uint32_t nf = n >> 2;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) if ((uint32_t)k < nf) w[k] = ldu32(s + i + 4 * k);
-    if (rem & 3u) wt = ldu32(s + n - 4);
+            for (int k = 0; k < 4; ++k) if ((uint32_t)k < nf) stu32(d + 4 * k, w[k]);
+            stu32(d + n - 4, wt);
+        } else if (n) {
+            d[0] = (uint8_t)w[0];
+            if (n > 1) d[1] = (uint8_t)(w[0] >> 8);
+            if (n > 2) d[2] = (uint8_t)(w[0] >> 16);
+        }
+    }
+};
+
+// Long copy tasks (16 < n <= 512) of a wave, done by all 64 lanes, 8 bytes per lane, four tasks in
+// flight (loads of all four before the first store).  Lane r of `m` owns a task: n bytes from
+// sbase + s to buf + d.  Source and destination of a task never overlap.
+__device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint32_t s, uint8_t* buf, uint32_t d, uint32_t n, uint32_t lane) {
+    while (m) {
+        uint32_t S[4], D[4], N[4], wa[4], wb[4];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) if ((uint32_t)k < nf) stu32(d + i + 4 * k, w[k]);
-    if (rem & 3u) stu32(d + n - 4, wt);
+        for (int j = 0; j < 4; ++j) {
+            N[j] = 0; S[j] = 0; D[j] = 0;
+            if (m) {
+                const int r = __builtin_ctzll(m);
+                m &= m - 1;
+                S[j] = __builtin_amdgcn_readlane(s, r);
+                D[j] = __builtin_amdgcn_readlane(d, r);
+                N[j] = __builtin_amdgcn_readlane(n, r);
+            }
+        }
+        const uint32_t off = 8 * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (off < N[j]) {
+                const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
+                wa[j] = ldu32(sbase + S[j] + a);
+                wb[j] = ldu32(sbase + S[j] + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (off < N[j]) {
+                const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
+                stu32(buf + D[j] + a, wa[j]);
+                stu32(buf + D[j] + c, wb[j]);
+            }
+        }
+    }
 }
 
-__global__ __launch_bounds__(kResThreads, 6) void k_lz77_resolve(
+// the whole wave copies N bytes inside LDS (wave-uniform arguments, ranges disjoint)
+__device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t N, uint32_t lane) {
+    if (N >= 4) {
+        for (uint32_t off = 4 * lane; off < N; off += 256) {
+            const uint32_t o2 = off + 4 <= N ? off : N - 4;
+            stu32(d + o2, ldu32(s + o2));
+        }
+    } else if (lane < N) {
+        d[lane] = s[lane];
+    }
+}
+
+__global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
     uint8_t* out, const uint32_t* __restrict__ status) {
-    __shared__ uint32_t s_end[kResThreads / 64][64];   // per wave: end offset (exclusive) of every entry's output
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
     if (b >= n_blocks) return;
     if (status[b] != INF_OK) return;
+    uint8_t* buf = smem + wv * kWaveLds;
     const uint64_t oo = out_off[b];
     const uint8_t* lit = lit_stream + lit_off(oo, block0 + b);
     const uint32_t* ent = ent_stream + ent_off(oo, block0 + b);
     uint8_t* o = out + oo;
     const uint32_t ne = n_entries[b];
-    uint32_t opos = 0, lpos = 0;   // wave-uniform running positions
-    uint32_t* end_arr = s_end[wv];
+    uint32_t opos = 0, lpos = 0;   // wave-uniform running positions (block-relative)
+    uint32_t base = 0;             // position held at buf[0]; multiple of 16
 
     uint32_t e_next = lane < ne ? ent[lane] : 0u;
-    for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
-        const uint32_t e = e_next;
-        e_next = (e0 + 64 + lane < ne) ? ent[e0 + 64 + lane] : 0u;      // prefetch the next batch of entries
-        const uint32_t lr = e >> 24, len = e & 511u, dist = ((e >> 9) & 0x7FFFu) + 1u;
-        const uint32_t tot = lr + len;
-        const uint32_t incl = wave_incl_scan(tot, lane);
-        const uint32_t lincl = wave_incl_scan(lr, lane);
-        const uint32_t eo = opos + incl - tot;        // first output byte of this entry (its literal run)
-        const uint32_t el = lpos + lincl - lr;        // first literal of this entry in the literal stream
-        const uint32_t dst = eo + lr;                 // first byte of the match
+    for (uint32_t e0 = 0; e0 < ne;) {
+        uint32_t e = e_next;
+        const uint32_t in_batch = ne - e0 < 64u ? ne - e0 : 64u;
+        // ---- positions: one packed scan (64 * 513 < 2^16), batch cut at kSpanMax bytes of output ----------
+        uint32_t lr = e >> 24, len = e & 511u;
+        const uint32_t dist = ((e >> 9) & 0x7FFFu) + 1u;
+        uint32_t tot = lr + len;
+        const uint32_t pk = wave_incl_scan(tot | (lr << 16), lane);
+        const uint32_t take = __popcll(__ballot(lane < in_batch && (pk & 0xFFFFu) <= kSpanMax));   // >= 1: an entry is <= 513 bytes
+        if (lane >= take) { lr = 0; len = 0; tot = 0; }
+        const uint32_t pk_last = __builtin_amdgcn_readlane(pk, take - 1);
+        const uint32_t span = pk_last & 0xFFFFu, lspan = pk_last >> 16;
+        e0 += take;
+        e_next = (e0 + lane < ne) ? ent[e0 + lane] : 0u;            // next batch (wherever this one was cut)
+        // ---- slide the window down when this batch might not fit -----------------------------------------
+        if (opos - base + kSpanMax > kCap) {
+            const uint32_t nb = (opos - kHist) & ~15u, delta = nb - base, keep = opos - nb;
+            for (uint32_t i = 16 * lane; i < keep; i += 1024) {
+                const u32x4 v = *(const u32x4*)(buf + delta + i);
+                *(u32x4*)(buf + i) = v;
+            }
+            base = nb;
+        }
+        const uint32_t eo = opos + (pk & 0xFFFFu) - tot;     // first output byte of this entry (its literal run)
+        const uint32_t el = lpos + (pk >> 16) - lr;          // its first literal in the block's literal stream
+        const uint32_t dst = eo + lr;                        // first byte of the match
         const uint32_t src = dst - dist;
-        end_arr[lane] = eo + tot;
-        // ---- literal run of my entry (source = literal stream: no dependencies) ----------
-        if (lr >= 4) copy_dwords(o + eo, lit + el, lr);
-        else if (lr) {
-            const uint8_t a0 = lit[el], a1 = lr > 1 ? lit[el + 1] : 0, a2 = lr > 2 ? lit[el + 2] : 0;
-            o[eo] = a0;
-            if (lr > 1) o[eo + 1] = a1;
-            if (lr > 2) o[eo + 2] = a2;
+        const bool far = len != 0 && src < base;             // (dist <= dst for every entry K1a emitted)
+        // ---- phase A: everything that comes from global memory, all loads before the first store ---------
+        {
+            const uint32_t n_l = lr <= 16 ? lr : 0u, n_f = far && len <= 16 ? len : 0u;
+            Short16 rl, rf;
+            rl.load(lit + el, n_l);
+            rf.load(o + src, n_f);
+            rl.store(buf + (eo - base), n_l);
+            rf.store(buf + (dst - base), n_f);
+            coop_copy(__ballot(lr > 16), lit, el, buf, eo - base, lr, lane);
+            coop_copy(__ballot(far && len > 16), o, src, buf, dst - base, len, lane);
         }
-        // ---- which earlier entries of this batch does my source range touch? -------------
-        // entry i occupies [end[i-1], end[i]); ends are non-decreasing.  lo = lowest i with
-        // end[i] > src ; hi = 1 + lowest i with end[i] >= src + min(len, dist)  (the source bytes
-        // actually read are [src, src + min(len, dist)) thanks to the periodic extension below).
-        uint64_t dep = 0;
+        // ---- phase B: near matches, LDS -> LDS --------------------------------------------------------------
+        // A match may start once everything below its source end is final.  Matches start in entry order,
+        // so "final" is everything below the start of the first unfinished match (the frontier F); that
+        // match itself always qualifies: its source ends at or before its own start (a self-overlapping
+        // match reads [src, dst) only and is extended periodically).
         const uint32_t s_hi = src + (len < dist ? len : dist);
-        if (len && s_hi > opos) {                     // (sources entirely before this batch are final)
-            uint32_t lo, hi;
+        const uint32_t dsto = dst - base, srco = src - base;
+        bool pending = len != 0 && !far;
+        for (uint64_t pm = __ballot(pending); pm; pm = __ballot(pending)) {
+            const uint32_t F = __builtin_amdgcn_readlane(dst, __builtin_ctzll(pm));
+            const bool ready = pending && s_hi <= F;
+            pending = pending && !ready;
+            const bool plain = ready && dist >= len;
             {
-                uint32_t a = 0, c = lane;
-                while (a < c) { uint32_t m = (a + c) >> 1; if (end_arr[m] > src) c = m; else a = m + 1; }
-                lo = a;
+                const uint32_t n_s = plain && len <= 16 ? len : 0u;
+                Short16 rs;
+                rs.load(buf + srco, n_s);
+                rs.store(buf + dsto, n_s);
             }
-            {
-                uint32_t a = lo, c = lane;
-                while (a < c) { uint32_t m = (a + c) >> 1; if (end_arr[m] >= s_hi) c = m; else a = m + 1; }
-                hi = a < lane ? a + 1 : lane;         // exclusive
-            }
-            if (hi > lo) dep = (hi - lo >= 64 ? ~0ULL : ((1ULL << (hi - lo)) - 1ULL)) << lo;
-        }
-        // ---- match rounds: every ready lane copies its own match -------------------------
-        uint64_t pending = __ballot(len != 0);
-        while (pending) {
-            const bool ready = len != 0 && ((pending >> lane) & 1ULL) && (dep & pending) == 0ULL;
-            const uint64_t rmask = __ballot(ready);
-            if (ready) {
-                uint8_t* d = o + dst;
-                const uint8_t* sp = o + src;
-                if (dist >= len) {
-                    if (len >= 4) copy_dwords(d, sp, len);
-                    else { const uint8_t a0 = sp[0], a1 = sp[1], a2 = sp[2]; d[0] = a0; d[1] = a1; d[2] = a2; }   // len == 3
-                } else {
-                    // self-overlapping match: byte k is src[k mod dist] (all inside [src, dst), final)
-                    uint32_t m = 0;
-                    for (uint32_t k = 0; k < len; ++k) {
-                        d[k] = sp[m];
+            coop_copy(__ballot(plain && len > 16), buf, srco, buf, dsto, len, lane);
+            // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
+            // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
+            // 1, 2, 4 ... periods copied from the match's own output.
+            const bool per = ready && dist < len;
+            if (per && len <= 16) {
+                uint32_t lo = 0, hi = 0, m = 0;      // 16 bytes in two 64-bit halves would need 4 regs; len <= 16
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k) {
+                    if (k < len) {
+                        w[k >> 2] |= (uint32_t)buf[srco + m] << (8 * (k & 3));
                         if (++m == dist) m = 0;
                     }
                 }
+                (void)lo; (void)hi;
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k)
+                    if (k < len) buf[dsto + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
             }
-            pending &= ~rmask;
+            for (uint64_t lm = __ballot(per && len > 16); lm; lm &= lm - 1) {
+                const int q = __builtin_ctzll(lm);
+                const uint32_t D = __builtin_amdgcn_readlane(dsto, q), P = __builtin_amdgcn_readlane(dist, q), N = __builtin_amdgcn_readlane(len, q);
+                wave_copy(buf + D, buf + D - P, P, lane);
+                for (uint32_t done = P; done < N;) {
+                    const uint32_t n2 = done < N - done ? done : N - done;
+                    wave_copy(buf + D + done, buf + D, n2, lane);
+                    done += n2;
+                }
+            }
         }
-        opos += __shfl(incl, 63, 64);
-        lpos += __shfl(lincl, 63, 64);
+        // ---- phase C: the finished span goes to HBM, contiguous ------------------------------------------------
+        {
+            const uint8_t* sp = buf + (opos - base);
+            uint8_t* dp = o + opos;
+            for (uint32_t i = 16 * lane; i < span; i += 1024) {
+                if (i + 16 <= span) {
+                    u32x4 v;
+                    v.x = ldu32(sp + i); v.y = ldu32(sp + i + 4); v.z = ldu32(sp + i + 8); v.w = ldu32(sp + i + 12);
+                    __builtin_memcpy(dp + i, &v, 16);
+                } else {
+                    for (uint32_t k = i; k < span; ++k) dp[k] = sp[k];
+                }
+            }
+        }
+        opos += span;
+        lpos += lspan;
     }
 }
 
@@ -689,7 +800,7 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
     {
         const uint32_t per = kResThreads / 64;
         dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
-        hipLaunchKernelGGL(k_lz77_resolve, grid, block, 0, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks, block0,
+        hipLaunchKernelGGL(k_lz77_resolve, grid, block, (kResThreads / 64) * kWaveLds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks, block0,
                            d_out, d_status);
         SBX_HIP(hipGetLastError());
     }
