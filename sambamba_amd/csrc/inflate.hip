@@ -70,10 +70,11 @@ __device__ __forceinline__ uint32_t ldu32(const uint8_t* p) { uint32_t v; __buil
 __device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
 // ---- token streams between K1a and K1b -----------------------------------------------------------
-// literal stream of block b: bytes at lit[lit_off(b) ..], 16-byte aligned, capacity isize[b] rounded up to 16
+// literal stream of block b: bytes at lit[lit_off(b) ..], 16-byte aligned, capacity >= isize[b] + 33 (K1a notices an
+// output overrun only at the end of a loop iteration, kLitPerIter literals late at most)
 // entry stream of block b  : u32 at ent[ent_off(b) ..], 16-byte aligned, capacity isize/3 + isize/255 + 7
 // Both offsets are pure functions of (out_off[b], b) so that no extra table is needed.
-__host__ __device__ __forceinline__ uint64_t lit_off(uint64_t out_off_b, uint32_t b) { return (out_off_b + 32ull * b + 15ull) & ~15ull; }
+__host__ __device__ __forceinline__ uint64_t lit_off(uint64_t out_off_b, uint32_t b) { return (out_off_b + 48ull * b + 15ull) & ~15ull; }
 __host__ __device__ __forceinline__ uint64_t ent_off(uint64_t out_off_b, uint32_t b) { return (out_off_b / 3 + out_off_b / 255 + 12ull * b + 3ull) & ~3ull; }
 
 __device__ __forceinline__ uint32_t make_entry(uint32_t lit_run, uint32_t len, uint32_t dist) {
@@ -104,7 +105,8 @@ struct BitReader {
     uint32_t wnext;       // next dword of the stream (already in a register)
     uint64_t buf;
     int cnt;              // valid bits in buf
-    uint32_t consumed;    // bits consumed so far (relative to payload start)
+    uint32_t staged;      // chunks put into the ring by service()
+    uint32_t cnt0;        // valid bits in buf after init
 
     __device__ __forceinline__ static u32x4 load16(const uint8_t* p) {
         u32x4 v;
@@ -130,7 +132,8 @@ struct BitReader {
         wnext = ring[1];
         rpos = 2;
         ravail = kRingDwords - 1;
-        consumed = 0;
+        staged = 0;
+        cnt0 = (uint32_t)cnt;
     }
     // wave-synchronous: call with all lanes of the wave converged, once per loop iteration
     __device__ __forceinline__ void service() {
@@ -138,6 +141,7 @@ struct BitReader {
             if (pend_valid && ravail + 4 <= (uint32_t)kRingDwords) {
                 put_chunk(pend);
                 ravail += 4;
+                ++staged;
                 pend_valid = 0;
             }
             if (!pend_valid) {
@@ -157,17 +161,24 @@ struct BitReader {
         }
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); }
-    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; consumed += (uint32_t)n; }
+    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
+    // bits consumed so far: every refill moved 32 bits into buf, and refills = dwords taken from the ring
+    __device__ __forceinline__ uint32_t consumed() const {
+        const uint32_t refills = (uint32_t)(kRingDwords - 1) + 4u * staged - ravail;
+        return cnt0 + 32u * refills - (uint32_t)cnt;
+    }
     __device__ __forceinline__ uint32_t take(int n) { uint32_t v = peek(n); drop(n); return v; }
 };
 
 // Canonical code held in registers, two 16-bit lanes per VGPR:
 //   lim1[j] = { limit[2j+1] - 1, limit[2j+2] - 1 }   limit[l] = left-justified (15-bit) exclusive upper
 //                                                    bound of the codes of length <= l
-//   dd[j]   = { D[2j+2] - D[2j+1], D[2j+3] - D[2j+2] } (mod 2^16), D[l] = first symbol index of
-//                                                    length l minus first code of length l
+//   dd[j]   = { D[2j+2] - D[2j+1], D[2j+3] - D[2j+2] } (mod 2^9) | 1 << 13,  D[l] = first symbol index
+//                                                    of length l minus first code of length l
 // For the 15-bit prefix v:  mask_l = (v >= limit[l]) ; len = 1 + sum mask_l ; D[len] = D[1] + sum mask_l*dd_l.
-// All of it is packed 16-bit VALU work: no memory, no VCC chains, identical in every lane.
+// Both sums come out of ONE accumulator: a symbol index needs 9 bits, so 16 terms stay below 2^13 and bit
+// 13 of every dd counts the masks.  Per pair of lengths: v_pk_sub_i16, v_pk_lshrrev_b16, v_dot2_u32_u16 --
+// no memory, no VCC chains, identical in every lane.
 struct Code {
     s16x2 lim1[8];
     u16x2 dd[8];
@@ -176,16 +187,14 @@ struct Code {
 
 __device__ __forceinline__ void decode_len(const Code& C, uint32_t v, int* len, uint32_t* delta) {
     const s16x2 vv = {(short)v, (short)v};
-    s16x2 cnt = {0, 0};
-    u16x2 acc = {0, 0};
+    uint32_t acc = C.d1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const s16x2 m = (C.lim1[j] - vv) >> 15;          // 0xFFFF where v >= limit
-        cnt -= m;
-        acc += (u16x2)m & C.dd[j];
+        const u16x2 m = (u16x2)(C.lim1[j] - vv) >> 15;   // 1 where v >= limit
+        acc = __builtin_amdgcn_udot2(m, C.dd[j], acc, false);
     }
-    *len = 1 + (int)cnt.x + (int)cnt.y;
-    *delta = (C.d1 + (uint32_t)acc.x + (uint32_t)acc.y) & 0xFFFFu;
+    *len = 1 + (int)(acc >> 13);
+    *delta = acc;                                        // low 9 bits: the caller masks
 }
 
 // Build one canonical code from `n` code lengths in lens[] (global scratch, 1 byte each): symbol
@@ -220,9 +229,10 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         C.lim1[j] = s16x2{(short)(lim[2 * j + 1] - 1), (short)(lim[2 * j + 2] - 1)};
-        C.dd[j] = u16x2{(unsigned short)(D[2 * j + 2] - D[2 * j + 1]), (unsigned short)(D[2 * j + 3] - D[2 * j + 2])};
+        C.dd[j] = u16x2{(unsigned short)(((D[2 * j + 2] - D[2 * j + 1]) & 0x1FFu) | 0x2000u),
+                        (unsigned short)(((D[2 * j + 3] - D[2 * j + 2]) & 0x1FFu) | 0x2000u)};
     }
-    C.d1 = D[1] & 0xFFFFu;
+    C.d1 = D[1] & 0x1FFu;
     if (!ok) return false;
     if (kIsLit) {
 #pragma unroll
@@ -273,13 +283,19 @@ struct Emitter {
         push_byte(byte);
         ++n_lit;
         if ((n_lit & 15u) == 0) store16(lit + n_lit - 16, la);
-        if (++run == 255) { push_entry(make_entry(255, 0, 1)); run = 0; }
+        ++run;
+    }
+    // an entry carries at most 255 literals: longer runs are split here, not in the per-literal path
+    __device__ __forceinline__ void split_run() {
+        while (run > 255u) { push_entry(make_entry(255, 0, 1)); run -= 255u; }
     }
     __device__ __forceinline__ void match(uint32_t len, uint32_t dist) {
+        split_run();
         push_entry(make_entry(run, len, dist));
         run = 0;
     }
     __device__ __forceinline__ void finish() {
+        split_run();
         if (run) { push_entry(make_entry(run, 0, 1)); run = 0; }
         const uint32_t rl = n_lit & 15u;
         if (rl) {
@@ -475,30 +491,23 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             for (int r = 0; r < kLitPerIter; ++r) {
                 if (sym_loop && msym == 0 && bad == INF_OK) {
                     br.refill();
-                    const uint32_t v = __brev(br.peek(15)) >> 17;
+                    const uint32_t v = __brev((uint32_t)br.buf) >> 17;
                     int len;
                     uint32_t delta;
                     decode_len(CL, v, &len, &delta);
                     const int lc = len > 15 ? 15 : len;
-                    uint32_t idx = (delta + (v >> (15 - lc))) & 0x1FFu;
-                    if (len > 15 || idx >= 288) bad = INF_BAD_SYMBOL;
-                    if (idx > 287) idx = 287;
+                    const uint32_t idx0 = (delta + (v >> (15 - lc))) & 0x1FFu;
+                    const uint32_t idx = idx0 > 287u ? 287u : idx0;
                     const uint32_t sym = (uint32_t)lds[kLitSymOff + idx] | (((uint32_t)lds[kLitHiOff + (idx >> 3)] >> (idx & 7)) & 1u) << 8;
                     br.drop(lc);
-                    if (bad == INF_OK) {
-                        if (sym < 256) {
-                            if (opos >= osize) bad = INF_OUTPUT_OVERRUN;
-                            else { ++opos; em.literal(sym); }
-                        } else if (sym == 256) {
-                            sym_loop = false;
-                        } else if (sym > 285) {
-                            bad = INF_BAD_SYMBOL;
-                        } else {
-                            msym = sym;
-                        }
-                    }
+                    const bool ok = len <= 15 && idx0 <= 287u && sym <= 285u;
+                    if (ok && sym < 256u) { ++opos; em.literal(sym); }     // (overrun: checked once per iteration below)
+                    sym_loop = !(ok && sym == 256u);
+                    msym = ok && sym > 256u ? sym : 0u;
+                    bad = ok ? INF_OK : INF_BAD_SYMBOL;
                 }
             }
+            if (opos > osize && bad == INF_OK) { bad = INF_OUTPUT_OVERRUN; msym = 0; }
             if (msym != 0) {
                 // match length (RFC 1951 3.2.5), computed arithmetically
                 uint32_t mlen;
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                     mlen = ((4 + ((msym - 261) & 3)) << e) + 3 + br.take((int)e);
                 }
                 br.refill();
-                const uint32_t dv = __brev(br.peek(15)) >> 17;
+                const uint32_t dv = __brev((uint32_t)br.buf) >> 17;
                 int dl;
                 uint32_t ddelta;
                 decode_len(CD, dv, &dl, &ddelta);
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     }
     em.finish();
     if (err == INF_OK && opos != osize) err = INF_SIZE_MISMATCH;
-    if (err == INF_OK && br.consumed > in_bits) err = INF_INPUT_OVERRUN;
+    if (err == INF_OK && br.consumed() > in_bits) err = INF_INPUT_OVERRUN;
     if (live) {
         status[b] = err;
         n_entries[b] = em.n_ent;
