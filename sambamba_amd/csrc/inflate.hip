@@ -509,38 +509,30 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             }
             if (opos > osize && bad == INF_OK) { bad = INF_OUTPUT_OVERRUN; msym = 0; }
             if (msym != 0) {
-                // match length (RFC 1951 3.2.5), computed arithmetically
-                uint32_t mlen;
-                if (msym < 265) mlen = msym - 254;
-                else if (msym == 285) mlen = 258;
-                else {
-                    const uint32_t e = (msym - 261) >> 2;
-                    br.refill();
-                    mlen = ((4 + ((msym - 261) & 3)) << e) + 3 + br.take((int)e);
-                }
+                // One refill covers the whole match: <= 5 length-extra + 15 code + 13 distance-extra bits.
                 br.refill();
+                // match length (RFC 1951 3.2.5), computed arithmetically, no branches
+                const uint32_t t = msym - 261u;                                     // valid for msym >= 265
+                const bool direct = msym < 265u || msym == 285u;
+                const uint32_t le = direct ? 0u : t >> 2;
+                const uint32_t lb = msym < 265u ? msym - 254u : msym == 285u ? 258u : ((4u + (t & 3u)) << le) + 3u;
+                const uint32_t mlen = lb + br.take((int)le);
                 const uint32_t dv = __brev((uint32_t)br.buf) >> 17;
                 int dl;
                 uint32_t ddelta;
                 decode_len(CD, dv, &dl, &ddelta);
                 const int dc = dl > 15 ? 15 : dl;
-                uint32_t didx = (ddelta + (dv >> (15 - dc))) & 0x1FFu;
-                if (dl > 15 || didx >= 30) bad = INF_BAD_DISTANCE;
-                if (didx > 31) didx = 31;
-                const uint32_t dsym = lds[kDistSymOff + didx];
+                const uint32_t didx0 = (ddelta + (dv >> (15 - dc))) & 0x1FFu;
+                const uint32_t dsym = lds[kDistSymOff + (didx0 > 31u ? 31u : didx0)];
                 br.drop(dc);
-                if (dsym > 29) bad = INF_BAD_DISTANCE;
-                uint32_t dist;
-                if (dsym < 4) dist = dsym + 1;
-                else {
-                    const uint32_t e = ((dsym >> 1) - 1) & 15u;
-                    dist = ((2 + (dsym & 1)) << e) + 1 + br.take((int)e);
-                }
-                if (bad == INF_OK) {
-                    if (dist > opos) bad = INF_BAD_DISTANCE;
-                    else if (opos + mlen > osize) bad = INF_OUTPUT_OVERRUN;
-                    else { opos += mlen; em.match(mlen, dist); }
-                }
+                // distance (RFC 1951 3.2.5)
+                const uint32_t de = dsym < 4u ? 0u : ((dsym >> 1) - 1u) & 15u;
+                const uint32_t db = dsym < 4u ? dsym + 1u : ((2u + (dsym & 1u)) << de) + 1u;
+                const uint32_t dist = db + br.take((int)de);
+                const bool code_ok = dl <= 15 && didx0 < 30u && dsym <= 29u && dist <= opos;
+                const bool fits = opos + mlen <= osize;
+                if (code_ok && fits) { opos += mlen; em.match(mlen, dist); }
+                bad = !code_ok ? (uint32_t)INF_BAD_DISTANCE : !fits ? (uint32_t)INF_OUTPUT_OVERRUN : bad;
             }
             if (bad != INF_OK) { err = bad; active = false; sym_loop = false; }
             br.service();
