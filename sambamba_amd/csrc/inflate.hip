@@ -41,12 +41,12 @@ namespace sbx {
 namespace {
 
 constexpr int kInfThreads = 64;              // K1a: one wavefront per workgroup, one lane per BGZF block
-constexpr int kLaneLds = 420;                // bytes of LDS per lane (105 dwords: odd stride)
+constexpr int kLaneLds = 356;                // bytes of LDS per lane (89 dwords: odd stride; 7 waves x 64 lanes fit 160 KiB)
 constexpr int kLitSymOff = 0;                // u8[288]  low 8 bits of literal/length symbols, canonical order
 constexpr int kLitHiOff = 288;               // u8[36]   bit 8 of those symbols, bit-packed
-constexpr int kDistSymOff = 324;             // u8[32]   distance symbols, canonical order
-constexpr int kTmpOff = 356;                 // u16[16]  scratch of build_code (counting sort positions)
-constexpr int kRingOff = 388;                // u32[8]   input ring (32 bytes of this lane's compressed payload)
+constexpr int kRingOff = 324;                // u32[8]   input ring (32 bytes of this lane's compressed payload)
+constexpr int kClLenOff = 32;                // u8[19]   code-length code lengths while a dynamic header is parsed (in the
+                                             //          literal area, which is rebuilt afterwards; its symbols sit at 0..18)
 constexpr int kLensScratch = 320;            // bytes of global scratch per lane: code lengths being built
 
 enum : uint32_t {
@@ -197,18 +197,64 @@ __device__ __forceinline__ void decode_len(const Code& C, uint32_t v, int* len, 
     *delta = acc;                                        // low 9 bits: the caller masks
 }
 
+// 16 small counters of a lane (code length -> count / insert position) packed two per VGPR.  Indexed
+// by a per-lane value, so every access is an unrolled compare-select over the 8 registers: ~25 VALU
+// ops, used a few hundred times per deflate block -- and 32 bytes of LDS per lane saved, which is what
+// lets a seventh wave onto the CU.
+struct Pack16 {
+    uint32_t r[8];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = 0;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t l) const {
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v = (l >> 1) == (uint32_t)j ? r[j] : v;
+        return (v >> (16u * (l & 1u))) & 0xFFFFu;
+    }
+    __device__ __forceinline__ void add(uint32_t l, uint32_t x) {     // no carry between the halves: values < 2^16
+        const uint32_t a = x << (16u * (l & 1u));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += (l >> 1) == (uint32_t)j ? a : 0u;
+    }
+    __device__ __forceinline__ void set(uint32_t l, uint32_t x) { add(l, x - get(l)); }
+};
+
+// The <= 30 distance symbols in canonical order, 5 bits each, six per VGPR.
+struct DistSyms {
+    uint32_t r[5];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) r[j] = 0;
+    }
+    __device__ __forceinline__ void put(uint32_t idx, uint32_t sym) {   // idx < 30, slot still zero
+        const uint32_t w = (idx * 43u) >> 8, a = sym << (5u * (idx - 6u * w));
+#pragma unroll
+        for (int j = 0; j < 5; ++j) r[j] |= w == (uint32_t)j ? a : 0u;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t idx) const {       // idx < 30
+        const uint32_t w = (idx * 43u) >> 8;
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v = w == (uint32_t)j ? r[j] : v;
+        return (v >> (5u * (idx - 6u * w))) & 31u;
+    }
+};
+
 // Build one canonical code from `n` code lengths in lens[] (global scratch, 1 byte each): symbol
 // permutation to LDS, limits/deltas to registers.  Returns false on an over-subscribed code.
 // (Incomplete codes are accepted, as zlib accepts the single-code distance tree; an unused code
 // decodes as "invalid symbol".)
 template <bool kIsLit>
-__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* lds, uint16_t* tmp, Code& C) {
-#pragma unroll
-    for (int l = 0; l < 16; ++l) tmp[l] = 0;
-    for (int s = 0; s < n; ++s) tmp[lens[s]] += 1;
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* lds, DistSyms& DS, Code& C) {
+    Pack16 tmp;
+    tmp.clear();
+    for (int s = 0; s < n; ++s) tmp.add(lens[s] & 15u, 1u);
     uint32_t cnt[16];
 #pragma unroll
-    for (int l = 0; l < 16; ++l) cnt[l] = tmp[l];
+    for (int l = 0; l < 16; ++l) cnt[l] = (tmp.r[l >> 1] >> (16 * (l & 1))) & 0xFFFFu;
+    tmp.clear();
     uint32_t first = 0, offs = 0;
     int32_t left = 1;
     bool ok = true;
@@ -219,7 +265,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
         if (left < 0) ok = false;
         lim[l] = (first + cnt[l]) << (15 - l);
         D[l] = offs - first;                   // delta of length l (mod 2^16 is all that matters)
-        tmp[l] = (uint16_t)offs;               // running insert position during the sort below
+        tmp.r[l >> 1] |= offs << (16 * (l & 1));   // running insert position during the sort below
         offs += cnt[l];
         first = (first + cnt[l]) << 1;
     }
@@ -238,16 +284,17 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
 #pragma unroll
         for (int i = 0; i < 9; ++i) ((uint32_t*)(lds + kLitHiOff))[i] = 0;
     }
+    if (!kIsLit) DS.clear();
     for (int s = 0; s < n; ++s) {
-        uint32_t l = lens[s];
+        uint32_t l = lens[s] & 15u;
         if (l) {
-            uint32_t idx = tmp[l];
-            tmp[l] = (uint16_t)(idx + 1);
+            uint32_t idx = tmp.get(l);
+            tmp.add(l, 1u);
             if (kIsLit) {
                 lds[kLitSymOff + idx] = (uint8_t)s;
                 if (s & 256) lds[kLitHiOff + (idx >> 3)] |= (uint8_t)(1u << (idx & 7));
-            } else {
-                lds[kDistSymOff + idx] = (uint8_t)s;
+            } else if (idx < 30u) {
+                DS.put(idx, (uint32_t)s);
             }
         }
     }
@@ -324,7 +371,8 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint32_t b = live ? b_raw : n_blocks - 1;
     uint8_t* lds = smem + threadIdx.x * kLaneLds;
     uint8_t* lens = lens_scratch + (size_t)b * kLensScratch;
-    uint16_t* tmp = (uint16_t*)(lds + kTmpOff);
+    DistSyms DS;
+    DS.clear();
 
     const uint8_t* in = comp + comp_off[b];
     const uint32_t in_bits = comp_len[b] * 8u;
@@ -389,7 +437,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         uint32_t ccnt[8];
 #pragma unroll
         for (int l = 0; l < 8; ++l) ccnt[l] = 0;
-        uint8_t* cl_len = lds + kDistSymOff;   // [19] parked in the symbol areas (rebuilt below)
+        uint8_t* cl_len = lds + kClLenOff;     // [19] parked in the literal symbol area (rebuilt below)
         uint8_t* cl_sym = lds + kLitSymOff;    // [19] symbols sorted by (length, value)
         int ncl_left = 0, cl_i = 0;
         bool dyn = active && btype == 2;
@@ -475,8 +523,8 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         }
         bool sym_loop = huff && active;
         if (sym_loop) {
-            if (!build_code<true>(lens, nlit, lds, tmp, CL)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
-            else if (!build_code<false>(lens + nlit, ndist, lds, tmp, CD)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
+            if (!build_code<true>(lens, nlit, lds, DS, CL)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
+            else if (!build_code<false>(lens + nlit, ndist, lds, DS, CD)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
         }
 
         // ---- symbol loop -----------------------------------------------------------------
@@ -523,7 +571,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                 decode_len(CD, dv, &dl, &ddelta);
                 const int dc = dl > 15 ? 15 : dl;
                 const uint32_t didx0 = (ddelta + (dv >> (15 - dc))) & 0x1FFu;
-                const uint32_t dsym = lds[kDistSymOff + (didx0 > 31u ? 31u : didx0)];
+                const uint32_t dsym = DS.get(didx0 > 29u ? 29u : didx0);
                 br.drop(dc);
                 // distance (RFC 1951 3.2.5)
                 const uint32_t de = dsym < 4u ? 0u : ((dsym >> 1) - 1u) & 15u;
