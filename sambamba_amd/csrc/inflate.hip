@@ -621,30 +621,27 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-// registers of one short copy task (n <= 16): full dwords, then a tail dword overlapping the last one
+// One short copy task (n <= 16) of a lane, loads and stores separated so that a caller can put the loads
+// of several tasks in flight before the first store.  n >= 4: four dwords at offsets min(4k, n - 4) --
+// the ones past the end collapse onto the tail dword, so nothing is predicated per dword.  n < 4: one
+// dword is read (the over-read stays inside the padded buffers) and 1..3 bytes of it are written.
 struct Short16 {
-    uint32_t w[4], wt;
+    uint32_t w[4];
     __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
-        const uint32_t nf = n >> 2;
+        if (n >= 4) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)k < nf ? ldu32(s + 4 * k) : 0u;
-        wt = n >= 4 ? ldu32(s + n - 4) : 0u;
-        if (n && n < 4) {          // 1..3 bytes: gathered into w[0]
-            w[0] = s[0];
-            if (n > 1) w[0] |= (uint32_t)s[1] << 8;
-            if (n > 2) w[0] |= (uint32_t)s[2] << 16;
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; w[k] = ldu32(s + o); }
+        } else if (n) {
+            w[0] = ldu32(s);
         }
     }
     __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
         if (n >= 4) {
-            const uint32_t nf = n >> 2;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if ((uint32_t)k < nf) stu32(d + 4 * k, w[k]);
-            stu32(d + n - 4, wt);
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; stu32(d + o, w[k]); }
         } else if (n) {
-            d[0] = (uint8_t)w[0];
-            if (n > 1) d[1] = (uint8_t)(w[0] >> 8);
-            if (n > 2) d[2] = (uint8_t)(w[0] >> 16);
+            if (n & 2u) { const uint16_t h = (uint16_t)w[0]; __builtin_memcpy(d, &h, 2); }
+            if (n & 1u) d[n & 2u] = (uint8_t)(w[0] >> (8u * (n & 2u)));
         }
     }
 };
