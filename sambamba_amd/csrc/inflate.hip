@@ -612,12 +612,16 @@ constexpr uint32_t kSpanMax = 1536;         // output bytes per batch (a batch i
 constexpr uint32_t kCap = 5120;             // LDS bytes per wave: kHist + slide hysteresis + kSpanMax
 constexpr uint32_t kWaveLds = kCap + 16;
 
+// inclusive prefix sum over the 64 lanes: four row-shift steps inside each row of 16 lanes, then the row
+// totals are broadcast across rows (DPP row_bcast15 / row_bcast31) -- VALU only, no LDS crossbar trips
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v += t;
-    }
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
