@@ -176,6 +176,8 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "algorithmic_bytes_per_launch": int(alg[dom]), "kernel_ms": round(kern[dom], 4)}
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
+        if args.length == CHR1_LEN:
+            roof.update(pmc_traffic(dom))
         per_kernel = {k: {"ms": round(kern[k], 4), "algorithmic_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 2),
                           "frac_of_hbm_peak": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in kern}
         cpu = None
@@ -202,6 +204,38 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+PMC_KERNELS = {"huffman_decode": ["k_huffman_decode"], "lz77_resolve": ["k_lz77_resolve"],
+               "record_index": ["k_block_walk", "k_chain_check", "k_chain_repair", "k_count_scan", "k_describe", "k_tile_compact"],
+               "decode_accumulate": ["k_accumulate"]}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same workload
+    (tools/profile_round.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, KiB).
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is."""
+    path = os.path.join(ROOT, "profiles", "round1", "pmc_fetch_write_chr1_30x.csv")
+    if not os.path.exists(path):
+        return {}
+    fetch = write = 0.0
+    best = {}
+    with open(path) as fh:
+        next(fh)
+        for ln in fh:
+            k, c, v, _ = ln.strip().split(",")
+            if k in PMC_KERNELS[kernel]:
+                best[(k, c)] = max(best.get((k, c), 0.0), float(v))     # the full-size launch
+    for (k, c), v in best.items():
+        if c == "FETCH_SIZE":
+            fetch += v * 1024
+        else:
+            write += v * 1024
+    if not fetch and not write:
+        return {}
+    return {"traffic": int(2 * fetch + write), "traffic_unit": "bytes per launch",
+            "traffic_source": "profiles/round1/pmc_fetch_write_chr1_30x.csv (rocprofv3 PMC, separate passes; "
+                              "FETCH_SIZE raw %.2f GB doubled, WRITE_SIZE %.2f GB)" % (fetch / 1e9, write / 1e9)}
 
 
 if __name__ == "__main__":
