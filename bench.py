@@ -60,26 +60,36 @@ def generate(path, length, coverage, seed, level, codec):
 
 
 def cpu_baseline(bam, sample_reads):
-    """Reference-algorithm CPU stand-in: the oracle CLI (single-threaded sweep-line pileup + text
-    formatting, zlib inflate on the same thread = sambamba's default of 0 worker threads,
-    depth.d:1081,1154) on the first `sample_reads` records of the same BAM, output to /dev/null."""
+    """Reference-algorithm CPU stand-in: the oracle CLI on the first `sample_reads` records of the same
+    BAM, output to /dev/null.  Structured like the reference: zlib inflate on a pool of worker threads
+    with in-order delivery (`-t`), then the single-threaded sweep-line pileup + text formatting.  Timed
+    twice -- sambamba's default (`-t 0`: everything on one thread, depth.d:1081,1154) and with 16 inflate
+    workers -- and the faster one is reported (the serial sweep bounds what more threads can buy)."""
     exe = os.path.join(ROOT, "oracle", "depth_oracle")
-    t0 = time.time()
     env = dict(os.environ, ORC_STATS="1")
-    r = subprocess.run([exe, "base", "--max-reads", str(sample_reads), bam], stdout=subprocess.DEVNULL,
-                       stderr=subprocess.PIPE, env=env)
-    dt = time.time() - t0
-    if r.returncode != 0:
+    runs = []
+    for workers in (0, max(1, min(16, (os.cpu_count() or 2) - 1))):
+        t0 = time.time()
+        r = subprocess.run([exe, "base", "-t", str(workers), "--max-reads", str(sample_reads), bam],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+        dt = time.time() - t0
+        if r.returncode != 0:
+            continue
+        secs, seen = dt, sample_reads
+        for line in r.stderr.decode().splitlines():
+            if line.startswith("[oracle]"):
+                parts = line.split()
+                secs = float(parts[1])
+                seen = int(parts[3])
+        runs.append({"workers": workers, "mreads_per_s": seen / secs / 1e6, "secs": secs, "seen": seen})
+    if not runs:
         return None
-    secs, seen = dt, sample_reads
-    for line in r.stderr.decode().splitlines():
-        if line.startswith("[oracle]"):
-            parts = line.split()
-            secs = float(parts[1])
-            seen = int(parts[3])
-    return {"value": round(seen / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
-            "sample": "first %d records of the same BAM, depth base -> /dev/null, %.1f s wall" % (seen, secs),
-            "threads_note": "sambamba depth default: 0 worker threads (fully serial); nproc=%d" % (os.cpu_count() or 0)}
+    best = max(runs, key=lambda x: x["mreads_per_s"])
+    return {"value": round(best["mreads_per_s"], 4), "unit": "Mreads/s", "cores": best["workers"] + 1, "kind": "port",
+            "sample": "first %d records of the same BAM, depth base -> /dev/null, %.1f s wall" % (best["seen"], best["secs"]),
+            "runs": [{"inflate_workers": x["workers"], "Mreads_per_s": round(x["mreads_per_s"], 4)} for x in runs],
+            "threads_note": "sambamba depth default is 0 worker threads (fully serial); the sweep-line pileup and the "
+                            "text output are single-threaded in the reference whatever -t says; nproc=%d" % (os.cpu_count() or 0)}
 
 
 def main():
