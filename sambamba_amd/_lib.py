@@ -56,6 +56,8 @@ class RunStats(C.Structure):
 
 
 # every symbol include/sbx_depth.h declares (checked by tests/test_abi.py)
+ENOMEM = -8
+
 EXPORTS = [
     "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
     "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_set_params",
@@ -220,6 +222,21 @@ class Depth:
         cov = np.zeros((count, S, max(1, n_thresholds)), dtype=np.uint32)
         self._check(self._L.sbx_depth_window_stats(self._ctx, ref_id, first, count, st.ctypes.data, cov.ctypes.data))
         return st[:, :, 0].copy(), st[:, :, 1].copy(), cov[:, :, :n_thresholds].copy()
+
+    def format_base_rows(self, ref_id, beg, end, min_cov=1.0, max_cov=float("inf"), annotate=False):
+        """Text of `depth base` for [beg, end) of ref_id, formatted on the device (bytes)."""
+        need = C.c_size_t(0)
+        cap = max(1 << 16, (end - beg) * 40 * self.n_samples_eff)
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            rc = self._L.sbx_format_base_rows(self._ctx, ref_id, beg, end, float(min_cov), float(max_cov), int(annotate),
+                                              buf, cap, C.byref(need))
+            if rc == ENOMEM and need.value > cap:
+                cap = need.value
+                continue
+            self._check(rc)
+            return buf.raw[:need.value]
+        self._check(rc)
 
     def base_counters(self, ref_id, beg, end, with_covered=False):
         S = self.n_samples_eff

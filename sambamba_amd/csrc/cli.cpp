@@ -185,7 +185,65 @@ public:
         h += "\n";
         out_.put(h);
     }
+    // Device-formatted output (K6, sbx_format_base_rows): without -L the text is a pure function of the
+    // position -- a column's rows, or with min_cov == 0 all-zero rows for every position of every contig
+    // (what push/close/writeEmptyColumns add up to) -- and with -L and min_cov > 0 it is the same restricted
+    // to the merged regions (outputRequired, depth.d:558-565).  -L with min_cov == 0 keeps the stateful
+    // host emulation below (raw BED consumption quirks of writeEmptyColumns).
+    bool device_format_applies() const {
+        if (getenv("SBX_HOST_FORMAT")) return false;
+        if (o_.min_cov < 0) return false;
+        return !bed_provided_ || o_.min_cov > 0;
+    }
+    void run_device() {
+        std::vector<char> text;
+        const uint64_t CH = 8u << 20;      // positions per call (~300 MB of text at one sample)
+        auto range = [&](uint32_t r, uint64_t b, uint64_t e) {
+            for (uint64_t p = b; p < e; p += CH) {
+                const uint64_t q = std::min(e, p + CH);
+                size_t need = 0;
+                if (text.size() < (size_t)(q - p) * 40) text.resize((size_t)(q - p) * 40);
+                int rc = sbx_format_base_rows(c_, r, (uint32_t)p, (uint32_t)q, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
+                                              text.data(), text.size(), &need);
+                if (rc == SBX_ENOMEM && need > text.size()) {
+                    text.resize(need);
+                    rc = sbx_format_base_rows(c_, r, (uint32_t)p, (uint32_t)q, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
+                                              text.data(), text.size(), &need);
+                }
+                check(c_, rc);
+                out_.flush();
+                fwrite(text.data(), 1, need, out_.fp);
+            }
+        };
+        if (bed_provided_) {      // merged, sorted regions
+            for (auto& g : bed_) range(g.ref_id, g.start, g.end);
+            return;
+        }
+        for (int r = 0; r < n_ref_; ++r) {
+            const uint64_t len = (uint64_t)sbx_ref_length(c_, r);
+            if (o_.min_cov == 0) range((uint32_t)r, 0, len);      // every position of the contig has rows
+            uint64_t from = o_.min_cov == 0 ? len : 0;
+            for (;;) {       // otherwise only stretches with admitted reads can have rows
+                uint64_t b, e;
+                check(c_, sbx_next_active_range(c_, (uint32_t)r, from, &b, &e));
+                if (b == ~0ULL) break;
+                b = std::max(b, from);
+                if (o_.min_cov == 0) host_columns(r, b, e);       // alignments hanging over the contig end: columns only
+                else range((uint32_t)r, b, e);
+                from = e;
+            }
+        }
+    }
+    void host_columns(int r, uint64_t b, uint64_t e) {
+        std::vector<uint32_t> cnt((size_t)(e - b) * S_ * SBX_NCOUNTERS);
+        std::vector<uint8_t> cov((size_t)(e - b));
+        check(c_, sbx_depth_base_tile(c_, (uint32_t)r, (uint32_t)b, (uint32_t)e, cnt.data(), cov.data()));
+        for (uint64_t x = b; x < e; ++x)
+            if (cov[(size_t)(x - b)]) write_column(r, (int64_t)x, &cnt[(size_t)(x - b) * S_ * SBX_NCOUNTERS]);
+        out_.flush();
+    }
     void run() {
+        if (device_format_applies()) { run_device(); return; }
         std::vector<uint32_t> cnt;
         std::vector<uint8_t> cov;
         const uint64_t CH = 1u << 20;

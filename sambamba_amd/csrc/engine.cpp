@@ -77,6 +77,10 @@ struct sbx_ctx {
     DevBuf<uint32_t> d_rg_off;
     DevBuf<uint16_t> d_rg_sample;
     DevBuf<IndexStats> d_stats;
+    DevBuf<uint32_t> d_fmt_len, d_fmt_soff;
+    DevBuf<uint64_t> d_fmt_off;
+    DevBuf<uint8_t> d_fmt_text;
+    DevBuf<char> d_fmt_names;
     bool tables_uploaded = false;
 
     // results of the last run
@@ -830,9 +834,70 @@ int sbx_depth_window_stats(sbx_ctx* c, uint32_t ref_id, uint64_t first_win, uint
         range_stats(c, ranges, true, (uint32_t)w, wb, nw, stats, cov_counts, nullptr);
     });
 }
-int sbx_format_base_rows(sbx_ctx* c, uint32_t, uint32_t, uint32_t, double, double, int, char*, size_t, size_t*) {
-    if (c) c->last_error = "device-side row formatting is not implemented yet";
-    return SBX_EUNSUPPORTED;
+// K6: the text of `depth base` for [beg, end) of ref_id, formatted on the device (format.hip).
+int sbx_format_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov, int annotate,
+                         char* out, size_t cap, size_t* out_len) {
+    return guarded(c, [&] {
+        if (!c || !out_len) throw Error(SBX_EINVAL, "null argument");
+        if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
+        if (c->mode != SBX_MODE_BASE) throw Error(SBX_EINVAL, "sbx_format_base_rows needs a `depth base` run");
+        if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
+        SBX_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        *out_len = 0;
+        if (beg == end) return;
+        const uint32_t S = c->n_samples_eff;
+        // names blob: contig name, then the sample names ("*" when the header has no read groups, as the CLI prints)
+        std::string blob = c->hdr.refs[ref_id].name;
+        std::vector<uint32_t> soff;
+        for (uint32_t i = 0; i < S; ++i) {
+            soff.push_back((uint32_t)blob.size());
+            if (!c->combined && i < c->hdr.sample_names.size()) blob += c->hdr.sample_names[i];
+        }
+        soff.push_back((uint32_t)blob.size());
+        c->d_fmt_names.ensure(blob.size() + 1);
+        c->d_fmt_soff.ensure(soff.size());
+        SBX_HIP(hipMemcpyAsync(c->d_fmt_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_fmt_soff.p, soff.data(), soff.size() * 4, hipMemcpyHostToDevice, s));
+        FormatArgs a{};
+        a.counters = c->d_counters.p;
+        a.span = c->span_valid ? c->d_span.p : nullptr;
+        a.slot_of = c->d_slot_of.p;
+        a.tile_first = c->h_tile_base[ref_id];
+        a.tile_end = c->h_tile_base[ref_id + 1];
+        a.T = c->tile_pos;
+        a.S = S;
+        a.beg = beg;
+        a.end = end;
+        // COV is an integer: the reference's double comparisons (depth.d:538) become integer bounds
+        if (!(max_cov >= 0) || !(min_cov <= max_cov)) { a.lo = 1; a.hi = 0; }
+        else {
+            a.lo = min_cov <= 0 ? 0 : (min_cov >= 1.8e19 ? ~0ull : (uint64_t)std::ceil(min_cov));
+            a.hi = max_cov >= 1.8e19 ? ~0ull : (uint64_t)std::floor(max_cov);
+        }
+        a.annotate = annotate ? 1u : 0u;
+        a.combined = c->combined ? 1u : 0u;
+        a.zero_fill = min_cov <= 0 ? 1u : 0u;
+        a.names = c->d_fmt_names.p;
+        a.ref_name_len = (uint32_t)c->hdr.refs[ref_id].name.size();
+        a.sample_off = c->d_fmt_soff.p;
+        const uint32_t per = format_chunk_positions();
+        const uint32_t n_chunks = (uint32_t)(((uint64_t)(end - beg) + per - 1) / per);
+        c->d_fmt_len.ensure(n_chunks);
+        c->d_fmt_off.ensure((size_t)n_chunks + 1);
+        launch_format_measure(a, n_chunks, c->d_fmt_len.p, s);
+        launch_count_scan(c->d_fmt_len.p, n_chunks, c->d_fmt_off.p, nullptr, 0, s);
+        uint64_t total = 0;
+        SBX_HIP(hipMemcpyAsync(&total, c->d_fmt_off.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+        *out_len = (size_t)total;
+        if (total > cap || (!out && total)) throw Error(SBX_ENOMEM, "output buffer too small for the formatted rows");
+        if (!total) return;
+        c->d_fmt_text.ensure((size_t)total + 64);
+        launch_format_write(a, n_chunks, c->d_fmt_off.p, c->d_fmt_text.p, s);
+        SBX_HIP(hipMemcpyAsync(out, c->d_fmt_text.p, (size_t)total, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+    });
 }
 
 // extent of the tile grid of a contig (positions) and activity of a tile -- used by the CLI to skip

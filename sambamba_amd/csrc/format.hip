@@ -1,0 +1,177 @@
+// format.hip -- K6 `format_base_rows`: the text of `sambamba depth base` written on the device.
+//
+// Replaces PerBasePrinter.writeColumn (sambamba/depth.d:534-555) and the zero-coverage rows of
+// writeEmptyColumns (depth.d:452-487) for a position range of one contig:
+// without it the end-to-end rate is bounded by the host formatting ~35 bytes for each of 10^8..10^9
+// positions.  A row is
+//     REF \t POS \t COV \t A \t C \t G \t T \t DEL \t REFSKIP [\t SAMPLE] [\t y|n] \n
+// per sample, in sample order; the loop over samples RETURNS at the first sample whose COV is outside
+// [min_cov, max_cov] unless rows are annotated (depth.d:540-541).  A position takes part iff a pileup
+// column exists there (>= 1 admitted read spans it) or min_cov == 0, in which case positions without a
+// column print all-zero rows -- the same text writeEmptyColumns produces from its precomputed tails.
+//
+// Two passes over the counter tiles with the same emitter: pass 1 only adds up the bytes of every
+// 256-position chunk, a scan turns them into offsets, pass 2 builds each chunk's text in LDS (one
+// position per lane) and streams it to HBM 16 bytes per lane, contiguous.  HBM-bound: 28 B of counters
+// read twice + ~35 B of text written per position and sample.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace sbx {
+
+namespace {
+
+constexpr int kFmtThreads = 256;
+constexpr uint32_t kFmtLds = 48 * 1024;     // text of one chunk; chunks that do not fit are written byte-wise to HBM
+
+__device__ __forceinline__ uint32_t n_digits(uint64_t v) {
+    uint32_t n = 1;
+    if (v >= 10000000000ull) { v /= 10000000000ull; n += 10; }
+    const uint32_t w = (uint32_t)v;
+    n += (w >= 10u) + (w >= 100u) + (w >= 1000u) + (w >= 10000u) + (w >= 100000u) + (w >= 1000000u) + (w >= 10000000u) +
+         (w >= 100000000u) + (w >= 1000000000u);
+    return n;
+}
+
+// byte sink: kWrite == false only counts
+template <bool kWrite>
+struct Sink {
+    uint8_t* p;
+    uint32_t n;
+    __device__ __forceinline__ void ch(char c) {
+        if (kWrite) p[n] = (uint8_t)c;
+        ++n;
+    }
+    __device__ __forceinline__ void str(const char* s, uint32_t len) {
+        if (kWrite) for (uint32_t i = 0; i < len; ++i) p[n + i] = (uint8_t)s[i];
+        n += len;
+    }
+    __device__ __forceinline__ void num(uint64_t v) {
+        const uint32_t nd = n_digits(v);
+        if (kWrite) {
+            if (v <= 0xFFFFFFFFull) {
+                uint32_t w = (uint32_t)v;
+                for (uint32_t i = nd; i-- > 0;) { p[n + i] = (uint8_t)('0' + w % 10u); w /= 10u; }
+            } else {
+                for (uint32_t i = nd; i-- > 0;) { p[n + i] = (uint8_t)('0' + v % 10u); v /= 10u; }
+            }
+        }
+        n += nd;
+    }
+};
+
+template <bool kWrite>
+__device__ uint32_t emit_position(const FormatArgs& a, uint32_t pos, uint8_t* dst) {
+    const uint32_t tile = a.tile_first + pos / a.T;
+    const uint32_t slot = tile < a.tile_end ? a.slot_of[tile] : 0xFFFFFFFFu;
+    const uint32_t in_tile = pos & (a.T - 1u);
+    const uint32_t* c = slot != 0xFFFFFFFFu ? a.counters + ((size_t)slot * a.T + in_tile) * a.S * 7u : nullptr;
+    bool column = false;      // does a pileup column exist here?
+    if (c) {
+        if (a.span) column = a.span[(size_t)slot * a.T + in_tile] != 0;
+        else {
+            uint32_t any = 0;
+            for (uint32_t k = 0; k < a.S * 7u; ++k) any |= c[k];
+            column = any != 0;
+        }
+    }
+    if (!column && !a.zero_fill) return 0;
+    Sink<kWrite> o{dst, 0};
+    for (uint32_t s = 0; s < a.S; ++s) {
+        uint32_t v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = column ? c[s * 7u + k] : 0u;
+        const uint64_t total = (uint64_t)v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6];
+        const bool ok = total >= a.lo && total <= a.hi;
+        if (!ok && !a.annotate) break;                       // return, not continue (depth.d:540-541)
+        o.str(a.names, a.ref_name_len);
+        o.ch('\t'); o.num(pos);
+        o.ch('\t'); o.num(total);
+        o.ch('\t'); o.num(v[0]);
+        o.ch('\t'); o.num(v[1]);
+        o.ch('\t'); o.num(v[2]);
+        o.ch('\t'); o.num(v[3]);
+        o.ch('\t'); o.num(v[5]);
+        o.ch('\t'); o.num(v[6]);
+        if (!a.combined) {
+            const uint32_t so = a.sample_off[s], sl = a.sample_off[s + 1] - so;
+            o.ch('\t');
+            o.str(a.names + so, sl);
+        }
+        if (a.annotate) { o.ch('\t'); o.ch(ok ? 'y' : 'n'); }
+        o.ch('\n');
+    }
+    return o.n;
+}
+
+__device__ __forceinline__ uint32_t wave_incl(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if ((int)lane >= d) v += t;
+    }
+    return v;
+}
+
+// pass 1: bytes of every chunk of kFmtThreads positions
+__global__ __launch_bounds__(kFmtThreads) void k_format_measure(FormatArgs a, uint32_t* __restrict__ chunk_len) {
+    __shared__ uint32_t wsum[kFmtThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const uint64_t pos = (uint64_t)a.beg + (uint64_t)blockIdx.x * kFmtThreads + t;
+    const uint32_t n = pos < a.end ? emit_position<false>(a, (uint32_t)pos, nullptr) : 0u;
+    const uint32_t inc = wave_incl(n, lane);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    if (t == 0) chunk_len[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2: the text
+__global__ __launch_bounds__(kFmtThreads) void k_format_write(FormatArgs a, const uint64_t* __restrict__ chunk_off,
+                                                             uint8_t* __restrict__ text) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_text[];
+    __shared__ uint32_t wsum[kFmtThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const uint64_t pos = (uint64_t)a.beg + (uint64_t)blockIdx.x * kFmtThreads + t;
+    const uint64_t off = chunk_off[blockIdx.x];
+    const uint32_t total = (uint32_t)(chunk_off[blockIdx.x + 1] - off);
+    if (total == 0) return;
+    const uint32_t n = pos < a.end ? emit_position<false>(a, (uint32_t)pos, nullptr) : 0u;
+    const uint32_t inc = wave_incl(n, lane);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t my = inc - n;
+    for (uint32_t w = 0; w < wv; ++w) my += wsum[w];
+    uint8_t* out = text + off;
+    if (total > kFmtLds) {            // very long names: straight to HBM
+        if (n) emit_position<true>(a, (uint32_t)pos, out + my);
+        return;
+    }
+    if (n) emit_position<true>(a, (uint32_t)pos, lds_text + my);
+    __syncthreads();
+    for (uint32_t i = 16 * t; i < total; i += 16 * kFmtThreads) {
+        if (i + 16 <= total) {
+            const uint4 v = *(const uint4*)(lds_text + i);
+            __builtin_memcpy(out + i, &v, 16);
+        } else {
+            for (uint32_t k = i; k < total; ++k) out[k] = lds_text[k];
+        }
+    }
+}
+
+}  // namespace
+
+uint32_t format_chunk_positions() { return kFmtThreads; }
+
+void launch_format_measure(const FormatArgs& a, uint32_t n_chunks, uint32_t* d_chunk_len, hipStream_t stream) {
+    if (!n_chunks) return;
+    hipLaunchKernelGGL(k_format_measure, dim3(n_chunks), dim3(kFmtThreads), 0, stream, a, d_chunk_len);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_format_write(const FormatArgs& a, uint32_t n_chunks, const uint64_t* d_chunk_off, uint8_t* d_text, hipStream_t stream) {
+    if (!n_chunks) return;
+    hipLaunchKernelGGL(k_format_write, dim3(n_chunks), dim3(kFmtThreads), kFmtLds, stream, a, d_chunk_off, d_text);
+    SBX_HIP(hipGetLastError());
+}
+
+}  // namespace sbx

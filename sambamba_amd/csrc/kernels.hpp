@@ -140,4 +140,22 @@ void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint6
                                 const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first, uint32_t S,
                                 uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);
 
+// K6 format_base_rows (format.hip): text of `depth base` for positions [beg, end) of one contig
+struct FormatArgs {
+    const uint32_t* counters;     // per active tile u32[T][S][7]
+    const uint32_t* span;         // per active tile u32[T] or nullptr (then "column exists" == any counter != 0)
+    const uint32_t* slot_of;      // tile -> slot, 0xFFFFFFFF = no admitted read touches the tile
+    uint32_t tile_first, tile_end;    // tiles of this contig
+    uint32_t T, S;
+    uint32_t beg, end;
+    uint64_t lo, hi;              // rows are printed for lo <= COV <= hi (or flagged y/n when annotate)
+    uint32_t annotate, combined, zero_fill;
+    const char* names;            // device blob: contig name, then the sample names
+    uint32_t ref_name_len;
+    const uint32_t* sample_off;   // [S + 1] offsets of the sample names inside `names`
+};
+uint32_t format_chunk_positions();
+void launch_format_measure(const FormatArgs& a, uint32_t n_chunks, uint32_t* d_chunk_len, hipStream_t stream);
+void launch_format_write(const FormatArgs& a, uint32_t n_chunks, const uint64_t* d_chunk_off, uint8_t* d_text, hipStream_t stream);
+
 }  // namespace sbx
