@@ -38,6 +38,9 @@ extern (C) nothrow @nogc {
                        const(uint)* thresholds, int n_thresholds);
     int sbx_set_regions(sbx_ctx*, const(sbx_region)*, size_t);
     int sbx_run(sbx_ctx*);
+    struct sbx_batch { uint first_ref, n_refs; ulong est_bytes; }
+    int sbx_plan_batches(sbx_ctx*, ulong budget_bytes, sbx_batch* out_batches, size_t cap, size_t* n_out);
+    int sbx_run_batch(sbx_ctx*, uint first_ref, uint n_refs);
     int sbx_depth_base_tile(sbx_ctx*, uint ref_id, uint beg, uint end, uint* counters, ubyte* covered);
     int sbx_depth_region_stats(sbx_ctx*, const(sbx_region)*, size_t, sbx_region_stats*, uint* cov_counts, ubyte* seen);
     int sbx_depth_window_stats(sbx_ctx*, uint ref_id, ulong first_win, ulong n_win, sbx_region_stats*, uint* cov_counts);

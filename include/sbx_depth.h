@@ -145,6 +145,21 @@ int sbx_set_regions(sbx_ctx*, const sbx_region* regions, size_t n);
  * sbx_run()/sbx_close(); the sbx_depth_* getters below copy them out.  */
 int sbx_run(sbx_ctx*);
 
+/* Streaming over contigs.  One pass needs ~4.5 bytes of HBM per inflated byte (stream, token streams,
+ * descriptors, counter tiles), so a whole-genome BAM is processed as consecutive batches of contigs --
+ * the device-side counterpart of the reference's streaming BamReadRange (readrange.d:118-173).
+ * sbx_plan_batches splits contigs [0, n_ref) into the fewest consecutive batches whose estimated footprint
+ * stays below budget_bytes (0 = 70 % of the free device memory); an over-sized single contig gets a batch of
+ * its own.  sbx_run_batch is sbx_run() restricted to the reads of contigs [first_ref, first_ref + n_refs)
+ * (and to the regions of sbx_set_regions that lie on them, if any): afterwards the getters below answer for
+ * those contigs only.  Results of the previous run / batch are replaced. */
+typedef struct {
+    uint32_t first_ref, n_refs;
+    uint64_t est_bytes;
+} sbx_batch;
+int sbx_plan_batches(sbx_ctx*, uint64_t budget_bytes, sbx_batch* out, size_t cap, size_t* n_out);
+int sbx_run_batch(sbx_ctx*, uint32_t first_ref, uint32_t n_refs);
+
 /* depth base: counters[(pos-beg)*n_samples*7 + s*7 + k] for pos in [beg,end) of ref_id
  * (k = A,C,G,T,other,DEL,REFSKIP; n_samples = 1 when --combined).  Positions no admitted read
  * spans are all-zero.  covered (optional, may be NULL): 1 byte per position, non-zero iff >= 1

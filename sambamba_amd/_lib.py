@@ -58,11 +58,15 @@ class RunStats(C.Structure):
 # every symbol include/sbx_depth.h declares (checked by tests/test_abi.py)
 ENOMEM = -8
 
+
+class Batch(C.Structure):
+    _fields_ = [("first_ref", C.c_uint32), ("n_refs", C.c_uint32), ("est_bytes", C.c_uint64)]
+
 EXPORTS = [
     "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
     "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_set_params",
     "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_window_stats",
-    "sbx_format_base_rows", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
+    "sbx_format_base_rows", "sbx_plan_batches", "sbx_run_batch", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
 ]
 
 _lib = None
@@ -115,6 +119,8 @@ def lib():
     L.sbx_depth_window_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     L.sbx_format_base_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_int,
                                        C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sbx_plan_batches.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sbx_run_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.sbx_last_run_stats.argtypes = [C.c_void_p, C.POINTER(RunStats)]
     L.sbx_tile_info.argtypes = [C.c_void_p, u32p, u32p]
     L.sbx_next_active_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, u64p, u64p]
@@ -222,6 +228,21 @@ class Depth:
         cov = np.zeros((count, S, max(1, n_thresholds)), dtype=np.uint32)
         self._check(self._L.sbx_depth_window_stats(self._ctx, ref_id, first, count, st.ctypes.data, cov.ctypes.data))
         return st[:, :, 0].copy(), st[:, :, 1].copy(), cov[:, :, :n_thresholds].copy()
+
+    def plan_batches(self, budget_bytes=0):
+        """[(first_ref, n_refs, est_bytes)]: consecutive batches of contigs that fit the device (sbx_plan_batches)."""
+        n = C.c_size_t(0)
+        self._check(self._L.sbx_plan_batches(self._ctx, int(budget_bytes), None, 0, C.byref(n)))
+        arr = (Batch * max(1, n.value))()
+        self._check(self._L.sbx_plan_batches(self._ctx, int(budget_bytes), arr, n.value, C.byref(n)))
+        return [(arr[i].first_ref, arr[i].n_refs, arr[i].est_bytes) for i in range(n.value)]
+
+    def run_batch(self, first_ref, n_refs):
+        """sbx_run restricted to the reads of contigs [first_ref, first_ref + n_refs)."""
+        self._check(self._L.sbx_run_batch(self._ctx, int(first_ref), int(n_refs)))
+        st = RunStats()
+        self._check(self._L.sbx_last_run_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
 
     def format_base_rows(self, ref_id, beg, end, min_cov=1.0, max_cov=float("inf"), annotate=False):
         """Text of `depth base` for [beg, end) of ref_id, formatted on the device (bytes)."""

@@ -195,7 +195,7 @@ public:
         if (o_.min_cov < 0) return false;
         return !bed_provided_ || o_.min_cov > 0;
     }
-    void run_device() {
+    void run_device(int r0, int r1) {
         std::vector<char> text;
         const uint64_t CH = 8u << 20;      // positions per call (~300 MB of text at one sample)
         auto range = [&](uint32_t r, uint64_t b, uint64_t e) {
@@ -216,10 +216,11 @@ public:
             }
         };
         if (bed_provided_) {      // merged, sorted regions
-            for (auto& g : bed_) range(g.ref_id, g.start, g.end);
+            for (auto& g : bed_)
+                if ((int)g.ref_id >= r0 && (int)g.ref_id < r1) range(g.ref_id, g.start, g.end);
             return;
         }
-        for (int r = 0; r < n_ref_; ++r) {
+        for (int r = r0; r < r1; ++r) {
             const uint64_t len = (uint64_t)sbx_ref_length(c_, r);
             if (o_.min_cov == 0) range((uint32_t)r, 0, len);      // every position of the contig has rows
             uint64_t from = o_.min_cov == 0 ? len : 0;
@@ -242,12 +243,13 @@ public:
             if (cov[(size_t)(x - b)]) write_column(r, (int64_t)x, &cnt[(size_t)(x - b) * S_ * SBX_NCOUNTERS]);
         out_.flush();
     }
-    void run() {
-        if (device_format_applies()) { run_device(); return; }
+    // rows of contigs [r0, r1) (the batch the device has just processed); finish() after the last batch
+    void run_refs(int r0, int r1) {
+        if (device_format_applies()) { run_device(r0, r1); return; }
         std::vector<uint32_t> cnt;
         std::vector<uint8_t> cov;
         const uint64_t CH = 1u << 20;
-        for (int r = 0; r < n_ref_; ++r) {
+        for (int r = r0; r < r1; ++r) {
             uint64_t from = 0;
             for (;;) {
                 uint64_t b, e;
@@ -264,7 +266,9 @@ public:
                 from = e;
             }
         }
-        close();
+    }
+    void finish() {
+        if (!device_format_applies()) close();
     }
 
 private:
@@ -430,12 +434,12 @@ void print_region_row(Out& out, const Options& o, const std::string& prefix, uin
 }
 
 // position of the first pileup column of the run (first admitted read), or false if there is none
-bool first_column(sbx_ctx* c, int n_ref, int* ref_out, uint64_t* pos_out) {
+bool first_column(sbx_ctx* c, int r0, int r1, int* ref_out, uint64_t* pos_out) {
     std::vector<uint32_t> cnt;
     std::vector<uint8_t> cov;
     uint32_t T = 0, S = 0;
     check(c, sbx_tile_info(c, &T, &S));
-    for (int r = 0; r < n_ref; ++r) {
+    for (int r = r0; r < r1; ++r) {
         uint64_t from = 0;
         for (;;) {
             uint64_t b, e;
@@ -455,61 +459,101 @@ bool first_column(sbx_ctx* c, int n_ref, int* ref_out, uint64_t* pos_out) {
     return false;
 }
 
-// PerBedRegionPrinter.close (depth.d:925-930): rows in input order; nothing at all unless some column
-// fell inside some region (the samples array is created lazily)
-void print_regions(sbx_ctx* c, const Options& o, Out& out, const std::vector<std::string>& samples,
-                   const std::vector<sbx_region>& raw, const std::vector<std::string>& lines) {
-    const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
-    const size_t n_thr = o.thresholds.size();
-    std::vector<sbx_region_stats> st(raw.size() * S);
-    std::vector<uint32_t> cov(raw.size() * S * std::max<size_t>(1, n_thr));
-    std::vector<uint8_t> seen(raw.size());
-    check(c, sbx_depth_region_stats(c, raw.data(), raw.size(), st.data(), cov.data(), seen.data()));
-    bool any = false;
-    for (auto v : seen) any |= v != 0;
-    if (!any) return;
-    for (size_t id = 0; id < raw.size(); ++id) {
-        std::string l = lines[id];
-        while (!l.empty() && isspace((unsigned char)l.back())) l.pop_back();   // stripRight (depth.d:904)
-        l += "\t";
-        for (uint32_t s = 0; s < S; ++s)
-            print_region_row(out, o, l, raw[id].end - raw[id].start, st[id * S + s], &cov[(id * S + s) * n_thr], samples[s]);
-    }
-}
-
-// PerWindowPrinter (depth.d:933-1077), overlap == 0
-void print_windows(sbx_ctx* c, const Options& o, Out& out, const std::vector<std::string>& samples, int n_ref) {
-    const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
-    const size_t n_thr = o.thresholds.size();
+// PerWindowPrinter (depth.d:933-1077), overlap == 0; fed one batch of contigs at a time
+struct WindowPrinter {
+    sbx_ctx* c;
+    const Options& o;
+    Out& out;
+    const std::vector<std::string>& samples;
+    bool have_first = false;     // the first pileup column of the whole run has been seen
     int fref = 0;
     uint64_t fpos = 0;
-    if (!first_column(c, n_ref, &fref, &fpos)) return;   // no column at all: header only
-    const uint64_t w = o.window;
-    std::vector<sbx_region_stats> st;
-    std::vector<uint32_t> cov;
-    for (int r = fref; r < n_ref; ++r) {
-        const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r));
-        const uint64_t n_full = len / w;
-        if (!n_full) continue;
-        const std::string name = sbx_ref_name(c, r);
-        const uint64_t CH = 1u << 18;
-        for (uint64_t k0 = 0; k0 < n_full; k0 += CH) {
-            const uint64_t k1 = std::min(n_full, k0 + CH);
-            st.assign((size_t)(k1 - k0) * S, sbx_region_stats{0, 0});
-            cov.assign((size_t)(k1 - k0) * S * std::max<size_t>(1, n_thr), 0);
-            if (k0 == 0 && k1 == n_full) check(c, sbx_depth_window_stats(c, (uint32_t)r, 0, n_full, st.data(), cov.data()));
-            else check(c, sbx_depth_window_stats(c, (uint32_t)r, k0, k1 - k0, st.data(), cov.data()));
-            for (uint64_t k = k0; k < k1; ++k) {
-                // windows finished before the first column of the run print nothing (samples not created yet)
-                if (r == fref && (k + 1) * w <= fpos) continue;
-                std::string prefix = name + "\t" + std::to_string(k * w) + "\t" + std::to_string((k + 1) * w) + "\t";
-                for (uint32_t s = 0; s < S; ++s)
-                    print_region_row(out, o, prefix, (uint32_t)w, st[(size_t)(k - k0) * S + s],
-                                     &cov[((size_t)(k - k0) * S + s) * n_thr], samples[s]);
+
+    void run_refs(int r0, int r1) {
+        const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
+        const size_t n_thr = o.thresholds.size();
+        if (!have_first) {
+            if (!first_column(c, r0, r1, &fref, &fpos)) return;   // no column yet: windows so far print nothing
+            have_first = true;
+        }
+        const uint64_t w = o.window;
+        std::vector<sbx_region_stats> st;
+        std::vector<uint32_t> cov;
+        for (int r = std::max(r0, fref); r < r1; ++r) {
+            const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r));
+            const uint64_t n_full = len / w;
+            if (!n_full) continue;
+            const std::string name = sbx_ref_name(c, r);
+            const uint64_t CH = 1u << 18;
+            for (uint64_t k0 = 0; k0 < n_full; k0 += CH) {
+                const uint64_t k1 = std::min(n_full, k0 + CH);
+                st.assign((size_t)(k1 - k0) * S, sbx_region_stats{0, 0});
+                cov.assign((size_t)(k1 - k0) * S * std::max<size_t>(1, n_thr), 0);
+                check(c, sbx_depth_window_stats(c, (uint32_t)r, k0, k1 - k0, st.data(), cov.data()));
+                for (uint64_t k = k0; k < k1; ++k) {
+                    // windows finished before the first column of the run print nothing (samples not created yet)
+                    if (r == fref && (k + 1) * w <= fpos) continue;
+                    std::string prefix = name + "\t" + std::to_string(k * w) + "\t" + std::to_string((k + 1) * w) + "\t";
+                    for (uint32_t s = 0; s < S; ++s)
+                        print_region_row(out, o, prefix, (uint32_t)w, st[(size_t)(k - k0) * S + s],
+                                         &cov[((size_t)(k - k0) * S + s) * n_thr], samples[s]);
+                }
             }
         }
     }
-}
+};
+
+// PerBedRegionPrinter (depth.d:879-931): statistics are gathered batch by batch, rows are printed at the end
+// in input order -- and not at all unless some column fell inside some region (the samples array is created
+// lazily)
+struct RegionPrinter {
+    sbx_ctx* c;
+    const Options& o;
+    Out& out;
+    const std::vector<std::string>& samples;
+    const std::vector<sbx_region>& raw;
+    const std::vector<std::string>& lines;
+    std::vector<sbx_region_stats> st;
+    std::vector<uint32_t> cov;
+    std::vector<uint8_t> seen;
+
+    void run_refs(int r0, int r1) {
+        const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
+        const size_t n_thr = std::max<size_t>(1, o.thresholds.size());
+        if (st.empty()) { st.assign(raw.size() * S, sbx_region_stats{0, 0}); cov.assign(raw.size() * S * n_thr, 0); seen.assign(raw.size(), 0); }
+        std::vector<size_t> ids;
+        std::vector<sbx_region> sub;
+        for (size_t i = 0; i < raw.size(); ++i)
+            if ((int)raw[i].ref_id >= r0 && (int)raw[i].ref_id < r1) { ids.push_back(i); sub.push_back(raw[i]); }
+        if (sub.empty()) return;
+        std::vector<sbx_region_stats> st2(sub.size() * S);
+        std::vector<uint32_t> cov2(sub.size() * S * n_thr);
+        std::vector<uint8_t> seen2(sub.size());
+        check(c, sbx_depth_region_stats(c, sub.data(), sub.size(), st2.data(), cov2.data(), seen2.data()));
+        const size_t nt = o.thresholds.size();
+        for (size_t j = 0; j < ids.size(); ++j) {
+            seen[ids[j]] = seen2[j];
+            for (uint32_t s2 = 0; s2 < S; ++s2) {
+                st[ids[j] * S + s2] = st2[j * S + s2];
+                for (size_t t = 0; t < nt; ++t) cov[(ids[j] * S + s2) * n_thr + t] = cov2[(j * S + s2) * nt + t];
+            }
+        }
+    }
+    void finish() {
+        const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
+        const size_t n_thr = std::max<size_t>(1, o.thresholds.size());
+        bool any = false;
+        for (auto v : seen) any |= v != 0;
+        if (!any) return;
+        for (size_t id = 0; id < raw.size(); ++id) {
+            std::string l = lines[id];
+            while (!l.empty() && isspace((unsigned char)l.back())) l.pop_back();   // stripRight (depth.d:904)
+            l += "\t";
+            for (uint32_t s2 = 0; s2 < S; ++s2)
+                print_region_row(out, o, l, raw[id].end - raw[id].start, st[id * S + s2], &cov[(id * S + s2) * n_thr], samples[s2]);
+        }
+    }
+};
 
 int depth_main(int argc, char** argv) {
     if (argc < 3) { usage(); return 0; }
@@ -604,17 +648,29 @@ int depth_main(int argc, char** argv) {
             check(ctx, sbx_set_regions(ctx, merged.data(), merged.size()));
         }
         if (o.mode == "region") print_bed_header(out, o, split_ws(raw_lines.empty() ? std::string("a b c") : raw_lines[0]).size());
-        check(ctx, sbx_run(ctx));
-        if (o.mode == "region") {
-            print_regions(ctx, o, out, samples, raw, raw_lines);
-        } else if (o.mode == "window") {
-            print_windows(ctx, o, out, samples, hi.n_ref);
-        } else if (o.mode == "base") {
-            BasePrinter p(ctx, o, out, samples);
-            if (o.has_regions) p.set_bed(merged);
+        // The device processes the file in batches of contigs sized to its free memory (one batch unless the
+        // BAM is whole-genome sized); the printers are fed batch by batch, in contig order.
+        uint64_t budget = 0;
+        if (const char* e = getenv("SBX_BATCH_BYTES")) budget = strtoull(e, nullptr, 10);
+        size_t n_batches = 0;
+        check(ctx, sbx_plan_batches(ctx, budget, nullptr, 0, &n_batches));
+        std::vector<sbx_batch> plan(n_batches);
+        if (n_batches) check(ctx, sbx_plan_batches(ctx, budget, plan.data(), plan.size(), &n_batches));
+        BasePrinter bp(ctx, o, out, samples);
+        if (o.mode == "base" && o.has_regions) bp.set_bed(merged);
+        WindowPrinter wp{ctx, o, out, samples};
+        RegionPrinter rp{ctx, o, out, samples, raw, raw_lines, {}, {}, {}};
+        for (auto& b : plan) {
+            if (plan.size() == 1) check(ctx, sbx_run(ctx));
+            else check(ctx, sbx_run_batch(ctx, b.first_ref, b.n_refs));
+            const int r0 = (int)b.first_ref, r1 = (int)(b.first_ref + b.n_refs);
             // "Processing reference #N (name)" lines go to stderr in the reference (depth.d:1225-1229)
-            p.run();
+            if (o.mode == "region") rp.run_refs(r0, r1);
+            else if (o.mode == "window") wp.run_refs(r0, r1);
+            else bp.run_refs(r0, r1);
         }
+        if (o.mode == "region") rp.finish();
+        else if (o.mode == "base") bp.finish();
         out.flush();
         if (out.fp != stdout) fclose(out.fp);
         sbx_close(ctx);

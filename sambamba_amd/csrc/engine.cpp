@@ -62,6 +62,8 @@ struct sbx_ctx {
     DevBuf<uint64_t> d_comp_off, d_out_off;
     DevBuf<uint32_t> d_comp_len, d_isize, d_status;
     DevBuf<uint8_t> d_U, d_scratch, d_lit;
+    uint64_t u_base = 0;      // stream offset held at d_U.p[0]: d_U covers the BGZF block range of the current run only
+    const uint8_t* U() const { return d_U.p - u_base; }     // address of stream offset 0 (only offsets >= u_base are backed)
     DevBuf<uint32_t> d_ent, d_nent;
     DevBuf<uint64_t> d_entry, d_exit, d_base;
     DevBuf<uint32_t> d_count, d_flag;
@@ -139,29 +141,33 @@ void upload_file(sbx_ctx* c) {
     c->comp_resident = true;
 }
 
-// inflate blocks [b0,b1) into d_U (which is laid out for the whole file) and check their status
+// Inflate blocks [b0,b1) into d_U.  Every buffer is sized for this block range only (a whole-genome BAM
+// is processed in batches of contigs, sbx_run_batch); the kernels address by absolute stream offset / block
+// index, so they get pointers biased by the range's first offsets.
 void inflate_blocks(sbx_ctx* c, uint32_t b0, uint32_t b1, hipEvent_t ev_mid = nullptr) {
     if (b1 <= b0) {
         if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, c->stream));
         return;
     }
     uint32_t n = b1 - b0;
-    const uint32_t nb = (uint32_t)c->blocks.size();
-    const uint64_t total = c->blocks.out_off.back();
-    c->d_status.ensure(nb + 1);
-    c->d_nent.ensure(nb + 1);
-    c->d_scratch.ensure(inflate_scratch_bytes(nb));
-    c->d_lit.ensure(inflate_lit_bytes(total, nb));
-    c->d_ent.ensure(inflate_ent_words(total, nb));
+    const uint64_t o0 = c->blocks.out_off[b0], o1 = c->blocks.out_off[b1];
+    c->u_base = o0;
+    c->d_U.ensure((size_t)(o1 - o0) + 64);
+    c->d_status.ensure(n + 1);
+    c->d_nent.ensure(n + 1);
+    c->d_scratch.ensure(inflate_scratch_bytes(n));
+    const size_t lit0 = inflate_lit_bytes(o0, b0) - inflate_lit_bytes(0, 0), ent0 = inflate_ent_words(o0, b0) - inflate_ent_words(0, 0);
+    c->d_lit.ensure(inflate_lit_bytes(o1, b1) - lit0);
+    c->d_ent.ensure(inflate_ent_words(o1, b1) - ent0);
     launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p + b0, c->d_comp_len.p + b0, c->d_isize.p + b0, c->d_out_off.p + b0,
-                        c->d_U.p, n, b0, c->d_scratch.p + (size_t)b0 * (inflate_scratch_bytes(2) / 2), c->d_lit.p, c->d_ent.p,
-                        c->d_nent.p + b0, c->d_status.p + b0, c->stream, ev_mid);
+                        c->d_U.p - o0, n, b0, c->d_scratch.p, c->d_lit.p - lit0, c->d_ent.p - ent0, c->d_nent.p, c->d_status.p,
+                        c->stream, ev_mid);
 }
 
 void check_inflate_status(sbx_ctx* c, uint32_t b0, uint32_t b1) {
     if (b1 <= b0) return;
     std::vector<uint32_t> st(b1 - b0);
-    SBX_HIP(hipMemcpyAsync(st.data(), c->d_status.p + b0, st.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    SBX_HIP(hipMemcpyAsync(st.data(), c->d_status.p, st.size() * 4, hipMemcpyDeviceToHost, c->stream));
     SBX_HIP(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < st.size(); ++i)
         if (st[i] != 0)
@@ -174,7 +180,6 @@ void parse_header_on_device(sbx_ctx* c) {
     if (total < 12) throw Error(SBX_EFORMAT, "BAM header is truncated");
     upload_tables(c);
     upload_file(c);
-    c->d_U.ensure(total + 64);
     uint32_t nb = (uint32_t)c->blocks.size();
     uint32_t k = std::min<uint32_t>(nb, 4);
     std::vector<uint8_t> host;
@@ -353,9 +358,9 @@ int sbx_preload(sbx_ctx* c) {
     });
 }
 
-int sbx_run(sbx_ctx* c) {
-    return guarded(c, [&] {
-        if (!c) throw Error(SBX_EINVAL, "null context");
+// The whole device pipeline for the reads selected by `sel` (restricted == false: every read of the file).
+static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
+    {
         if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
         if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
         if (c->fix_mate && c->mode != SBX_MODE_BASE)
@@ -377,8 +382,8 @@ int sbx_run(sbx_ctx* c) {
         // the run that lie outside the regions cannot change any reported number.
         uint32_t blk0 = 0, blk1 = nb_file;
         uint64_t first_off = c->hdr.first_record_off, total = total_file;
-        if (!c->regions.empty()) {
-            std::vector<sbx_region> regs = c->regions;
+        if (restricted) {
+            std::vector<sbx_region> regs = sel;
             std::sort(regs.begin(), regs.end(), [](const sbx_region& a, const sbx_region& b) {
                 if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
                 if (a.start != b.start) return a.start < b.start;
@@ -421,7 +426,6 @@ int sbx_run(sbx_ctx* c) {
         t_all.start(s);
 
         // ---- K1 ----
-        c->d_U.ensure(total_file + 64);
         t1.start(s);
         inflate_blocks(c, blk0, blk1, t1m.b);
         t1.stop(s);
@@ -465,7 +469,7 @@ int sbx_run(sbx_ctx* c) {
         };
         lap("start-index");
         t2.start(s);
-        launch_block_walk(c->d_U.p, total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, refs, c->d_entry.p,
+        launch_block_walk(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, refs, c->d_entry.p,
                           c->d_exit.p, c->d_count.p, s);
         lap("block_walk");
         uint32_t verify_iters = 0;   // number of blocks whose guessed entry had to be re-walked
@@ -485,7 +489,7 @@ int sbx_run(sbx_ctx* c) {
                 if (force && round == 0) { uint32_t f = (uint32_t)atoi(force); if (f < first_bad && f < nb) { first_bad = f; forced = true; } }
                 if (first_bad == 0xFFFFFFFFu || first_bad >= nb) break;
                 const bool to_the_end = forced || round >= 16;
-                launch_chain_repair(c->d_U.p, total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, first_bad,
+                launch_chain_repair(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, first_bad,
                                     !to_the_end, c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_flag.p + 1, s);
                 if (round > 64) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
             }
@@ -559,7 +563,7 @@ int sbx_run(sbx_ctx* c) {
         c->d_stats.ensure(1);
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
         lap("scan+setup");
-        launch_describe(c->d_U.p, total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
+        launch_describe(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
                         T, c->d_desc.p, c->d_rec_ref.p, c->fix_mate ? c->d_name_hash.p : nullptr, c->d_tile_lo.p, c->d_tile_hi.p,
                         c->d_stats.p, s);
         lap("describe");
@@ -599,10 +603,10 @@ int sbx_run(sbx_ctx* c) {
             if (max_partners > 1)
                 throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps: a read overlaps two or more records with the same name; the reference's "
                                               "result then depends on per-column status history (depth.d:343-377) and is not on the device path");
-            launch_accumulate_mates(c->d_U.p, c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
+            launch_accumulate_mates(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
                                     c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
         } else
-        launch_accumulate(c->d_U.p, c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, c->d_tile_base.p,
+        launch_accumulate(c->U(), c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, c->d_tile_base.p,
                           n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
         t3.stop(s);
         t_all.stop(s);
@@ -640,6 +644,92 @@ int sbx_run(sbx_ctx* c) {
                     (unsigned long long)n_records, verify_iters, (unsigned long long)nt, n_active, T);
         c->stats.launches_accumulate = 1;
         c->have_run = true;
+    }
+}
+
+int sbx_run(sbx_ctx* c) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        run_impl(c, c->regions, !c->regions.empty());
+    });
+}
+
+// ---- streaming over contigs -----------------------------------------------------------------------
+// BGZF block range [b0, b1) holding every read of contig r (from the BAI; empty contigs: b0 == b1)
+static void contig_blocks(sbx_ctx* c, uint32_t r, uint32_t* b0, uint32_t* b1) {
+    *b0 = *b1 = 0;
+    if (r >= c->bai.refs.size()) return;
+    std::vector<sbx_region> whole{{r, 0u, 0x7FFFFFFFu}};
+    uint64_t vbeg = ~0ull, vend = 0;
+    for (auto& ch : group_chunks(c->bai, whole)) { vbeg = std::min(vbeg, ch.beg); vend = std::max(vend, ch.end); }
+    if (vbeg >= vend) return;
+    const auto& co = c->blocks.coffset;
+    const uint32_t nb = (uint32_t)c->blocks.size();
+    size_t i0 = (size_t)(std::lower_bound(co.begin(), co.end(), vbeg >> 16) - co.begin());
+    size_t i1 = (size_t)(std::lower_bound(co.begin(), co.end(), vend >> 16) - co.begin());
+    if (i0 >= nb) return;
+    if (i1 < nb && (vend & 0xFFFF)) ++i1;
+    *b0 = (uint32_t)i0;
+    *b1 = (uint32_t)std::min<size_t>(std::max(i1, i0 + 1), nb);
+}
+
+// estimated device bytes of a run over BGZF blocks [b0, b1) covering `positions` reference positions:
+// inflated stream + literal and entry token streams (~2.4x) + descriptors + counter tiles
+static uint64_t footprint(sbx_ctx* c, uint32_t b0, uint32_t b1, uint64_t positions) {
+    if (b1 <= b0) return 0;
+    const uint64_t u = c->blocks.out_off[b1] - c->blocks.out_off[b0];
+    const uint32_t S = c->combined ? 1u : (uint32_t)std::max<size_t>(1, c->hdr.sample_names.size());
+    return u + (u + 48ull * (b1 - b0)) + 4 * (u / 3 + u / 255 + 12ull * (b1 - b0)) + u / 8 + positions * (28ull * S + 4);
+}
+
+int sbx_plan_batches(sbx_ctx* c, uint64_t budget_bytes, sbx_batch* out, size_t cap, size_t* n_out) {
+    return guarded(c, [&] {
+        if (!c || !n_out) throw Error(SBX_EINVAL, "null argument");
+        if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
+        SBX_HIP(hipSetDevice(c->device));
+        if (budget_bytes == 0) {
+            size_t free_b = 0, total_b = 0;
+            SBX_HIP(hipMemGetInfo(&free_b, &total_b));
+            // what this context already holds (the compressed file, buffers of an earlier run) is reused
+            budget_bytes = (uint64_t)((double)free_b * 0.7) + c->d_U.bytes() + c->d_lit.bytes() + c->d_ent.bytes() + c->d_counters.bytes();
+            if (!c->comp_resident) budget_bytes -= std::min<uint64_t>(budget_bytes, c->file.size);   // the file itself goes to HBM first
+        }
+        const uint32_t n_ref = (uint32_t)c->hdr.refs.size();
+        std::vector<sbx_batch> plan;
+        uint32_t first = 0, lo = 0, hi = 0;       // current batch: contigs [first, r), blocks [lo, hi)
+        uint64_t pos = 0;
+        for (uint32_t r = 0; r < n_ref; ++r) {
+            uint32_t b0, b1;
+            contig_blocks(c, r, &b0, &b1);
+            const uint64_t len = (uint64_t)std::max(0, c->hdr.refs[r].length);
+            uint32_t nlo = lo, nhi = hi;
+            if (b1 > b0) { nlo = hi > lo ? std::min(lo, b0) : b0; nhi = hi > lo ? std::max(hi, b1) : b1; }
+            if (r > first && footprint(c, nlo, nhi, pos + len) > budget_bytes) {
+                plan.push_back({first, r - first, footprint(c, lo, hi, pos)});
+                first = r; pos = 0;
+                nlo = b0; nhi = b1;
+            }
+            lo = nlo; hi = nhi; pos += len;
+        }
+        if (n_ref > first) plan.push_back({first, n_ref - first, footprint(c, lo, hi, pos)});
+        *n_out = plan.size();
+        if (out) for (size_t i = 0; i < plan.size() && i < cap; ++i) out[i] = plan[i];
+        if (out && plan.size() > cap) throw Error(SBX_ENOMEM, "batch array too small");
+    });
+}
+
+int sbx_run_batch(sbx_ctx* c, uint32_t first_ref, uint32_t n_refs) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        if ((uint64_t)first_ref + n_refs > c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
+        std::vector<sbx_region> sel;
+        if (c->regions.empty()) {
+            for (uint32_t r = first_ref; r < first_ref + n_refs; ++r) sel.push_back({r, 0u, 0x7FFFFFFFu});
+        } else {
+            for (auto& g : c->regions)
+                if (g.ref_id >= first_ref && g.ref_id < first_ref + n_refs) sel.push_back(g);
+        }
+        run_impl(c, sel, true);
     });
 }
 
@@ -733,7 +823,7 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
         d_nw.alloc(n_win.size() + 1);
         SBX_HIP(hipMemcpyAsync(d_wb.p, win_base.data(), win_base.size() * 8, hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(d_nw.p, n_win.data(), n_win.size() * 8, hipMemcpyHostToDevice, s));
-        launch_count_reads_windows(c->d_U.p, c->d_desc.p, n_records, c->d_rec_ref.p, window, d_wb.p, d_nw.p, S, c->min_bq, d_nr.p, s);
+        launch_count_reads_windows(c->U(), c->d_desc.p, n_records, c->d_rec_ref.p, window, d_wb.p, d_nw.p, S, c->min_bq, d_nr.p, s);
     } else {
         // (ref, start)-sorted view + prefix max of ends per contig
         const size_t n_ref = c->hdr.refs.size();
@@ -765,7 +855,7 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
             SBX_HIP(hipMemcpyAsync(d_pmax.p, pmax.data(), n * 4, hipMemcpyHostToDevice, s));
         }
         SBX_HIP(hipMemcpyAsync(d_first.p, first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
-        launch_count_reads_regions(c->d_U.p, c->d_desc.p, n_records, c->d_rec_ref.p, d_regs.p, d_pmax.p, d_first.p, S, c->min_bq,
+        launch_count_reads_regions(c->U(), c->d_desc.p, n_records, c->d_rec_ref.p, d_regs.p, d_pmax.p, d_first.p, S, c->min_bq,
                                    d_nr.p, s);
         SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
     }
