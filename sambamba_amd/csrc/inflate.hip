@@ -304,16 +304,31 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
 // Token emitter of one lane (K1a).  Scattered 4-byte stores from 64 lanes are 64 partial-line write
 // requests each; the emitter therefore keeps the last 16 literal bytes and the last 4 match entries in
 // registers (byte / dword shift registers) and writes both streams with aligned 16-byte stores only.
+// The stores are DEFERRED: a full 16-byte group is parked in a second register set and written by flush(),
+// which the decode loop calls right after the input-ring service.  gfx9 counts loads and stores in the
+// same in-order vmcnt, so the wait in front of the ring service would otherwise also wait for token stores
+// issued moments before -- a store round trip of stall in every iteration; this way every VMEM operation of
+// an iteration is issued at its top and has a whole iteration to complete.
 struct Emitter {
     uint8_t* lit;         // 16-byte aligned literal stream of this block
     uint32_t* ent;        // 16-byte aligned entry stream of this block
     u32x4 la, ea;
+    u32x4 lp, ep;         // parked groups
+    uint32_t lp_at, ep_at;    // where they go (byte offset / entry index), kNone = nothing parked
     uint32_t n_lit, n_ent, run;
+    static constexpr uint32_t kNone = 0xFFFFFFFFu;
     __device__ __forceinline__ static void store16(void* p, u32x4 v) { *(u32x4*)p = v; }
     __device__ __forceinline__ void init(uint8_t* l, uint32_t* e) {
         lit = l; ent = e; n_lit = n_ent = run = 0;
         la = u32x4{0, 0, 0, 0};
         ea = u32x4{0, 0, 0, 0};
+        lp = u32x4{0, 0, 0, 0};
+        ep = u32x4{0, 0, 0, 0};
+        lp_at = ep_at = kNone;
+    }
+    __device__ __forceinline__ void flush() {
+        if (lp_at != kNone) { store16(lit + lp_at, lp); lp_at = kNone; }
+        if (ep_at != kNone) { store16(ent + ep_at, ep); ep_at = kNone; }
     }
     __device__ __forceinline__ void push_byte(uint32_t byte) {      // la = (la >> 8) | byte << 120
         la.x = __builtin_amdgcn_alignbit(la.y, la.x, 8);
@@ -324,12 +339,20 @@ struct Emitter {
     __device__ __forceinline__ void push_entry(uint32_t e) {
         ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = e;
         ++n_ent;
-        if ((n_ent & 3u) == 0) store16(ent + n_ent - 4, ea);
+        if ((n_ent & 3u) == 0) {
+            if (ep_at != kNone) store16(ent + ep_at, ep);      // (second group within one iteration: split runs only)
+            ep = ea;
+            ep_at = n_ent - 4;
+        }
     }
     __device__ __forceinline__ void literal(uint32_t byte) {
         push_byte(byte);
         ++n_lit;
-        if ((n_lit & 15u) == 0) store16(lit + n_lit - 16, la);
+        if ((n_lit & 15u) == 0) {
+            if (lp_at != kNone) store16(lit + lp_at, lp);      // (stored blocks emit more than 16 bytes between flushes)
+            lp = la;
+            lp_at = n_lit - 16;
+        }
         ++run;
     }
     // an entry carries at most 255 literals: longer runs are split here, not in the per-literal path
@@ -342,6 +365,7 @@ struct Emitter {
         run = 0;
     }
     __device__ __forceinline__ void finish() {
+        flush();
         split_run();
         if (run) { push_entry(make_entry(run, 0, 1)); run = 0; }
         const uint32_t rl = n_lit & 15u;
@@ -355,6 +379,7 @@ struct Emitter {
             for (uint32_t k = re; k < 4; ++k) { ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = 0; }
             store16(ent + (keep & ~3u), ea);
         }
+        flush();
     }
 };
 
@@ -533,6 +558,8 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         // per lane -- literals are emitted on the spot, the first length symbol (or end-of-block) stops
         // the lane's run -- and then handles at most one match per lane.
         while (__any(sym_loop)) {
+            br.service();               // every VMEM operation of the iteration is issued here, at its top:
+            em.flush();                 // one ring load and the token stores parked by the previous iteration
             uint32_t msym = 0;          // pending length symbol (257..285) of this lane, 0 = none
             uint32_t bad = INF_OK;
 #pragma unroll 1
@@ -583,7 +610,6 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                 bad = !code_ok ? (uint32_t)INF_BAD_DISTANCE : !fits ? (uint32_t)INF_OUTPUT_OVERRUN : bad;
             }
             if (bad != INF_OK) { err = bad; active = false; sym_loop = false; }
-            br.service();
         }
         if (active && last) active = false;
     }
