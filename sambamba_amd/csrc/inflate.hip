@@ -557,12 +557,12 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         // lane has a match, so each iteration first decodes up to kLitPerIter literal/length symbols
         // per lane -- literals are emitted on the spot, the first length symbol (or end-of-block) stops
         // the lane's run -- and then handles at most one match per lane.
-        while (__any(sym_loop)) {
+        if (__any(sym_loop)) do {
             br.service();               // every VMEM operation of the iteration is issued here, at its top:
             em.flush();                 // one ring load and the token stores parked by the previous iteration
             uint32_t msym = 0;          // pending length symbol (257..285) of this lane, 0 = none
             uint32_t bad = INF_OK;
-#pragma unroll 1
+#pragma unroll
             for (int r = 0; r < kLitPerIter; ++r) {
                 if (sym_loop && msym == 0 && bad == INF_OK) {
                     br.refill();
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                 bad = !code_ok ? (uint32_t)INF_BAD_DISTANCE : !fits ? (uint32_t)INF_OUTPUT_OVERRUN : bad;
             }
             if (bad != INF_OK) { err = bad; active = false; sym_loop = false; }
-        }
+        } while (__any(sym_loop));
         if (active && last) active = false;
     }
     em.finish();
