@@ -80,10 +80,12 @@ typedef struct {
 
 /* The compiled subset of the -F filter language (sambamba/utils/common/filtering.d:86-214,
  * queryparser.d:232-483): a postfix program over flag tests, integer-field comparisons,
- * and / or / not.  Built by sbx_compile_filter() from the query string. */
+ * integer-tag comparisons ([NM] <= 2), tag existence ([XS] == null) and and / or / not.
+ * Built by sbx_compile_filter() from the query string. */
 #define SBX_FILTER_MAX_OPS 64
 typedef struct {
-    uint8_t  kind;     /* 0 FLAG_ANY(mask)  1 CHIMERIC  2 INTCMP  3 AND  4 OR  5 NOT  6 TRUE */
+    uint8_t  kind;     /* 0 FLAG_ANY(mask)  1 CHIMERIC  2 INTCMP  3 AND  4 OR  5 NOT  6 TRUE
+                          7 TAGCMP (mask = key chars c0 | c1 << 8; cmp; value)  8 TAGNULL (cmp 4: absent, 5: present) */
     uint8_t  field;    /* INTCMP: 0 ref_id 1 position 2 mapping_quality 3 sequence_length
                                   4 mate_ref_id 5 mate_position 6 template_length            */
     uint8_t  cmp;      /* INTCMP: 0 >  1 <  2 >=  3 <=  4 ==  5 !=                           */

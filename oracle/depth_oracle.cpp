@@ -136,8 +136,39 @@ static inline bool find_rg(const Rec& r, std::string* out) {
 // 32-byte part of the record (flags, integer fields, and/or/not, parentheses).
 // Precedences: comparison 110 > not 100 > and 80 > or 60 (queryparser.d:424-483).
 // ---------------------------------------------------------------------------
+// first aux field with the given two-character key: type character and value pointer (BamRead.opIndex,
+// read.d:1070-1087 with skipValue read.d:1219-1230); 0 = absent (or the tag area is malformed before it)
+static inline char find_tag(const Rec& r, char c0, char c1, const uint8_t** val) {
+    const uint8_t* t = r.tags();
+    const uint8_t* e = r.end();
+    while (t + 3 <= e) {
+        char k0 = (char)t[0], k1 = (char)t[1], ty = (char)t[2];
+        t += 3;
+        const uint8_t* v = t;
+        switch (ty) {
+            case 'A': case 'c': case 'C': t += 1; break;
+            case 's': case 'S': t += 2; break;
+            case 'i': case 'I': case 'f': t += 4; break;
+            case 'Z': case 'H': while (t < e && *t) ++t; ++t; break;
+            case 'B': {
+                if (t + 5 > e) return 0;
+                char sub = (char)t[0];
+                uint32_t n = le32(t + 1);
+                size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                t += 5 + (size_t)n * w;
+                break;
+            }
+            default: return 0;
+        }
+        if (t > e) return 0;
+        if (k0 == c0 && k1 == c1) { *val = v; return ty; }
+    }
+    return 0;
+}
+
 struct FilterNode {
-    enum Kind { FLAG, CHIMERIC, INTCMP, AND, OR, NOT, TRUE_ } kind = TRUE_;
+    enum Kind { FLAG, CHIMERIC, INTCMP, AND, OR, NOT, TRUE_, TAGCMP, TAGNULL } kind = TRUE_;
+    char key[2] = {0, 0};   // TAGCMP / TAGNULL: the aux key
     uint32_t mask = 0;
     int field = 0;  // 0 ref_id 1 position 2 mapping_quality 3 sequence_length 4 mate_ref_id 5 mate_position 6 template_length
     int op = 0;     // 0 > 1 < 2 >= 3 <= 4 == 5 !=
@@ -167,6 +198,47 @@ struct FilterNode {
                     case 3: return v <= value;
                     case 4: return v == value;
                     default: return v != value;
+                }
+            }
+            case TAGNULL: {   // TagExistenceFilter (filtering.d:216-230): op 4 "== null", 5 "!= null"
+                const uint8_t* v = nullptr;
+                bool present = find_tag(r, key[0], key[1], &v) != 0;
+                return op == 5 ? present : !present;
+            }
+            case TAGCMP: {    // IntegerTagFilter (filtering.d:233-252): integer or float tags only
+                const uint8_t* v = nullptr;
+                char ty = find_tag(r, key[0], key[1], &v);
+                long iv = 0;
+                switch (ty) {
+                    case 'c': iv = (int8_t)v[0]; break;
+                    case 'C': iv = v[0]; break;
+                    case 's': iv = (int16_t)(v[0] | (v[1] << 8)); break;
+                    case 'S': iv = (uint16_t)(v[0] | (v[1] << 8)); break;
+                    case 'i': iv = (int32_t)le32(v); break;
+                    case 'I': iv = (long)le32(v); break;
+                    case 'f': {
+                        uint32_t w = le32(v);
+                        float f;
+                        memcpy(&f, &w, 4);
+                        const float fv = (float)value;
+                        switch (op) {
+                            case 0: return f > fv;
+                            case 1: return f < fv;
+                            case 2: return f >= fv;
+                            case 3: return f <= fv;
+                            case 4: return f == fv;
+                            default: return f != fv;
+                        }
+                    }
+                    default: return false;
+                }
+                switch (op) {
+                    case 0: return iv > value;
+                    case 1: return iv < value;
+                    case 2: return iv >= value;
+                    case 3: return iv <= value;
+                    case 4: return iv == value;
+                    default: return iv != value;
                 }
             }
             case AND: return a->accepts(r) && b->accepts(r);
@@ -251,7 +323,36 @@ private:
                     }
                 throw Error("filter: comparison operator expected");
             }
-        throw Error("filter: unsupported expression at '" + s_.substr(p_) + "' (oracle supports flags and integer fields)");
+        if (eat("[", false)) {      // [XX] op integer | [XX] == null | [XX] != null (queryparser.d:285-300)
+            if (p_ + 3 > s_.size() || s_[p_ + 2] != ']') throw Error("filter: tag name of two characters expected");
+            auto n = std::make_unique<FilterNode>();
+            n->key[0] = s_[p_];
+            n->key[1] = s_[p_ + 1];
+            p_ += 3;
+            static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
+            static const int opid[] = {2, 3, 4, 5, 0, 1};
+            for (int k = 0; k < 6; ++k)
+                if (eat(ops[k], false)) {
+                    n->op = opid[k];
+                    if (eat("null", true)) {
+                        if (n->op != 4 && n->op != 5) throw Error("filter: only == and != can be used with null");
+                        n->kind = FilterNode::TAGNULL;
+                        return n;
+                    }
+                    skip();
+                    size_t q = p_;
+                    if (q < s_.size() && (s_[q] == '-' || s_[q] == '+')) ++q;
+                    size_t d0 = q;
+                    while (q < s_.size() && isdigit((unsigned char)s_[q])) ++q;
+                    if (q == d0) throw Error("filter: integer or null expected after a tag comparison (oracle subset)");
+                    n->kind = FilterNode::TAGCMP;
+                    n->value = atol(s_.substr(p_, q - p_).c_str());
+                    p_ = q;
+                    return n;
+                }
+            throw Error("filter: comparison operator expected");
+        }
+        throw Error("filter: unsupported expression at '" + s_.substr(p_) + "' (oracle supports flags, integer fields and integer tags)");
     }
     std::unique_ptr<FilterNode> expr(int rbp) {
         auto left = primary();

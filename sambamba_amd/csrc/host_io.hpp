@@ -463,8 +463,33 @@ private:
                     }
                 throw Error(SBX_EUNSUPPORTED, "filter: comparison operator expected");
             }
+        if (eat("[", false)) {      // [XX] op integer | [XX] == null | [XX] != null (queryparser.d:285-300)
+            if (p_ + 3 > s_.size() || s_[p_ + 2] != ']') throw Error(SBX_EUNSUPPORTED, "filter: tag name of two characters expected");
+            const uint32_t key = (uint8_t)s_[p_] | ((uint32_t)(uint8_t)s_[p_ + 1] << 8);
+            p_ += 3;
+            static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
+            static const uint8_t opid[] = {2, 3, 4, 5, 0, 1};
+            for (int k = 0; k < 6; ++k)
+                if (eat(ops[k], false)) {
+                    if (eat("null", true)) {
+                        if (opid[k] != 4 && opid[k] != 5) throw Error(SBX_EUNSUPPORTED, "filter: only == and != can be used with null");
+                        emit(8, key, 0, opid[k], 0);
+                        return;
+                    }
+                    skip();
+                    size_t q = p_;
+                    if (q < s_.size() && (s_[q] == '-' || s_[q] == '+')) ++q;
+                    size_t d0 = q;
+                    while (q < s_.size() && isdigit((unsigned char)s_[q])) ++q;
+                    if (q == d0) throw Error(SBX_EUNSUPPORTED, "filter: string / regex tag comparisons are outside the device-compilable subset");
+                    emit(7, key, 0, opid[k], atoll(s_.substr(p_, q - p_).c_str()));
+                    p_ = q;
+                    return;
+                }
+            throw Error(SBX_EUNSUPPORTED, "filter: comparison operator expected");
+        }
         throw Error(SBX_EUNSUPPORTED, "filter: '" + s_.substr(p_) + "' is outside the device-compilable subset "
-                                      "(flags, integer fields, and/or/not)");
+                                      "(flags, integer fields, integer tags, tag existence, and/or/not)");
     }
     void expr(int rbp) {
         primary();

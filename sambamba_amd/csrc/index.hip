@@ -245,8 +245,49 @@ __global__ __launch_bounds__(kScanThreads) void k_count_scan(const uint32_t* __r
 }
 
 // ---- describe ---------------------------------------------------------------------------------
+// first aux field with the given key (BamRead.opIndex, read.d:1070-1087; skipValue read.d:1219-1230):
+// returns its type character and value pointer, 0 when absent or when the tag area is malformed before it
+__device__ uint32_t find_tag(const uint8_t* t, const uint8_t* e, uint32_t key, const uint8_t** val) {
+    while (t + 3 <= e) {
+        const uint32_t k = (uint32_t)t[0] | ((uint32_t)t[1] << 8);
+        const uint8_t ty = t[2];
+        t += 3;
+        const uint8_t* v = t;
+        switch (ty) {
+            case 'A': case 'c': case 'C': t += 1; break;
+            case 's': case 'S': t += 2; break;
+            case 'i': case 'I': case 'f': t += 4; break;
+            case 'Z': case 'H': while (t < e && *t) ++t; ++t; break;
+            case 'B': {
+                if (t + 5 > e) return 0;
+                const uint8_t sub = t[0];
+                const uint32_t n = ld32(t + 1);
+                const uint32_t w = (sub == 'c' || sub == 'C') ? 1u : (sub == 's' || sub == 'S') ? 2u : 4u;
+                t += 5 + (uint64_t)n * w;
+                break;
+            }
+            default: return 0;
+        }
+        if (t > e) return 0;
+        if (k == key) { *val = v; return ty; }
+    }
+    return 0;
+}
+
+template <class T>
+__device__ __forceinline__ bool cmp_op(uint32_t op, T x, T y) {
+    switch (op) {
+        case 0: return x > y;
+        case 1: return x < y;
+        case 2: return x >= y;
+        case 3: return x <= y;
+        case 4: return x == y;
+        default: return x != y;
+    }
+}
+
 __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID */, int32_t ref, int32_t pos, uint32_t bmn,
-                            uint32_t fnc, int32_t l_seq) {
+                            uint32_t fnc, int32_t l_seq, const uint8_t* tags, const uint8_t* tags_end) {
     // postfix program over a tiny bool stack (bit stack in a 64-bit word); the fields every record's
     // walk has loaded anyway come in registers
     uint64_t stack = 0;
@@ -277,6 +318,31 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
                     case 4: v = x == op.value; break;
                     default: v = x != op.value; break;
                 }
+                break;
+            }
+            case 7: {     // IntegerTagFilter (filtering.d:233-252): integer or float tags only, anything else rejects
+                const uint8_t* tv = nullptr;
+                const uint32_t ty = find_tag(tags, tags_end, op.mask, &tv);
+                int64_t iv = 0;
+                bool is_int = true;
+                switch (ty) {
+                    case 'c': iv = (int8_t)tv[0]; break;
+                    case 'C': iv = tv[0]; break;
+                    case 's': iv = (int16_t)(tv[0] | (tv[1] << 8)); break;
+                    case 'S': iv = (uint16_t)(tv[0] | (tv[1] << 8)); break;
+                    case 'i': iv = (int32_t)ld32(tv); break;
+                    case 'I': iv = (int64_t)ld32(tv); break;
+                    default: is_int = false; break;
+                }
+                if (is_int) v = cmp_op<int64_t>(op.cmp, iv, op.value);
+                else if (ty == 'f') v = cmp_op<float>(op.cmp, __uint_as_float(ld32(tv)), (float)op.value);
+                else v = false;
+                break;
+            }
+            case 8: {     // TagExistenceFilter (filtering.d:216-230)
+                const uint8_t* tv = nullptr;
+                const bool present = find_tag(tags, tags_end, op.mask, &tv) != 0;
+                v = op.cmp == 5 ? present : !present;
                 break;
             }
             case 3: { bool b2 = stack & 1; stack >>= 1; bool a2 = stack & 1; stack >>= 1; sp -= 2; v = a2 && b2; break; }
@@ -397,7 +463,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
         bool sane = l_seq >= 0 && bs >= fixed && ref >= -1 && ref < refs.n_ref;
         if (!sane) ++n_bad;
         bool admit = sane && !(flag & 0x4) && ref >= 0;                       // read.d:256, unmapped reads cover nothing
-        if (admit) admit = eval_filter(filt, r, ref, pos, bmn, fnc, l_seq);                              // filtering.d:36-38
+        if (admit) admit = eval_filter(filt, r, ref, pos, bmn, fnc, l_seq, r + fixed, r + bs);                              // filtering.d:36-38
         if (admit) {
             // basesCovered + shape of the CIGAR
             const uint8_t* cg = r + 32 + l_name;

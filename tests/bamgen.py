@@ -76,6 +76,14 @@ def tag_i(key, value):
     return key.encode() + b"i" + struct.pack("<i", value)
 
 
+def tag_num(key, ty, value):
+    """Numeric aux field of BAM type ty in cCsSiIf, or A (one character)."""
+    fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+    if ty == "A":
+        return key.encode() + b"A" + value.encode()
+    return key.encode() + ty.encode() + struct.pack(fmt[ty], value)
+
+
 def tag_bytes(key, payload):
     """B:C array tag carrying arbitrary bytes."""
     return key.encode() + b"B" + b"C" + struct.pack("<I", len(payload)) + bytes(payload)

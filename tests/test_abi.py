@@ -38,9 +38,12 @@ def test_filter_compiler_default_and_errors():
     assert f.ops[1].mask == 0x400 and f.ops[4].mask == 0x200
     g = sambamba_amd.compile_filter("not (unmapped or mate_is_unmapped) and mapping_quality >= 20 or chimeric")
     assert g.n_ops > 0
+    h = sambamba_amd.compile_filter("[NM] < 3 and [XS] == null")      # integer tags and tag existence compile
+    assert [h.ops[i].kind for i in range(h.n_ops)] == [7, 8, 3]
+    assert h.ops[0].mask == ord("N") | (ord("M") << 8) and h.ops[0].cmp == 1 and h.ops[0].value == 3
     with pytest.raises(sambamba_amd.SbxError) as ei:
-        sambamba_amd.compile_filter("[NM] < 3")
-    assert ei.value.code == -5   # SBX_EUNSUPPORTED: tag conditions are outside the device subset
+        sambamba_amd.compile_filter("[RG] == 'a'")
+    assert ei.value.code == -5   # SBX_EUNSUPPORTED: string / regex tag conditions are outside the device subset
     with pytest.raises(sambamba_amd.SbxError):
         sambamba_amd.compile_filter("read_name =~ /abc/")
 

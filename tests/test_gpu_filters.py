@@ -1,0 +1,59 @@
+"""-F filters on the device (K2 eval_filter): integer tag comparisons and tag existence
+(IntegerTagFilter / TagExistenceFilter, filtering.d:216-252) against the oracle, on hand-made records that
+put the tag behind every kind of aux field, and on the reference's fixtures."""
+import os
+
+import pytest
+
+from tests import bamgen as bg
+from tests.util import GOLDEN, run_cli, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tagged(tmp_path_factory):
+    d = tmp_path_factory.mktemp("tags")
+    path = str(d / "t.bam")
+    recs = []
+    seq = "ACGT" * 10
+    variants = [
+        bg.tag_num("NM", "c", -3), bg.tag_num("NM", "C", 200), bg.tag_num("NM", "s", -300), bg.tag_num("NM", "S", 40000),
+        bg.tag_num("NM", "i", -70000), bg.tag_num("NM", "I", 3000000000), bg.tag_num("NM", "f", 2.5), bg.tag_num("NM", "f", 3.0),
+        bg.tag_num("NM", "A", "x"), bg.tag_z("NM", "7"), b"",
+        bg.tag_z("RG", "g1") + bg.tag_bytes("ZB", range(7)) + bg.tag_num("XS", "A", "q") + bg.tag_num("NM", "C", 3),
+        bg.tag_num("XN", "i", 5) + bg.tag_num("NM", "i", 3) + bg.tag_num("NM", "i", 99),       # the first NM counts
+        bg.tag_z("MD", "40") + bg.tag_num("AS", "i", 37) + bg.tag_num("NM", "C", 0),
+        bg.tag_num("AS", "f", 36.5), bg.tag_num("nm", "C", 1),
+    ]
+    pos = 100
+    for k in range(6):
+        for i, t in enumerate(variants):
+            recs.append(bg.make_record(0, pos, "40M", seq, 30, name="r%d_%d" % (k, i), tags=t))
+            pos += 3
+    bg.write_bam(path, [("c1", 5000)], recs, read_groups=[("g1", "s1")])
+    return path
+
+
+@pytest.mark.parametrize("flt", [
+    "[NM] > 2", "[NM] >= 3", "[NM] < 0", "[NM] <= -300", "[NM] == 3", "[NM] != 3", "[NM] > 2999999999",
+    "[NM] == null", "[NM] != null", "[XS] != null", "[XS] == null and [NM] >= 0",
+    "not ([NM] > 2) and mapping_quality >= 0", "[AS] >= 37 or [NM] == 200", "[AS] < 37", "[nm] == 1", "[ZZ] > 0",
+])
+def test_tag_filters_synthetic(tagged, flt):
+    args = ["base", "-F", flt, tagged]
+    assert run_cli(args) == run_oracle(args)
+
+
+@pytest.mark.parametrize("flt", ["[NM] <= 1", "[NM] > 1 and mapping_quality >= 30", "[XS] == null", "[AS] > 90 and not duplicate",
+                                 "[MD] != null and [NM] == 0"])
+@pytest.mark.parametrize("bam", ["issue_204.bam", "mate_overlaps_1_3M_4M.bam"])
+def test_tag_filters_reference_fixtures(flt, bam):
+    args = ["base", "-F", flt, bam]
+    a, b = run_cli(args, cwd=GOLDEN), run_oracle(args, cwd=GOLDEN)
+    assert a == b
+
+
+def test_string_tag_filter_is_reported_unsupported(tagged):
+    r = run_cli(["base", "-F", "[RG] == 'g1'", tagged], check=False)
+    assert r.returncode != 0 and b"device-compilable subset" in r.stderr
