@@ -545,31 +545,36 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* _
                                                                 const uint32_t* __restrict__ tile_hi, uint32_t n_tiles,
                                                                 uint32_t* __restrict__ active, uint32_t* __restrict__ slot_of,
                                                                 uint32_t* __restrict__ n_active) {
-    __shared__ uint32_t part[kScanThreads];
-    uint32_t t = threadIdx.x;
-    uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
-    uint32_t lo = t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += (tile_hi[i] > tile_lo[i]) ? 1u : 0u;
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
-        uint32_t v = t >= d ? part[t - d] : 0;
+    // 1024 tiles per step, coalesced: rank inside the wave by ballot, wave totals through LDS
+    __shared__ uint32_t wtot[kScanThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    uint32_t run = 0;                    // active tiles before this step (workgroup-uniform)
+    for (uint32_t i0 = 0; i0 < n_tiles; i0 += kScanThreads) {
+        const uint32_t i = i0 + t;
+        const bool on = i < n_tiles && tile_hi[i] > tile_lo[i];
+        const uint64_t m = __ballot(on);
+        if (lane == 0) wtot[wv] = (uint32_t)__popcll(m);
         __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = t ? part[t - 1] : 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        if (tile_hi[i] > tile_lo[i]) {
-            active[run] = i;
-            slot_of[i] = run;
-            ++run;
-        } else {
-            slot_of[i] = 0xFFFFFFFFu;
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+            const uint32_t v = wtot[w];
+            before += w < wv ? v : 0u;
+            all += v;
         }
+        if (i < n_tiles) {
+            if (on) {
+                const uint32_t slot = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                active[slot] = i;
+                slot_of[i] = slot;
+            } else {
+                slot_of[i] = 0xFFFFFFFFu;
+            }
+        }
+        run += all;
+        __syncthreads();
     }
-    if (t == kScanThreads - 1) *n_active = part[kScanThreads - 1];
+    if (t == 0) *n_active = run;
 }
 
 }  // namespace
