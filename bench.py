@@ -111,14 +111,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # one rank per GPU; SBX_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs
+    # than ranks (ranks then share devices and the timing reductions travel through host memory)
+    backend = os.environ.get("SBX_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if rank == 0:
         ensure_built()
@@ -137,7 +143,7 @@ def main():
     if rank != 0:
         info = json.load(open(path + ".json"))
 
-    d = sambamba_amd.Depth(path, device=local_rank if world > 1 else 0)
+    d = sambamba_amd.Depth(path, device=dev_index)
     d.set_params()             # depth base, default filter, -q 0
     d.preload()                # compressed BAM resident in HBM before the timed region
 
@@ -159,10 +165,10 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([float(last["n_records"]), float(last["n_admitted"])], dtype=torch.float64, device=dev)
+        r = torch.tensor([float(last["n_records"]), float(last["n_admitted"])], dtype=torch.float64, device=red_dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_reads, total_admitted = float(r[0].item()), float(r[1].item())
     else:
