@@ -74,6 +74,7 @@ struct sbx_ctx {
     DevBuf<int32_t> d_ref_len;
     DevBuf<uint32_t> d_tile_base, d_tile_lo, d_tile_hi, d_active, d_slot_of, d_n_active;
     DevBuf<uint32_t> d_counters, d_span;
+    DevBuf<uint32_t> d_covm, d_addm;     // per-column quantities of region/window runs with --fix-mate-overlaps
     DevBuf<DeviceFilter> d_filter;
     DevBuf<char> d_rg_ids;
     DevBuf<uint32_t> d_rg_off;
@@ -363,9 +364,6 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     {
         if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
         if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
-        if (c->fix_mate && c->mode != SBX_MODE_BASE)
-            throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps is only on the device path in base mode (the region/window bookkeeping of "
-                                          "depth.d:717-845 is history dependent, see DESIGN.md)");
         SBX_HIP(hipSetDevice(c->device));
         hipStream_t s = c->stream;
         c->have_run = false;
@@ -450,7 +448,36 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         c->d_tile_base.ensure((size_t)n_ref + 1);
         if (n_ref) SBX_HIP(hipMemcpyAsync(c->d_ref_len.p, ref_len.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(c->d_tile_base.p, tile_base.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
-        RefTable refs{c->d_ref_len.p, c->d_tile_base.p, n_ref};
+        // -L: merged, start-sorted regions per contig for the read selection in `describe`
+        DevBuf<SortedRegion> d_sel;
+        DevBuf<uint32_t> d_sel_first;
+        if (restricted) {
+            std::vector<sbx_region> regs = sel;
+            std::sort(regs.begin(), regs.end(), [](const sbx_region& x, const sbx_region& y) {
+                if (x.ref_id != y.ref_id) return x.ref_id < y.ref_id;
+                if (x.start != y.start) return x.start < y.start;
+                return x.end < y.end;
+            });
+            std::vector<SortedRegion> merged;
+            std::vector<uint32_t> first((size_t)n_ref + 1, 0);
+            size_t j = 0;
+            for (int32_t r = 0; r < n_ref; ++r) {
+                first[(size_t)r] = (uint32_t)merged.size();
+                bool open = false;
+                while (j < regs.size() && regs[j].ref_id == (uint32_t)r) {
+                    if (open && merged.back().end >= regs[j].start) merged.back().end = std::max(merged.back().end, regs[j].end);
+                    else { merged.push_back({regs[j].start, regs[j].end, 0}); open = true; }
+                    ++j;
+                }
+            }
+            first[(size_t)n_ref] = (uint32_t)merged.size();
+            d_sel.alloc(merged.size() + 1);
+            d_sel_first.alloc((size_t)n_ref + 2);
+            if (!merged.empty()) SBX_HIP(hipMemcpyAsync(d_sel.p, merged.data(), merged.size() * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
+            SBX_HIP(hipMemcpyAsync(d_sel_first.p, first.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+            SBX_HIP(hipStreamSynchronize(s));
+        }
+        RefTable refs{c->d_ref_len.p, c->d_tile_base.p, n_ref, restricted ? d_sel.p : nullptr, restricted ? d_sel_first.p : nullptr};
 
         c->d_entry.ensure(nb + 1);
         c->d_exit.ensure(nb + 1);
@@ -582,7 +609,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
             throw Error(SBX_ERG, "error in read: read group is not present in the header (" + std::to_string(ist.n_unknown_rg) + " reads)");
 
         // ---- K3 ----
-        const bool want_span = c->min_bq > 0;
+        const bool want_span = c->min_bq > 0 || (c->fix_mate && c->mode != SBX_MODE_BASE);
         size_t per_tile = (size_t)T * S * SBX_NCOUNTERS;
         c->d_counters.ensure((size_t)n_active * per_tile + 4);
         if (want_span) c->d_span.ensure((size_t)n_active * T + 4);
@@ -603,8 +630,17 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
             if (max_partners > 1)
                 throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps: a read overlaps two or more records with the same name; the reference's "
                                               "result then depends on per-column status history (depth.d:343-377) and is not on the device path");
-            launch_accumulate_mates(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
-                                    c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+            if (c->mode == SBX_MODE_BASE) {
+                launch_accumulate_mates(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
+                                        c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+            } else {
+                // region / window: the statistics come from per-column quantities, not from the base counters
+                c->d_covm.ensure((size_t)n_active * T * S + 1);
+                c->d_addm.ensure((size_t)n_active * T * S + 1);
+                if (n_active) SBX_HIP(hipMemsetAsync(c->d_counters.p, 0, (size_t)n_active * per_tile * 4, s));
+                launch_mates_columns(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
+                                     c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_covm.p, c->d_addm.p, c->d_span.p, s);
+            }
         } else
         launch_accumulate(c->U(), c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, c->d_tile_base.p,
                           n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
@@ -812,9 +848,59 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
     SBX_HIP(hipMemsetAsync(d_seen.p, 0, d_seen.bytes(), s));
     EventTimer t;
     t.start(s);
+    const uint64_t n_records = c->stats.n_records;
+    if (c->fix_mate && c->mode != SBX_MODE_BASE) {
+        // ---- --fix-mate-overlaps: closed form of depth.d:717-845 (reduce.hip) -------------------------------------
+        const size_t n_ref = c->hdr.refs.size();
+        DevBuf<uint32_t> d_firstcol(n + 1);
+        SBX_HIP(hipMemsetAsync(d_firstcol.p, 0xFF, d_firstcol.bytes(), s));
+        launch_range_first(d_chunks.p, (uint32_t)chunks.size(), c->d_span.p, c->d_slot_of.p, c->d_tile_base.p, T, d_firstcol.p, s);
+        launch_range_reduce_m(d_chunks.p, (uint32_t)chunks.size(), c->d_covm.p, c->d_addm.p, c->d_span.p, c->d_slot_of.p,
+                              c->d_tile_base.p, T, S, d_thr.p, n_thr, d_nb.p, d_cov.p, d_seen.p, s);
+        // (ref, start)-sorted view with prefix maxima of the ends, and the union of the ranges (where pairs get "fixed")
+        std::vector<uint32_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (ranges[x].ref_id != ranges[y].ref_id) return ranges[x].ref_id < ranges[y].ref_id;
+            return ranges[x].start < ranges[y].start;
+        });
+        std::vector<SortedRegion> regs(n), un;
+        std::vector<uint32_t> pmax(n), first(n_ref + 1, 0), un_first(n_ref + 1, 0);
+        size_t j = 0;
+        for (size_t r = 0; r < n_ref; ++r) {
+            first[r] = (uint32_t)j;
+            un_first[r] = (uint32_t)un.size();
+            uint32_t mx = 0;
+            bool open = false;
+            while (j < n && ranges[order[j]].ref_id == r) {
+                const sbx_region& g = ranges[order[j]];
+                regs[j] = {g.start, g.end, order[j]};
+                mx = std::max(mx, g.end);
+                pmax[j] = mx;
+                if (g.end > g.start) {
+                    if (open && un.back().end >= g.start) un.back().end = std::max(un.back().end, g.end);
+                    else { un.push_back({g.start, g.end, 0}); open = true; }
+                }
+                ++j;
+            }
+        }
+        first[n_ref] = (uint32_t)j;
+        un_first[n_ref] = (uint32_t)un.size();
+        DevBuf<SortedRegion> d_regs2(n + 1), d_un(un.size() + 1);
+        DevBuf<uint32_t> d_pmax2(n + 1), d_first2(n_ref + 2), d_unfirst(n_ref + 2);
+        if (n) {
+            SBX_HIP(hipMemcpyAsync(d_regs2.p, regs.data(), n * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
+            SBX_HIP(hipMemcpyAsync(d_pmax2.p, pmax.data(), n * 4, hipMemcpyHostToDevice, s));
+        }
+        if (!un.empty()) SBX_HIP(hipMemcpyAsync(d_un.p, un.data(), un.size() * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(d_first2.p, first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(d_unfirst.p, un_first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+        launch_count_reads_mates(c->U(), c->d_desc.p, n_records, c->d_rec_ref.p, c->d_mate.p, d_regs2.p, d_pmax2.p, d_first2.p, d_un.p,
+                                 d_unfirst.p, windows, d_firstcol.p, S, c->min_bq, d_nb.p, d_nr.p, s);
+        SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
+    } else {
     launch_range_reduce(d_chunks.p, (uint32_t)chunks.size(), c->d_counters.p, c->span_valid ? c->d_span.p : nullptr, c->d_slot_of.p,
                         c->d_tile_base.p, T, S, d_thr.p, n_thr, d_nb.p, d_cov.p, d_seen.p, s);
-    const uint64_t n_records = c->stats.n_records;
     DevBuf<uint64_t> d_wb, d_nw;
     DevBuf<SortedRegion> d_regs;
     DevBuf<uint32_t> d_pmax, d_first;
@@ -858,6 +944,7 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
         launch_count_reads_regions(c->U(), c->d_desc.p, n_records, c->d_rec_ref.p, d_regs.p, d_pmax.p, d_first.p, S, c->min_bq,
                                    d_nr.p, s);
         SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
+    }
     }
     t.stop(s);
     std::vector<uint32_t> h_nb(n * S), h_nr(n * S), h_seen(n);

@@ -501,6 +501,12 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
                 else d.kind = 2;
             }
         }
+        if (admit && refs.sel) {
+            // the read must overlap one of the requested regions: pos < region.end && pos + span > region.start
+            uint32_t lo = refs.sel_first[ref], hi = refs.sel_first[ref + 1];
+            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((int64_t)refs.sel[m].end > (int64_t)pos) hi = m; else lo = m + 1; }
+            if (lo >= refs.sel_first[ref + 1] || (int64_t)refs.sel[lo].start >= (int64_t)d.end) { admit = false; d.kind = 0; d.end = d.pos; }
+        }
         if (admit && rg.lookup) {
             const uint8_t* tags = r + fixed;
             uint32_t s = lookup_sample(tags, r + bs, rg);

@@ -55,6 +55,10 @@ struct RefTable {           // per-reference device arrays
     const int32_t* ref_len;        // [n_ref]
     const uint32_t* tile_base;     // [n_ref + 1] index of the contig's first tile
     int32_t n_ref;
+    // -L read selection (bam.getReadsOverlapping, randomaccessmanager.d:397-461): merged regions sorted by start,
+    // sel_first[ref] .. sel_first[ref + 1]; sel == nullptr: every read
+    const SortedRegion* sel;
+    const uint32_t* sel_first;
 };
 
 struct RgTable {            // read-group id strings -> sample id (depth.d:1170-1181)
@@ -139,6 +143,22 @@ void launch_count_reads_windows(const uint8_t* d_U, const RecDesc* d_desc, uint6
 void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
                                 const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first, uint32_t S,
                                 uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);
+
+// region / window statistics with --fix-mate-overlaps (mates.hip: per-column quantities; reduce.hip: the rest)
+void launch_mates_columns(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,
+                          const uint32_t* d_tile_hi, const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base,
+                          int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_covm, uint32_t* d_addm,
+                          uint32_t* d_span, hipStream_t stream);
+void launch_range_first(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_span, const uint32_t* d_slot_of,
+                        const uint32_t* d_tile_base, uint32_t T, uint32_t* d_first, hipStream_t stream);
+void launch_range_reduce_m(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_covm, const uint32_t* d_addm,
+                           const uint32_t* d_span, const uint32_t* d_slot_of, const uint32_t* d_tile_base, uint32_t T, uint32_t S,
+                           const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases, uint32_t* d_cov_counts, uint32_t* d_seen,
+                           hipStream_t stream);
+void launch_count_reads_mates(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
+                              const uint32_t* d_mate, const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first,
+                              const SortedRegion* d_union, const uint32_t* d_union_first, bool everywhere, const uint32_t* d_first,
+                              uint32_t S, uint32_t min_bq, uint32_t* d_n_bases, uint32_t* d_n_reads, hipStream_t stream);
 
 // K6 format_base_rows (format.hip): text of `depth base` for positions [beg, end) of one contig
 struct FormatArgs {

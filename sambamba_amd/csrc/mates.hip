@@ -177,6 +177,78 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     }
 }
 
+// Per-column quantities of `depth region|window --fix-mate-overlaps` (PerRegionPrinter.push with mate
+// fixing, depth.d:760-845), for every position of a tile and every sample:
+//   covm = what the column contributes to the threshold test: reads that are not paired at this column count
+//          with their own base quality (D/N: 255), a pair counts once, with the better mate's (depth.d:820-836);
+//   addm = what the column adds to n_bases through process_base: the better mate of every pair, and every read
+//          that HAS BEEN paired earlier and is alone again (status "past", depth.d:824-826) -- D/N included.
+// A read's status at a column follows from geometry alone: before the overlap with its partner it is "none", inside
+// it the two form a pair, after it the survivor is "past" (detectOverlappingMates, depth.d:319-388).
+__global__ __launch_bounds__(kMateThreads) void k_mates_columns(
+    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ mate,
+    const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active,
+    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq,
+    uint32_t* __restrict__ covm_out, uint32_t* __restrict__ addm_out, uint32_t* __restrict__ span_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* covm = lds;                 // [T][S]
+    uint32_t* addm = lds + T * S;         // [T][S]
+    uint32_t* spn = lds + 2 * T * S;      // [T]
+    const uint32_t tile = active[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < 2 * T * S + T; i += kMateThreads) lds[i] = 0;
+    int lo_r = 0, hi_r = n_ref;
+    while (hi_r - lo_r > 1) {
+        int mid = (lo_r + hi_r) >> 1;
+        if (tile_base[mid] <= tile) lo_r = mid; else hi_r = mid;
+    }
+    const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T), te = ts + (int32_t)T;
+    const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t ri = r_lo + wave; ri < r_hi; ri += kMateThreads / 64) {
+        const RecDesc a = desc[ri];
+        if (a.kind == 0 || a.pos >= te || a.end <= ts) continue;
+        const uint32_t mi = mate[ri];
+        RecDesc b;
+        b.kind = 0; b.pos = 0; b.end = 0; b.rec_off = 0; b.l_seq = 0; b.n_cigar = 0; b.l_name = 0; b.q_start = 0; b.sample = 0; b.mapq = 0;
+        if (mi != 0xFFFFFFFFu) b = desc[mi];
+        const uint32_t sample = S > 1 ? a.sample : 0u;
+        const int32_t ob = b.kind != 0 ? (a.end < b.end ? a.end : b.end) : 0x7FFFFFFF;     // end of the overlap with the partner
+        const int32_t p0 = a.pos > ts ? a.pos : ts, p1 = a.end < te ? a.end : te;
+        for (int32_t p = p0 + (int32_t)lane; p < p1; p += 64) {
+            const Cursor ca = state_at(U, a, p);
+            if (ca.kind == 0) continue;
+            atomicAdd(&spn[p - ts], 1u);
+            uint32_t q = ca.kind == 1 ? ca.qual : 255u;
+            bool adds = false;                       // does this column add to n_bases through process_base?
+            if (b.kind != 0) {
+                const Cursor cb = state_at(U, b, p);
+                if (cb.kind != 0) {
+                    if (!(ri < mi)) continue;        // the pair is handled once, by its first record
+                    // selectBetterMate(m1, m2), m1 = the record earlier in the file; ties -> m2 (depth.d:391-399)
+                    bool first_wins;
+                    if (ca.kind != 1 || cb.kind != 1) first_wins = a.mapq > b.mapq;
+                    else first_wins = ca.qual > cb.qual;
+                    if (!first_wins) q = cb.kind == 1 ? cb.qual : 255u;
+                    adds = true;
+                } else if (p >= ob) {
+                    adds = true;                     // alone again after having been paired: "past"
+                }
+            }
+            if (q >= min_bq) {
+                atomicAdd(&covm[(uint32_t)(p - ts) * S + sample], 1u);
+                if (adds) atomicAdd(&addm[(uint32_t)(p - ts) * S + sample], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < T * S; i += kMateThreads) {
+        covm_out[(size_t)blockIdx.x * T * S + i] = covm[i];
+        addm_out[(size_t)blockIdx.x * T * S + i] = addm[i];
+    }
+    for (uint32_t i = threadIdx.x; i < T; i += kMateThreads) span_out[(size_t)blockIdx.x * T + i] = spn[i];
+}
+
 }  // namespace
 
 void launch_find_mates(const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
@@ -205,4 +277,18 @@ void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const ui
     SBX_HIP(hipGetLastError());
 }
 
+}  // namespace sbx
+
+namespace sbx {
+void launch_mates_columns(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,
+                          const uint32_t* d_tile_hi, const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base,
+                          int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_covm, uint32_t* d_addm,
+                          uint32_t* d_span, hipStream_t stream) {
+    if (!n_active) return;
+    const size_t lds = ((size_t)2 * tile_pos * n_samples + tile_pos) * 4;
+    SBX_HIP(hipFuncSetAttribute((const void*)k_mates_columns, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_mates_columns, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo, d_tile_hi,
+                       d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_covm, d_addm, d_span);
+    SBX_HIP(hipGetLastError());
+}
 }  // namespace sbx

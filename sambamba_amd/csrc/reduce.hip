@@ -167,6 +167,192 @@ __global__ __launch_bounds__(kRedThreads) void k_count_reads_regions(
     }
 }
 
+// ---- region / window statistics with --fix-mate-overlaps -------------------------------------------------------
+// Closed form of PerRegionPrinter.push with mate fixing (depth.d:717-845), derived from the literal restatement in
+// oracle/ and checked against it (tests/test_gpu_mates.py).  For a region R, with F = the first pileup column inside
+// R, a pair's overlap O = [oa, ob) and f = the first column of O that lies inside ANY region (there the pair is
+// "fixed", depth.d:751-758):
+//   n_bases[R] = sum over reads counted for R of B(r, R)                      (countRead, depth.d:661-669)
+//              - for pairs with f in R: B(r1, R from f on) + B(r2, R from f on)   (uncountOverlappingMates, :717-743)
+//              + sum over columns of R of addm                                 (process_base, :802-808 -- k_mates_columns)
+//   a read is counted for R iff it spans F and is not "fixed" there (f < F, F inside O), or starts inside R after F;
+//   n_reads[R] = sum over counted reads of [B > 0], pairs with f in R merged into one read ([B1>0] + [B2>0] ->
+//                [B1+B2 > 0]), + 1 for every pair that is already fixed at F and has a base in R (:779-796);
+//   cov_count[R][t] = #columns of R with covm >= T_t.
+// B(r, [lo, hi)) = number of M/=/X bases of r at reference positions in [lo, hi) with quality >= min_bq.
+
+// number of M/=/X bases of the read at reference positions in [lo, hi) with quality >= min_bq (countOverlappingBases,
+// depth.d:671-698; zero-length reference-consuming ops occupy one column and the read ends at d.end, as in K3)
+__device__ uint32_t count_good(const uint8_t* U, const RecDesc& d, uint32_t min_bq, int64_t lo, int64_t hi) {
+    const uint8_t* rec = U + d.rec_off;
+    const uint8_t* cig = rec + 36 + d.l_name;
+    const uint8_t* seq = cig + 4 * (uint32_t)d.n_cigar;
+    const uint8_t* qual = seq + ((d.l_seq + 1) >> 1);
+    uint32_t n = 0;
+    auto run = [&](int64_t rp, uint32_t qp, uint32_t len) {
+        int64_t a = lo > rp ? lo : rp, b = hi < rp + (int64_t)len ? hi : rp + (int64_t)len;
+        if (a >= b) return;
+        uint32_t q0 = qp + (uint32_t)(a - rp), q1 = qp + (uint32_t)(b - rp);
+        if (q1 > d.l_seq) q1 = d.l_seq;
+        for (uint32_t q = q0; q < q1; ++q) n += qual[q] >= min_bq ? 1u : 0u;
+    };
+    if (lo >= hi) return 0;
+    if (d.kind == 1) { run(d.pos, d.q_start, (uint32_t)(d.end - d.pos)); return n; }
+    int64_t rp = d.pos;
+    uint32_t qp = 0;
+    for (uint32_t k = 0; k < d.n_cigar; ++k) {
+        uint32_t op = ld32r(cig + 4 * k);
+        uint32_t ty = (kCigarType >> ((op & 15u) * 2u)) & 3u, len = op >> 4;
+        if (ty & 2u) {
+            if (len == 0) len = 1;
+            int64_t room = (int64_t)d.end - rp;
+            if ((int64_t)len > room) len = (uint32_t)(room > 0 ? room : 0);
+        }
+        if (ty == 3) {
+            run(rp, qp, len);
+            rp += len;
+            qp += len;
+        } else if (ty == 2) {
+            rp += len;
+        } else if (ty == 1) {
+            qp += len;
+        }
+        if (rp >= hi || rp >= d.end) break;
+    }
+    return n;
+}
+
+// first pileup column of every range: atomicMin over the positions with span > 0
+__global__ __launch_bounds__(kRedThreads) void k_range_first(const RangeChunk* __restrict__ chunks, uint32_t n_chunks,
+                                                             const uint32_t* __restrict__ span, const uint32_t* __restrict__ slot_of,
+                                                             const uint32_t* __restrict__ tile_base, uint32_t T, uint32_t* first /*[id]*/) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t ci = blockIdx.x * (kRedThreads / 64) + wv;
+    if (ci >= n_chunks) return;
+    const RangeChunk ch = chunks[ci];
+    const uint32_t tb = tile_base[ch.ref_id], t_end = tile_base[ch.ref_id + 1];
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t p = ch.start + lane; p < ch.end && best == 0xFFFFFFFFu; p += 64) {
+        const uint32_t tile = tb + p / T;
+        if (tile >= t_end) break;
+        const uint32_t slot = slot_of[tile];
+        if (slot == 0xFFFFFFFFu) continue;
+        if (span[(size_t)slot * T + (p & (T - 1))]) best = p;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_down(best, d, 64); best = o < best ? o : best; }
+    if (lane == 0 && best != 0xFFFFFFFFu) atomicMin(&first[ch.id], best);
+}
+
+// column sums of a range: n_bases += addm, cov_count[t] += [covm >= T_t], seen
+__global__ __launch_bounds__(kRedThreads) void k_range_reduce_m(
+    const RangeChunk* __restrict__ chunks, uint32_t n_chunks, const uint32_t* __restrict__ covm, const uint32_t* __restrict__ addm,
+    const uint32_t* __restrict__ span, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ tile_base, uint32_t T,
+    uint32_t S, const uint32_t* __restrict__ thresholds, uint32_t n_thr, uint32_t* n_bases, uint32_t* cov_counts, uint32_t* seen) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t ci = blockIdx.x * (kRedThreads / 64) + wv;
+    if (ci >= n_chunks) return;
+    const RangeChunk ch = chunks[ci];
+    const uint32_t tb = tile_base[ch.ref_id], t_end = tile_base[ch.ref_id + 1];
+    uint32_t any = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        uint32_t nb = 0;
+        uint32_t cc[kMaxThresholds];
+#pragma unroll
+        for (int t = 0; t < kMaxThresholds; ++t) cc[t] = 0;
+        for (uint32_t p = ch.start + lane; p < ch.end; p += 64) {
+            const uint32_t tile = tb + p / T;
+            if (tile >= t_end) continue;
+            const uint32_t slot = slot_of[tile];
+            if (slot == 0xFFFFFFFFu) continue;
+            const size_t at = (size_t)slot * T + (p & (T - 1));
+            if (!span[at]) continue;                     // statistics are gathered per pileup column
+            any = 1;
+            nb += addm[at * S + s];
+            const uint32_t cov = covm[at * S + s];
+#pragma unroll
+            for (int t = 0; t < kMaxThresholds; ++t)
+                if ((uint32_t)t < n_thr && cov >= thresholds[t]) cc[t] += 1;
+        }
+        nb = wave_sum(nb);
+        if (lane == 0 && nb) atomicAdd(&n_bases[(size_t)ch.id * S + s], nb);
+#pragma unroll
+        for (int t = 0; t < kMaxThresholds; ++t) {
+            if ((uint32_t)t < n_thr) {
+                uint32_t v = wave_sum(cc[t]);
+                if (lane == 0 && v) atomicAdd(&cov_counts[((size_t)ch.id * S + s) * n_thr + t], v);
+            }
+        }
+    }
+    const uint64_t am = __ballot(any != 0);
+    if (lane == 0 && am) seen[ch.id] = 1;
+}
+
+// first column of [oa, ob) inside the union of the regions (sorted, disjoint intervals per contig); 0xFFFFFFFF = none
+__device__ uint32_t first_in_union(const SortedRegion* __restrict__ un, uint32_t lo, uint32_t hi, uint32_t oa, uint32_t ob) {
+    uint32_t a = lo, c = hi;          // first interval with end > oa
+    while (a < c) { const uint32_t m = (a + c) >> 1; if (un[m].end > oa) c = m; else a = m + 1; }
+    if (a >= hi || un[a].start >= ob) return 0xFFFFFFFFu;
+    return un[a].start > oa ? un[a].start : oa;
+}
+
+// per read: countRead / uncountOverlappingMates / countPreviouslySeenMateOverlaps for every region it touches
+__global__ __launch_bounds__(kRedThreads) void k_count_reads_mates(
+    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, uint64_t n_records, const int32_t* __restrict__ rec_ref,
+    const uint32_t* __restrict__ mate, const SortedRegion* __restrict__ regs, const uint32_t* __restrict__ pmax_end,
+    const uint32_t* __restrict__ ref_first, const SortedRegion* __restrict__ un, const uint32_t* __restrict__ un_first,
+    uint32_t everywhere /* windows: every column is inside a region */, const uint32_t* __restrict__ first, uint32_t S,
+    uint32_t min_bq, uint32_t* n_bases, uint32_t* n_reads) {
+    const uint64_t i = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    if (i >= n_records) return;
+    const RecDesc d = desc[i];
+    if (d.kind == 0) return;
+    const int32_t ref = rec_ref[i];
+    const uint32_t lo0 = ref_first[ref], hi0 = ref_first[ref + 1];
+    if (lo0 >= hi0) return;
+    const uint32_t mi = mate[i];
+    RecDesc b;
+    b.kind = 0; b.pos = 0; b.end = 0;
+    uint32_t oa = 0, ob = 0, f = 0xFFFFFFFFu;
+    if (mi != 0xFFFFFFFFu) {
+        b = desc[mi];
+        oa = (uint32_t)(d.pos > b.pos ? d.pos : b.pos);
+        ob = (uint32_t)(d.end < b.end ? d.end : b.end);
+        f = everywhere ? oa : first_in_union(un, un_first[ref], un_first[ref + 1], oa, ob);
+    }
+    const bool pair_owner = b.kind != 0 && i < mi;      // pair terms are applied once, by the pair's first record
+    // regions with start < d.end, walking back while anything can still reach the read
+    uint32_t a = lo0, c = hi0;
+    while (a < c) { uint32_t m = (a + c) >> 1; if ((int64_t)regs[m].start < (int64_t)d.end) a = m + 1; else c = m; }
+    const uint32_t s = S > 1 ? d.sample : 0u;
+    for (uint32_t j = a; j > lo0;) {
+        --j;
+        if ((int64_t)pmax_end[j] <= (int64_t)d.pos) break;
+        const uint32_t rs = regs[j].start, re = regs[j].end, id = regs[j].id;
+        if ((int64_t)re <= (int64_t)d.pos) continue;
+        const uint32_t F = first[id];
+        if (F == 0xFFFFFFFFu) continue;
+        const uint32_t B = count_good(U, d, min_bq, rs, re);
+        const bool fixed_at_F = b.kind != 0 && F >= oa && F < ob && f != 0xFFFFFFFFu && f < F;
+        const bool spans_F = (int64_t)d.pos <= (int64_t)F && (int64_t)F < (int64_t)d.end;
+        const bool counted = (spans_F && !fixed_at_F) || ((int64_t)d.pos > (int64_t)F && (int64_t)d.pos < (int64_t)re);
+        if (counted) {
+            if (B) atomicAdd(&n_bases[(size_t)id * S + s], B);
+            if (B) atomicAdd(&n_reads[(size_t)id * S + s], 1u);
+        }
+        if (pair_owner && rs < ob && re > oa) {
+            const uint32_t B2 = count_good(U, b, min_bq, rs, re);
+            if (f != 0xFFFFFFFFu && f >= rs && f < re) {
+                const uint32_t from = count_good(U, d, min_bq, f, re) + count_good(U, b, min_bq, f, re);
+                if (from) atomicSub(&n_bases[(size_t)id * S + s], from);
+                const uint32_t merged = (B + B2 > 0) ? 1u : 0u, apart = (B > 0 ? 1u : 0u) + (B2 > 0 ? 1u : 0u);
+                if (apart != merged) atomicSub(&n_reads[(size_t)id * S + s], apart - merged);
+            }
+            if (fixed_at_F && (B + B2 > 0)) atomicAdd(&n_reads[(size_t)id * S + s], 1u);
+        }
+    }
+}
+
 }  // namespace
 
 void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_counters, const uint32_t* d_span,
@@ -195,6 +381,37 @@ void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint6
     if (!n_records) return;
     hipLaunchKernelGGL(k_count_reads_regions, dim3((uint32_t)((n_records + kRedThreads - 1) / kRedThreads)), dim3(kRedThreads), 0,
                        stream, d_U, d_desc, n_records, d_rec_ref, d_regs, d_pmax_end, d_ref_first, S, min_bq, d_n_reads);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_range_first(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_span, const uint32_t* d_slot_of,
+                        const uint32_t* d_tile_base, uint32_t T, uint32_t* d_first, hipStream_t stream) {
+    if (!n_chunks) return;
+    const uint32_t per = kRedThreads / 64;
+    hipLaunchKernelGGL(k_range_first, dim3((n_chunks + per - 1) / per), dim3(kRedThreads), 0, stream, d_chunks, n_chunks, d_span, d_slot_of,
+                       d_tile_base, T, d_first);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_range_reduce_m(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_covm, const uint32_t* d_addm,
+                           const uint32_t* d_span, const uint32_t* d_slot_of, const uint32_t* d_tile_base, uint32_t T, uint32_t S,
+                           const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases, uint32_t* d_cov_counts, uint32_t* d_seen,
+                           hipStream_t stream) {
+    if (!n_chunks) return;
+    const uint32_t per = kRedThreads / 64;
+    hipLaunchKernelGGL(k_range_reduce_m, dim3((n_chunks + per - 1) / per), dim3(kRedThreads), 0, stream, d_chunks, n_chunks, d_covm,
+                       d_addm, d_span, d_slot_of, d_tile_base, T, S, d_thresholds, n_thr, d_n_bases, d_cov_counts, d_seen);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_count_reads_mates(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
+                              const uint32_t* d_mate, const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first,
+                              const SortedRegion* d_union, const uint32_t* d_union_first, bool everywhere, const uint32_t* d_first,
+                              uint32_t S, uint32_t min_bq, uint32_t* d_n_bases, uint32_t* d_n_reads, hipStream_t stream) {
+    if (!n_records) return;
+    hipLaunchKernelGGL(k_count_reads_mates, dim3((uint32_t)((n_records + kRedThreads - 1) / kRedThreads)), dim3(kRedThreads), 0, stream,
+                       d_U, d_desc, n_records, d_rec_ref, d_mate, d_regs, d_pmax_end, d_ref_first, d_union, d_union_first,
+                       everywhere ? 1u : 0u, d_first, S, min_bq, d_n_bases, d_n_reads);
     SBX_HIP(hipGetLastError());
 }
 
