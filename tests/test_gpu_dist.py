@@ -1,0 +1,53 @@
+"""`depth region|window` of one BAM sharded over the ranks of a torch.distributed job (sambamba_amd.dist_depth,
+BASELINE config 4's shape): every rank runs its contigs through the device, rank 0 prints -- byte-identical to the
+single-GPU CLI.  Ranks share the one GPU of the test box and talk through gloo; on a multi-GPU node the same
+module runs one rank per GPU over RCCL."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.util import ROOT, gen_bam, run_cli
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def genome(tmp_path_factory):
+    d = tmp_path_factory.mktemp("dist")
+    bam = gen_bam(str(d / "g.bam"), "c1:90000,c2:30000,cNone:2500,c3:70000,c4:900,c5:50000", coverage=12, seed=41,
+                  extra=["--samples", "2", "--insert-mean", "260", "--insert-sd", "40", "--tie-free-overlaps"])
+    bed = str(d / "r.bed")
+    with open(bed, "w") as fh:
+        fh.write("c3\t100\t9000\tx\nc1\t5000\t5100\ty\nc5\t49000\t50000\tz\ncNone\t10\t500\tq\nc1\t80000\t89000\tw\nc2\t0\t30000\tv\n")
+    return bam, bed
+
+
+def run_sharded(args, world, port):
+    env = dict(os.environ, SBX_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "sambamba_amd.dist_depth"] + args
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    # gloo announces its connections on stdout while the process group comes up (the ranks' lines interleave);
+    # rank 0 prints afterwards, starting with the "# chrom ..." header
+    at = r.stdout.find(b"# ")
+    return r.stdout[at:] if at >= 0 else r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("args", [
+    ["region", "-L", "BED", "-T", "5", "-T", "20"],
+    ["region", "-L", "BED", "-m", "-q", "20", "-T", "3"],
+    ["window", "-w", "1000", "-T", "10"],
+    ["window", "-w", "700", "-m", "-q", "13", "--combined"],
+])
+def test_sharded_equals_single_gpu_cli(genome, args, world):
+    bam, bed = genome
+    if "--combined" in args and "-m" in args:
+        args = [a for a in args if a != "--combined"]      # (undefined in the reference with several samples)
+    a = [bed if x == "BED" else x for x in args]
+    want = run_cli([a[0]] + a[1:] + [bam])
+    got = run_sharded([a[0], bam] + a[1:], world, 29700 + world)
+    assert got == want
