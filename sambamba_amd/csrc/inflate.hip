@@ -12,27 +12,30 @@
 //      mapping is ONE LANE PER BGZF BLOCK: 64 independent decoders per wavefront, every VALU
 //      instruction doing useful work in all lanes.  No lookup tables in memory for the code
 //      lengths: the 15 left-justified limits of the literal/length and the distance code live in
-//      VGPRs (two 16-bit limits per register) and the code length is 1 + sum_l (peek >= limit[l]),
-//      the symbol-index delta sum_l mask_l * ddelta_l -- packed 16-bit VALU ops, branch-free and
-//      identical for every lane.  The per-lane symbol permutations (288 + 32 entries) sit in LDS
-//      at a 105-dword lane stride (odd => conflict-free for equal offsets), next to a 32-byte ring of
-//      the lane's compressed input that the whole wave tops up in synchronous events, so that the
-//      decode loops never wait on a global load.  The decoder does NOT
-//      touch the LZ77 window: it emits the literal bytes (packed 4 per store) and one 32-bit
+//      VGPRs (two 16-bit limits per register) next to per-length deltas, and ONE accumulator of
+//      v_dot2_u32_u16 products yields both the code length (1 + sum_l (peek >= limit[l])) and the
+//      symbol-index delta -- 3 VALU ops per pair of lengths, branch-free, identical in every lane.
+//      Only the literal/length symbol permutation (288 B + a 36-byte "symbol >= 256" bitmap) and a
+//      32-byte ring of the lane's compressed input are in LDS: 356 B per lane at an 89-dword stride
+//      (odd => conflict-free for equal offsets), 7 waves per CU; distance symbols and the table-build
+//      counters are packed into VGPRs.  The ring is topped up by the whole wave in synchronous events,
+//      so that the decode loop never waits on a global load.  The decoder does NOT touch the LZ77
+//      window: it emits the literal bytes (16-byte stores out of a byte shift register) and one 32-bit
 //      entry {literals-before:8, distance-1:15, length:9} per match.  Nothing it loads depends on
 //      anything it stored, so the lane never waits on the LZ77 window's memory latency.
 //
 //  K1b `lz77_resolve`    -- copying matches is data-parallel once positions are known, so the
-//      mapping is ONE WAVE PER BGZF BLOCK: 64 entries at a time, output offsets by a wave prefix
-//      sum, literals and match bytes copied by 8 lanes per entry (coalesced within an entry),
-//      periodic extension (src + k mod dist) removes the intra-match dependency, and matches whose
-//      source overlaps a still-pending match of the same batch wait for the next round (bitmask
-//      test; the first pending entry is always ready).  No LDS window: the sliding window is the
-//      wave's own earlier output in HBM/L2, and 32 waves per CU hide its latency.
+//      mapping is ONE WAVE PER BGZF BLOCK: 64 entries at a time, output offsets by a DPP prefix sum.
+//      The wave keeps the last 2-3.5 KiB of its output in a linear LDS window: NEAR matches -- the
+//      record -> previous record -> ... chain that makes a BAM stream serial -- are resolved LDS -> LDS
+//      in rounds (a match may start once everything below its source end is final, i.e. lies below
+//      the start of the first unfinished match; self-overlapping matches are extended periodically),
+//      FAR matches and literal runs come from global memory with every load of the batch in flight
+//      before the first store, and the finished span is written to HBM once, contiguously.
 //
-// Roofline: K1a is bound by the serial decode chain (VALU + LDS latency), K1b by memory latency of
-// scattered short copies; neither is HBM-bandwidth bound and their GB/s are reported separately
-// from the HBM-bound accumulate kernel.
+// Roofline: K1a is bound by the instruction issue of the serial decode chain, K1b by VALU issue;
+// neither is HBM-bandwidth bound and their GB/s are reported separately from the HBM-bound
+// accumulate kernel.
 #include "common.hpp"
 #include "kernels.hpp"
 
