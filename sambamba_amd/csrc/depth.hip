@@ -12,14 +12,14 @@
 //     cnt[pos][sample][5]   += 1  for every position inside a D operation,
 //     cnt[pos][sample][6]   += 1  for every position inside an N operation,
 // so the GPU formulation is a scatter of read bases into position tiles:
-//   * one workgroup owns one tile of T reference positions; its counters live in LDS
-//     (T x n_samples x 7 u32, 56 KiB => 2 workgroups per CU) and are written to HBM exactly
+//   * one workgroup owns one tile of T = 1024 / n_samples reference positions; its counters live in
+//     LDS (T x n_samples x 7 u32 = 28.7 KB => 5 workgroups per CU) and are written to HBM exactly
 //     once with coalesced stores -- no global atomics, no zero-fill pass over HBM;
 //   * the records of a tile are a contiguous range [lo,hi) of the descriptor array (K2);
-//     each wavefront pulls 64 descriptors with one coalesced load, ballots the ones that
-//     overlap the tile, and spreads the bases of each such read across its 64 lanes
-//     (consecutive lanes -> consecutive quality bytes and consecutive LDS counters at a
-//     7-dword stride, which is conflict-free across 32 banks);
+//     each wavefront pulls 64 descriptors with one coalesced load and ballots the ones that
+//     overlap the tile; reads with a single run of aligned bases go three per pass (21 lanes x 8
+//     bases each: one 8-byte quality load, one 8-byte packed-sequence load, 8 LDS atomics per
+//     lane), general CIGARs are walked one read at a time across the 64 lanes;
 //   * reads straddling a tile edge are visited by both tiles and clipped.
 // Roofline: HBM.  Algorithmic bytes per read = record bytes + 28 B per covered position
 // per sample written once.
