@@ -130,7 +130,8 @@ const char* sbx_header_text(sbx_ctx*, size_t* len);
 
 /* createFilterFromQuery (filtering.d:40-51).  query == NULL compiles the default
  * "mapping_quality > 0 and not duplicate and not failed_quality_control" (depth.d:1159).
- * Returns SBX_EUNSUPPORTED for string / tag / regex conditions. */
+ * Integer tag comparisons ([NM] <= 2) and tag existence ([XS] == null) compile; string and regex
+ * conditions return SBX_EUNSUPPORTED. */
 int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t errlen);
 int sbx_set_filter(sbx_ctx*, const sbx_filter* f);
 
