@@ -111,8 +111,13 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
 
 /* ---- engine seam ------------------------------------------------------------ */
 
-/* new MultiBamReader(filenames) (multireader.d:244) + BamReader header parse
- * (reader.d:101-125).  n_bams must be 1 in this version (multi-BAM merge is SURVEY 8(f)-2).
+/* new MultiBamReader(filenames) (multireader.d:244) + BamReader header parse (reader.d:101-125).
+ * Several BAMs are processed as the reference's merged stream would be: the pileup of the merge is the union
+ * of the files' reads, so every file goes through the device pipeline on its own and the per-position results
+ * are added up; samples are the union of the @RG SM values in order of first appearance (depth.d:1170-1181 over
+ * the merged header) and every file keeps its own RG-id -> sample table.  The files must have identical
+ * reference dictionaries (SBX_EUNSUPPORTED otherwise; the reference also merges compatible, non-identical
+ * ones).  With -m, mates are paired within a file only.
  * device = HIP device ordinal (or -1: use LOCAL_RANK / 0). */
 sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* err, size_t errlen);
 void sbx_close(sbx_ctx*);

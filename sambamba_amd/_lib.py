@@ -156,13 +156,14 @@ def compile_filter(query):
 
 
 class Depth:
-    """Thin object wrapper over an sbx_ctx (one BAM, one device)."""
+    """Thin object wrapper over an sbx_ctx (one BAM or a list of BAMs, one device)."""
 
     def __init__(self, bam_path, device=-1):
         self._L = lib()
-        arr = (C.c_char_p * 1)(bam_path.encode())
+        paths = [bam_path] if isinstance(bam_path, str) else list(bam_path)
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         err = C.create_string_buffer(1024)
-        self._ctx = self._L.sbx_open(arr, 1, device, err, 1024)
+        self._ctx = self._L.sbx_open(arr, len(paths), device, err, 1024)
         if not self._ctx:
             raise SbxError(-1, err.value.decode())
         hi = HeaderInfo()

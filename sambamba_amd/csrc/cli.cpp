@@ -222,7 +222,22 @@ public:
         }
         for (int r = r0; r < r1; ++r) {
             const uint64_t len = (uint64_t)sbx_ref_length(c_, r);
-            if (o_.min_cov == 0) range((uint32_t)r, 0, len);      // every position of the contig has rows
+            if (o_.min_cov == 0) {
+                // Every position of a contig with pileup columns has rows.  A contig WITHOUT columns is zero-filled
+                // only before the first and after the last contig that has some: push() fills from the previous
+                // column's contig straight to the current one and skips what lies between (depth.d:574-583), close()
+                // fills everything after the last column (depth.d:593-606).
+                uint64_t b0 = 0, e0 = 0;
+                check(c_, sbx_next_active_range(c_, (uint32_t)r, 0, &b0, &e0));
+                if (b0 == ~0ULL) {
+                    if (!seen_columns_) range((uint32_t)r, 0, len);
+                    else pending_empty_.push_back(r);
+                    continue;
+                }
+                seen_columns_ = true;
+                pending_empty_.clear();
+                range((uint32_t)r, 0, len);
+            }
             uint64_t from = o_.min_cov == 0 ? len : 0;
             for (;;) {       // otherwise only stretches with admitted reads can have rows
                 uint64_t b, e;
@@ -233,6 +248,25 @@ public:
                 else range((uint32_t)r, b, e);
                 from = e;
             }
+        }
+    }
+    void run_device_empty(int r) {
+        std::vector<char> text;
+        const uint64_t len = (uint64_t)sbx_ref_length(c_, r), CH = 8u << 20;
+        for (uint64_t p = 0; p < len; p += CH) {
+            const uint64_t q = std::min(len, p + CH);
+            size_t need = 0;
+            text.resize((size_t)(q - p) * 40 * S_ + 64);
+            int rc = sbx_format_base_rows(c_, (uint32_t)r, (uint32_t)p, (uint32_t)q, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
+                                          text.data(), text.size(), &need);
+            if (rc == SBX_ENOMEM && need > text.size()) {
+                text.resize(need);
+                rc = sbx_format_base_rows(c_, (uint32_t)r, (uint32_t)p, (uint32_t)q, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
+                                          text.data(), text.size(), &need);
+            }
+            check(c_, rc);
+            out_.flush();
+            fwrite(text.data(), 1, need, out_.fp);
         }
     }
     void host_columns(int r, uint64_t b, uint64_t e) {
@@ -268,7 +302,9 @@ public:
         }
     }
     void finish() {
-        if (!device_format_applies()) close();
+        if (!device_format_applies()) { close(); return; }
+        if (o_.min_cov == 0 && !bed_provided_)       // contigs without columns after the last one that had some
+            for (int r : pending_empty_) run_device_empty(r);
     }
 
 private:
@@ -286,6 +322,8 @@ private:
     int prev_ref_ = -2;
     int64_t prev_pos_ = 0;
     std::vector<std::string> tails_;
+    bool seen_columns_ = false;            // device-formatted -c 0 output: has any contig so far had a pileup column?
+    std::vector<int> pending_empty_;       // ... contigs without columns seen since the last one that had some
 
     static bool fully_left_of(const sbx_region& g, uint32_t ref, uint32_t pos) { return g.ref_id < ref || (g.ref_id == ref && g.end <= pos); }
     static bool overlaps(const sbx_region& g, uint32_t ref, uint32_t pos) { return g.ref_id == ref && g.start <= pos && pos < g.end; }

@@ -39,6 +39,9 @@ using namespace sbx;
 
 struct sbx_ctx {
     std::string last_error;
+    // several BAMs (MultiBamReader, multireader.d:244): this context is the first file and owns the merged view;
+    // every further file is a complete single-file context of its own
+    std::vector<sbx_ctx*> members;
     int device = 0;
     hipStream_t stream = nullptr;
     FileMap file;
@@ -62,6 +65,7 @@ struct sbx_ctx {
     DevBuf<uint64_t> d_comp_off, d_out_off;
     DevBuf<uint32_t> d_comp_len, d_isize, d_status;
     DevBuf<uint8_t> d_U, d_scratch, d_lit;
+    uint64_t primary_records = 0;   // records of THIS file in the last run (stats.n_records is the sum over files after a merge)
     uint64_t u_base = 0;      // stream offset held at d_U.p[0]: d_U covers the BGZF block range of the current run only
     const uint8_t* U() const { return d_U.p - u_base; }     // address of stream offset 0 (only offsets >= u_base are backed)
     DevBuf<uint32_t> d_ent, d_nent;
@@ -95,6 +99,13 @@ struct sbx_ctx {
 };
 
 namespace {
+
+// the files of a (possibly multi-BAM) context, the primary first
+std::vector<sbx_ctx*> files_of(sbx_ctx* c) {
+    std::vector<sbx_ctx*> v{c};
+    v.insert(v.end(), c->members.begin(), c->members.end());
+    return v;
+}
 
 template <class F>
 int guarded(sbx_ctx* c, F&& f) {
@@ -248,8 +259,7 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
 sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* err, size_t errlen) {
     std::unique_ptr<sbx_ctx> c(new sbx_ctx());
     try {
-        if (n_bams != 1 || !bam_paths || !bam_paths[0])
-            throw Error(SBX_EUNSUPPORTED, "exactly one BAM file is supported in this version (multi-BAM merge: SURVEY 8f-2)");
+        if (n_bams < 1 || !bam_paths || !bam_paths[0]) throw Error(SBX_EINVAL, "no input files");
         require_device(device);
         SBX_HIP(hipGetDevice(&c->device));
         SBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -258,9 +268,42 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
         c->has_index = load_bai(c->file.path, &c->bai);
         default_filter(&c->filter);
         parse_header_on_device(c.get());
+        // further files: MultiBamReader semantics that matter for depth -- identical reference dictionaries
+        // (the reference merges compatible ones, multireader.d:174-215; anything else is rejected here), samples =
+        // union of the @RG SM values in order of first appearance (depth.d:1170-1181 over the merged header), every
+        // file keeps its own RG-id -> sample table (so colliding RG ids need no renaming)
+        for (int i = 1; i < n_bams; ++i) {
+            if (!bam_paths[i]) throw Error(SBX_EINVAL, "null path");
+            const char* one[1] = {bam_paths[i]};
+            char e2[512] = {0};
+            sbx_ctx* m = sbx_open(one, 1, c->device, e2, sizeof e2);
+            if (!m) throw Error(SBX_EIO, e2);
+            c->members.push_back(m);
+            if (m->hdr.refs.size() != c->hdr.refs.size()) throw Error(SBX_EUNSUPPORTED, "the BAM files have different reference dictionaries");
+            for (size_t r = 0; r < m->hdr.refs.size(); ++r)
+                if (m->hdr.refs[r].name != c->hdr.refs[r].name || m->hdr.refs[r].length != c->hdr.refs[r].length)
+                    throw Error(SBX_EUNSUPPORTED, "the BAM files have different reference dictionaries");
+            if (m->hdr.sorting_order != "coordinate") c->hdr.sorting_order = m->hdr.sorting_order;
+            if (!m->has_index) c->has_index = false;
+        }
+        if (!c->members.empty()) {
+            std::vector<std::string> names;
+            auto id_of = [&](const std::string& sm) -> uint16_t {
+                for (size_t k = 0; k < names.size(); ++k) if (names[k] == sm) return (uint16_t)k;
+                names.push_back(sm);
+                return (uint16_t)(names.size() - 1);
+            };
+            for (sbx_ctx* f : files_of(c.get())) {
+                f->hdr.rg_sample.clear();
+                for (auto& g : f->hdr.read_groups) f->hdr.rg_sample.push_back(id_of(g.sample));
+            }
+            if (names.empty()) names.push_back("*");
+            for (sbx_ctx* f : files_of(c.get())) f->hdr.sample_names = names;
+        }
         return c.release();
     } catch (const std::exception& e) {
         set_err(err, errlen, e.what());
+        if (c) for (sbx_ctx* m : c->members) sbx_close(m);
         if (c && c->stream) (void)hipStreamDestroy(c->stream);
         return nullptr;
     }
@@ -268,6 +311,7 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
 
 void sbx_close(sbx_ctx* c) {
     if (!c) return;
+    for (sbx_ctx* m : c->members) sbx_close(m);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
 }
@@ -312,8 +356,7 @@ int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t err
 
 int sbx_set_filter(sbx_ctx* c, const sbx_filter* f) {
     if (!c || !f || f->n_ops < 0 || f->n_ops > SBX_FILTER_MAX_OPS) return SBX_EINVAL;
-    c->filter = *f;
-    c->have_run = false;
+    for (sbx_ctx* m : files_of(c)) { m->filter = *f; m->have_run = false; }
     return SBX_OK;
 }
 
@@ -326,14 +369,16 @@ int sbx_set_params(sbx_ctx* c, int mode, uint8_t min_bq, int fix_mate, int combi
             if (window == 0) throw Error(SBX_EINVAL, "positive window size must be specified");        // depth.d:1020-1021
             if (overlap >= window) throw Error(SBX_EINVAL, "specified overlap is larger than window size");  // depth.d:1023-1024
         }
-        c->mode = mode;
-        c->min_bq = min_bq;
-        c->fix_mate = fix_mate != 0;
-        c->combined = combined != 0;
-        c->window = window;
-        c->overlap = overlap;
-        c->thresholds.assign(thr, thr + (n_thr > 0 ? n_thr : 0));
-        c->have_run = false;
+        for (sbx_ctx* m : files_of(c)) {
+            m->mode = mode;
+            m->min_bq = min_bq;
+            m->fix_mate = fix_mate != 0;
+            m->combined = combined != 0;
+            m->window = window;
+            m->overlap = overlap;
+            m->thresholds.assign(thr, thr + (n_thr > 0 ? n_thr : 0));
+            m->have_run = false;
+        }
     });
 }
 
@@ -344,8 +389,7 @@ int sbx_set_regions(sbx_ctx* c, const sbx_region* r, size_t n) {
             if (r[i].ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
             if (!(r[i].start < r[i].end)) throw Error(SBX_EINVAL, "Enforcement failed");   // randomaccessmanager.d:256
         }
-        c->regions.assign(r, r + n);
-        c->have_run = false;
+        for (sbx_ctx* m : files_of(c)) { m->regions.assign(r, r + n); m->have_run = false; }
     });
 }
 
@@ -353,9 +397,11 @@ int sbx_preload(sbx_ctx* c) {
     return guarded(c, [&] {
         if (!c) throw Error(SBX_EINVAL, "null context");
         SBX_HIP(hipSetDevice(c->device));
-        upload_tables(c);
-        upload_file(c);
-        SBX_HIP(hipStreamSynchronize(c->stream));
+        for (sbx_ctx* m : files_of(c)) {
+            upload_tables(m);
+            upload_file(m);
+            SBX_HIP(hipStreamSynchronize(m->stream));
+        }
     });
 }
 
@@ -683,10 +729,76 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     }
 }
 
+// Several BAMs: every file has been through the pipeline on its own; the per-position results are sums over the
+// files (the pileup of the merged stream is the union of the reads), so the primary's tile set becomes the union
+// of the files' tile sets with the counters added up.  Per-read work that needs a file's records (read counts of
+// regions / windows) is done file by file at query time.
+static void merge_members(sbx_ctx* c) {
+    if (c->members.empty()) return;
+    SBX_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const auto files = files_of(c);
+    const uint32_t T = c->tile_pos, S = c->n_samples_eff;
+    const size_t nt = c->h_slot_of.size();
+    for (sbx_ctx* m : files)
+        if (m->tile_pos != T || m->n_samples_eff != S || m->h_slot_of.size() != nt) throw Error(SBX_EINVAL, "internal: tile grids differ");
+    std::vector<uint32_t> slot(nt, 0xFFFFFFFFu);
+    uint32_t n_active = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        bool on = false;
+        for (sbx_ctx* m : files) on |= m->h_slot_of[t] != 0xFFFFFFFFu;
+        if (on) slot[t] = n_active++;
+    }
+    const size_t per_tile = (size_t)T * S * SBX_NCOUNTERS;
+    const bool region_m = c->fix_mate && c->mode != SBX_MODE_BASE;
+    DevBuf<uint32_t> d_slot(nt + 1), cnt((size_t)n_active * per_tile + 4), spn, covm, addm;
+    if (nt) SBX_HIP(hipMemcpyAsync(d_slot.p, slot.data(), nt * 4, hipMemcpyHostToDevice, s));
+    SBX_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes(), s));
+    if (c->span_valid) { spn.alloc((size_t)n_active * T + 4); SBX_HIP(hipMemsetAsync(spn.p, 0, spn.bytes(), s)); }
+    if (region_m) {
+        covm.alloc((size_t)n_active * T * S + 1); addm.alloc((size_t)n_active * T * S + 1);
+        SBX_HIP(hipMemsetAsync(covm.p, 0, covm.bytes(), s));
+        SBX_HIP(hipMemsetAsync(addm.p, 0, addm.bytes(), s));
+    }
+    sbx_run_stats sum{};
+    for (sbx_ctx* m : files) {
+        SBX_HIP(hipStreamSynchronize(m->stream));
+        launch_merge_tiles(m->d_counters.p, m->d_active.p, m->n_active, d_slot.p, (uint32_t)per_tile, cnt.p, s);
+        if (c->span_valid) launch_merge_tiles(m->d_span.p, m->d_active.p, m->n_active, d_slot.p, T, spn.p, s);
+        if (region_m) {
+            launch_merge_tiles(m->d_covm.p, m->d_active.p, m->n_active, d_slot.p, T * S, covm.p, s);
+            launch_merge_tiles(m->d_addm.p, m->d_active.p, m->n_active, d_slot.p, T * S, addm.p, s);
+        }
+        const sbx_run_stats& a = m->stats;
+        sum.ms_inflate += a.ms_inflate; sum.ms_index += a.ms_index; sum.ms_accumulate += a.ms_accumulate; sum.ms_total += a.ms_total;
+        sum.ms_h2d += a.ms_h2d; sum.ms_huffman += a.ms_huffman; sum.ms_lz77 += a.ms_lz77;
+        sum.n_records += a.n_records; sum.n_admitted += a.n_admitted; sum.n_bgzf_blocks += a.n_bgzf_blocks;
+        sum.compressed_bytes += a.compressed_bytes; sum.uncompressed_bytes += a.uncompressed_bytes;
+        sum.launches_inflate += a.launches_inflate; sum.launches_index += a.launches_index; sum.launches_accumulate += a.launches_accumulate;
+    }
+    SBX_HIP(hipStreamSynchronize(s));
+    // the primary now answers for the merged tile set (its own per-file results were folded in above)
+    c->primary_records = c->stats.n_records;
+    std::swap(c->d_counters, cnt);
+    if (c->span_valid) std::swap(c->d_span, spn);
+    if (region_m) { std::swap(c->d_covm, covm); std::swap(c->d_addm, addm); }
+    std::swap(c->d_slot_of, d_slot);
+    c->h_slot_of = slot;
+    c->n_active = n_active;
+    sum.counter_bytes = (uint64_t)n_active * per_tile * 4;
+    sum.covered_positions = (uint64_t)n_active * T;
+    c->stats = sum;
+}
+
+static void run_files(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
+    for (sbx_ctx* m : files_of(c)) run_impl(m, sel, restricted);
+    merge_members(c);
+}
+
 int sbx_run(sbx_ctx* c) {
     return guarded(c, [&] {
         if (!c) throw Error(SBX_EINVAL, "null context");
-        run_impl(c, c->regions, !c->regions.empty());
+        run_files(c, c->regions, !c->regions.empty());
     });
 }
 
@@ -736,11 +848,11 @@ int sbx_plan_batches(sbx_ctx* c, uint64_t budget_bytes, sbx_batch* out, size_t c
         uint64_t pos = 0;
         for (uint32_t r = 0; r < n_ref; ++r) {
             uint32_t b0, b1;
-            contig_blocks(c, r, &b0, &b1);
+            contig_blocks(c, r, &b0, &b1);       // (several BAMs: sized by the first file times the number of files)
             const uint64_t len = (uint64_t)std::max(0, c->hdr.refs[r].length);
             uint32_t nlo = lo, nhi = hi;
             if (b1 > b0) { nlo = hi > lo ? std::min(lo, b0) : b0; nhi = hi > lo ? std::max(hi, b1) : b1; }
-            if (r > first && footprint(c, nlo, nhi, pos + len) > budget_bytes) {
+            if (r > first && footprint(c, nlo, nhi, pos + len) * (1 + c->members.size()) > budget_bytes) {
                 plan.push_back({first, r - first, footprint(c, lo, hi, pos)});
                 first = r; pos = 0;
                 nlo = b0; nhi = b1;
@@ -765,7 +877,7 @@ int sbx_run_batch(sbx_ctx* c, uint32_t first_ref, uint32_t n_refs) {
             for (auto& g : c->regions)
                 if (g.ref_id >= first_ref && g.ref_id < first_ref + n_refs) sel.push_back(g);
         }
-        run_impl(c, sel, true);
+        run_files(c, sel, true);
     });
 }
 
@@ -848,7 +960,9 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
     SBX_HIP(hipMemsetAsync(d_seen.p, 0, d_seen.bytes(), s));
     EventTimer t;
     t.start(s);
-    const uint64_t n_records = c->stats.n_records;
+    // per-read work goes file by file (records of every BAM stay resident after the run)
+    const auto files = files_of(c);
+    auto records_of = [&](sbx_ctx* f) -> uint64_t { return (f == c && !c->members.empty()) ? c->primary_records : f->stats.n_records; };
     if (c->fix_mate && c->mode != SBX_MODE_BASE) {
         // ---- --fix-mate-overlaps: closed form of depth.d:717-845 (reduce.hip) -------------------------------------
         const size_t n_ref = c->hdr.refs.size();
@@ -895,8 +1009,9 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
         if (!un.empty()) SBX_HIP(hipMemcpyAsync(d_un.p, un.data(), un.size() * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(d_first2.p, first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(d_unfirst.p, un_first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
-        launch_count_reads_mates(c->U(), c->d_desc.p, n_records, c->d_rec_ref.p, c->d_mate.p, d_regs2.p, d_pmax2.p, d_first2.p, d_un.p,
-                                 d_unfirst.p, windows, d_firstcol.p, S, c->min_bq, d_nb.p, d_nr.p, s);
+        for (sbx_ctx* f : files)
+            launch_count_reads_mates(f->U(), f->d_desc.p, records_of(f), f->d_rec_ref.p, f->d_mate.p, d_regs2.p, d_pmax2.p, d_first2.p,
+                                     d_un.p, d_unfirst.p, windows, d_firstcol.p, S, c->min_bq, d_nb.p, d_nr.p, s);
         SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
     } else {
     launch_range_reduce(d_chunks.p, (uint32_t)chunks.size(), c->d_counters.p, c->span_valid ? c->d_span.p : nullptr, c->d_slot_of.p,
@@ -909,7 +1024,8 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
         d_nw.alloc(n_win.size() + 1);
         SBX_HIP(hipMemcpyAsync(d_wb.p, win_base.data(), win_base.size() * 8, hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(d_nw.p, n_win.data(), n_win.size() * 8, hipMemcpyHostToDevice, s));
-        launch_count_reads_windows(c->U(), c->d_desc.p, n_records, c->d_rec_ref.p, window, d_wb.p, d_nw.p, S, c->min_bq, d_nr.p, s);
+        for (sbx_ctx* f : files)
+            launch_count_reads_windows(f->U(), f->d_desc.p, records_of(f), f->d_rec_ref.p, window, d_wb.p, d_nw.p, S, c->min_bq, d_nr.p, s);
     } else {
         // (ref, start)-sorted view + prefix max of ends per contig
         const size_t n_ref = c->hdr.refs.size();
@@ -941,8 +1057,9 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
             SBX_HIP(hipMemcpyAsync(d_pmax.p, pmax.data(), n * 4, hipMemcpyHostToDevice, s));
         }
         SBX_HIP(hipMemcpyAsync(d_first.p, first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
-        launch_count_reads_regions(c->U(), c->d_desc.p, n_records, c->d_rec_ref.p, d_regs.p, d_pmax.p, d_first.p, S, c->min_bq,
-                                   d_nr.p, s);
+        for (sbx_ctx* f : files)
+            launch_count_reads_regions(f->U(), f->d_desc.p, records_of(f), f->d_rec_ref.p, d_regs.p, d_pmax.p, d_first.p, S, c->min_bq,
+                                       d_nr.p, s);
         SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
     }
     }

@@ -160,6 +160,10 @@ void launch_count_reads_mates(const uint8_t* d_U, const RecDesc* d_desc, uint64_
                               const SortedRegion* d_union, const uint32_t* d_union_first, bool everywhere, const uint32_t* d_first,
                               uint32_t S, uint32_t min_bq, uint32_t* d_n_bases, uint32_t* d_n_reads, hipStream_t stream);
 
+// multi-BAM: add the tile slots of one file's run into the merged tile set
+void launch_merge_tiles(const uint32_t* d_src, const uint32_t* d_src_active, uint32_t n_src_active, const uint32_t* d_dst_slot_of,
+                        uint32_t per_tile, uint32_t* d_dst, hipStream_t stream);
+
 // K6 format_base_rows (format.hip): text of `depth base` for positions [beg, end) of one contig
 struct FormatArgs {
     const uint32_t* counters;     // per active tile u32[T][S][7]

@@ -168,8 +168,8 @@ __global__ __launch_bounds__(kRedThreads) void k_count_reads_regions(
 }
 
 // ---- region / window statistics with --fix-mate-overlaps -------------------------------------------------------
-// Closed form of PerRegionPrinter.push with mate fixing (depth.d:717-845), derived from the literal restatement in
-// oracle/ and checked against it (tests/test_gpu_mates.py).  For a region R, with F = the first pileup column inside
+// Closed form of PerRegionPrinter.push with mate fixing (depth.d:717-845), derived from a literal restatement of
+// the reference's status machine and checked against it (tests/test_gpu_mates.py).  For a region R, with F = the first pileup column inside
 // R, a pair's overlap O = [oa, ob) and f = the first column of O that lies inside ANY region (there the pair is
 // "fixed", depth.d:751-758):
 //   n_bases[R] = sum over reads counted for R of B(r, R)                      (countRead, depth.d:661-669)
@@ -381,6 +381,26 @@ void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint6
     if (!n_records) return;
     hipLaunchKernelGGL(k_count_reads_regions, dim3((uint32_t)((n_records + kRedThreads - 1) / kRedThreads)), dim3(kRedThreads), 0,
                        stream, d_U, d_desc, n_records, d_rec_ref, d_regs, d_pmax_end, d_ref_first, S, min_bq, d_n_reads);
+    SBX_HIP(hipGetLastError());
+}
+
+// dst[dst_slot_of[tile of src slot k]] += src[k] for every tile slot of another BAM's run (multi-BAM merge)
+namespace {
+__global__ __launch_bounds__(kRedThreads) void k_merge_tiles(const uint32_t* __restrict__ src, const uint32_t* __restrict__ src_active,
+                                                             const uint32_t* __restrict__ dst_slot_of, uint32_t per_tile,
+                                                             uint32_t* __restrict__ dst) {
+    const uint32_t tile = src_active[blockIdx.x];
+    const uint32_t ds = dst_slot_of[tile];
+    const uint32_t* a = src + (size_t)blockIdx.x * per_tile;
+    uint32_t* b = dst + (size_t)ds * per_tile;
+    for (uint32_t i = threadIdx.x; i < per_tile; i += kRedThreads) b[i] += a[i];
+}
+}  // namespace
+
+void launch_merge_tiles(const uint32_t* d_src, const uint32_t* d_src_active, uint32_t n_src_active, const uint32_t* d_dst_slot_of,
+                        uint32_t per_tile, uint32_t* d_dst, hipStream_t stream) {
+    if (!n_src_active) return;
+    hipLaunchKernelGGL(k_merge_tiles, dim3(n_src_active), dim3(kRedThreads), 0, stream, d_src, d_src_active, d_dst_slot_of, per_tile, d_dst);
     SBX_HIP(hipGetLastError());
 }
 

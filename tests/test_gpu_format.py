@@ -105,3 +105,20 @@ def test_api_small_buffer_reports_required_size(synth_ms):
         rc = d._L.sbx_format_base_rows(d._ctx, 0, 0, 5000, 1.0, 1e300, 0, buf, 16, C.byref(need))
         assert rc == _lib.ENOMEM and need.value > 16
         assert len(d.format_base_rows(0, 0, 5000)) == need.value
+
+
+def test_zero_fill_skips_contigs_between_columns(tmp_path):
+    """-c 0: a contig without reads is zero-filled before the first / after the last contig that has columns,
+    but skipped when it lies between two that have (PerBasePrinter.push jumps straight to the new contig,
+    depth.d:574-583)."""
+    from tests import bamgen as bg
+    refs = [("e0", 30), ("a", 400), ("e1", 25), ("e2", 7), ("b", 300), ("e3", 12), ("e4", 3)]
+    recs = [bg.make_record(1, 50, "40M", "ACGT" * 10, 30, name="x"), bg.make_record(4, 10, "20M2D20M", "ACGT" * 10, 30, name="y")]
+    p = str(tmp_path / "gaps.bam")
+    bg.write_bam(p, refs, recs)
+    for args in (["base", "-c", "0"], ["base", "-c", "0", "-a"], ["base"]):
+        dev = run_cli(args + [p])
+        assert dev == run_oracle(args + [p])
+        assert dev == run_cli_host_format(args + [p], cwd=None)
+    out = run_cli(["base", "-c", "0", p]).decode()
+    assert "e0\t0\t" in out and "e3\t0\t" in out and "e4\t2\t" in out and "e1\t" not in out and "e2\t" not in out
