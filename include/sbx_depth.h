@@ -80,12 +80,18 @@ typedef struct {
 
 /* The compiled subset of the -F filter language (sambamba/utils/common/filtering.d:86-214,
  * queryparser.d:232-483): a postfix program over flag tests, integer-field comparisons,
- * integer-tag comparisons ([NM] <= 2), tag existence ([XS] == null) and and / or / not.
+ * integer-tag comparisons ([NM] <= 2), tag existence ([XS] == null), string comparisons of tags and of
+ * read_name / ref_name / mate_ref_name / strand ([RG] == 'lane1', ref_name != 'chrM') and and / or / not.
  * Built by sbx_compile_filter() from the query string. */
 #define SBX_FILTER_MAX_OPS 64
+#define SBX_FILTER_STRINGS 512
 typedef struct {
     uint8_t  kind;     /* 0 FLAG_ANY(mask)  1 CHIMERIC  2 INTCMP  3 AND  4 OR  5 NOT  6 TRUE
-                          7 TAGCMP (mask = key chars c0 | c1 << 8; cmp; value)  8 TAGNULL (cmp 4: absent, 5: present) */
+                          7 TAGCMP (mask = key chars c0 | c1 << 8; cmp; value)  8 TAGNULL (cmp 4: absent, 5: present)
+                          9 TAGSTR (mask = key; cmp; value = string)  10 NAMESTR (read_name; cmp; value = string)
+                          11 REFNAME (field 0 ref_name, 1 mate_ref_name; cmp 4 / 5; value = string; resolved against
+                             the header when the filter is installed)  12 FALSE
+                          strings: value = offset into sbx_filter.strings | length << 32 */
     uint8_t  field;    /* INTCMP: 0 ref_id 1 position 2 mapping_quality 3 sequence_length
                                   4 mate_ref_id 5 mate_position 6 template_length            */
     uint8_t  cmp;      /* INTCMP: 0 >  1 <  2 >=  3 <=  4 ==  5 !=                           */
@@ -97,6 +103,7 @@ typedef struct {
     int32_t n_ops;
     int32_t reserved;
     sbx_filter_op ops[SBX_FILTER_MAX_OPS];
+    char strings[SBX_FILTER_STRINGS];
 } sbx_filter;
 
 /* ---- codec seam -------------------------------------------------------------
@@ -135,8 +142,8 @@ const char* sbx_header_text(sbx_ctx*, size_t* len);
 
 /* createFilterFromQuery (filtering.d:40-51).  query == NULL compiles the default
  * "mapping_quality > 0 and not duplicate and not failed_quality_control" (depth.d:1159).
- * Integer tag comparisons ([NM] <= 2) and tag existence ([XS] == null) compile; string and regex
- * conditions return SBX_EUNSUPPORTED. */
+ * Everything but regular expressions (=~), avg_base_quality and the sequence / cigar string fields compiles;
+ * those return SBX_EUNSUPPORTED. */
 int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t errlen);
 int sbx_set_filter(sbx_ctx*, const sbx_filter* f);
 

@@ -166,8 +166,25 @@ static inline char find_tag(const Rec& r, char c0, char c1, const uint8_t** val)
     return 0;
 }
 
+// reference names of the open BAM, for ref_name / mate_ref_name conditions ("*" for id -1, read.d ref_name)
+static const std::vector<std::string>* g_filter_ref_names = nullptr;
+
+static inline bool cmp_int(int op, long x, long y) {
+    switch (op) {
+        case 0: return x > y;
+        case 1: return x < y;
+        case 2: return x >= y;
+        case 3: return x <= y;
+        case 4: return x == y;
+        default: return x != y;
+    }
+}
+static inline bool cmp_strs(int op, const std::string& a, const std::string& b) { return cmp_int(op, a.compare(b) < 0 ? -1 : a.compare(b) > 0 ? 1 : 0, 0); }
+
 struct FilterNode {
-    enum Kind { FLAG, CHIMERIC, INTCMP, AND, OR, NOT, TRUE_, TAGCMP, TAGNULL } kind = TRUE_;
+    enum Kind { FLAG, CHIMERIC, INTCMP, AND, OR, NOT, TRUE_, TAGCMP, TAGNULL, TAGSTR, FIELDSTR } kind = TRUE_;
+    std::string text;       // TAGSTR / FIELDSTR: the literal
+    int sfield = 0;         // FIELDSTR: 0 read_name 1 ref_name 2 mate_ref_name 3 strand
     char key[2] = {0, 0};   // TAGCMP / TAGNULL: the aux key
     uint32_t mask = 0;
     int field = 0;  // 0 ref_id 1 position 2 mapping_quality 3 sequence_length 4 mate_ref_id 5 mate_position 6 template_length
@@ -198,6 +215,33 @@ struct FilterNode {
                     case 3: return v <= value;
                     case 4: return v == value;
                     default: return v != value;
+                }
+            }
+            case TAGSTR: {    // StringTagFilter (filtering.d:276-297)
+                const uint8_t* v = nullptr;
+                char ty = find_tag(r, key[0], key[1], &v);
+                if (ty == 'Z') {
+                    const uint8_t* e = v;
+                    while (e < r.end() && *e) ++e;
+                    return cmp_strs(op, std::string((const char*)v, (size_t)(e - v)), text);
+                }
+                if (ty == 'A') return text.size() == 1 && cmp_int(op, (long)v[0], (long)(uint8_t)text[0]);
+                return false;
+            }
+            case FIELDSTR: {  // StringFieldFilter (filtering.d:255-273)
+                auto ref_name = [&](int id) -> std::string {
+                    if (id < 0 || !g_filter_ref_names || (size_t)id >= g_filter_ref_names->size()) return "*";
+                    return (*g_filter_ref_names)[(size_t)id];
+                };
+                switch (sfield) {
+                    case 0: return cmp_strs(op, std::string((const char*)r.name(), (size_t)r.name_len()), text);
+                    case 1: return cmp_strs(op, ref_name(r.ref_id()), text);
+                    case 2: return cmp_strs(op, ref_name(r.mate_ref_id()), text);
+                    default: {
+                        if (text.empty()) return false;
+                        char strand = (r.flag() & 0x10) ? '-' : '+';
+                        return cmp_int(op, (long)strand, (long)text[0]);
+                    }
                 }
             }
             case TAGNULL: {   // TagExistenceFilter (filtering.d:216-230): op 4 "== null", 5 "!= null"
@@ -270,8 +314,42 @@ private:
         p_ += w.size();
         return true;
     }
+    std::string string_literal() {
+        skip();
+        if (p_ >= s_.size() || s_[p_] != '\'') throw Error("filter: string literal expected");
+        ++p_;
+        std::string v;
+        for (;;) {
+            if (p_ >= s_.size()) throw Error("filter: unterminated string literal");
+            char ch = s_[p_++];
+            if (ch == '\\' && p_ < s_.size()) { v.push_back(s_[p_++]); continue; }
+            if (ch == '\'') break;
+            v.push_back(ch);
+        }
+        return v;
+    }
+    int cmp_operator() {
+        static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
+        static const int opid[] = {2, 3, 4, 5, 0, 1};
+        for (int k = 0; k < 6; ++k) if (eat(ops[k], false)) return opid[k];
+        return -1;
+    }
     std::unique_ptr<FilterNode> primary() {
         skip();
+        {
+            static const char* sf[] = {"read_name", "mate_ref_name", "ref_name", "strand"};
+            static const int sid[] = {0, 2, 1, 3};
+            for (int k = 0; k < 4; ++k)
+                if (eat(sf[k], true)) {
+                    auto n = std::make_unique<FilterNode>();
+                    n->kind = FilterNode::FIELDSTR;
+                    n->sfield = sid[k];
+                    n->op = cmp_operator();
+                    if (n->op < 0) throw Error("filter: comparison operator expected (regex conditions are not in the oracle)");
+                    n->text = string_literal();
+                    return n;
+                }
+        }
         if (eat("(", false)) {
             auto n = expr(0);
             if (!eat(")", false)) throw Error("filter: missing ')'");
@@ -340,11 +418,16 @@ private:
                         return n;
                     }
                     skip();
+                    if (p_ < s_.size() && s_[p_] == '\'') {
+                        n->kind = FilterNode::TAGSTR;
+                        n->text = string_literal();
+                        return n;
+                    }
                     size_t q = p_;
                     if (q < s_.size() && (s_[q] == '-' || s_[q] == '+')) ++q;
                     size_t d0 = q;
                     while (q < s_.size() && isdigit((unsigned char)s_[q])) ++q;
-                    if (q == d0) throw Error("filter: integer or null expected after a tag comparison (oracle subset)");
+                    if (q == d0) throw Error("filter: integer, string or null expected after a tag comparison (oracle subset)");
                     n->kind = FilterNode::TAGCMP;
                     n->value = atol(s_.substr(p_, q - p_).c_str());
                     p_ = q;
@@ -1320,6 +1403,10 @@ static int depth_main_impl(Options opt, FILE* outfp, std::string* err, RunStats*
         if (bam.hdr.sorting_order != "coordinate") throw Error("All files must be coordinate-sorted");
         if (!bam.has_index()) throw Error("All files must be indexed");
         printer->bam = &bam;
+        static std::vector<std::string> ref_names_for_filter;
+        ref_names_for_filter.clear();
+        for (auto& rs : bam.hdr.refs) ref_names_for_filter.push_back(rs.name);
+        g_filter_ref_names = &ref_names_for_filter;
 
         std::map<std::string, uint32_t> sm2id, rg2id;  // depth.d:1170-1181
         for (auto& rg : bam.hdr.read_groups) {

@@ -40,7 +40,8 @@ class FilterOp(C.Structure):
 
 
 class Filter(C.Structure):
-    _fields_ = [("n_ops", C.c_int32), ("reserved", C.c_int32), ("ops", FilterOp * SBX_FILTER_MAX_OPS)]
+    _fields_ = [("n_ops", C.c_int32), ("reserved", C.c_int32), ("ops", FilterOp * SBX_FILTER_MAX_OPS),
+                ("strings", C.c_char * 512)]
 
 
 class RunStats(C.Structure):

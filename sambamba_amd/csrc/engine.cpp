@@ -619,6 +619,19 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         memset(&df, 0, sizeof df);
         df.n_ops = c->filter.n_ops;
         memcpy(df.ops, c->filter.ops, sizeof(sbx_filter_op) * (size_t)c->filter.n_ops);
+        memcpy(df.strings, c->filter.strings, sizeof df.strings);
+        for (int i = 0; i < df.n_ops; ++i) {
+            // ref_name / mate_ref_name == 'x' becomes a comparison of the reference id ("*" is the name of id -1)
+            sbx_filter_op& o = df.ops[i];
+            if (o.kind != 11) continue;
+            const size_t off = (size_t)(o.value & 0xFFFFFFFF), len = (size_t)(o.value >> 32);
+            const std::string name(df.strings + std::min(off, sizeof df.strings), std::min(len, sizeof df.strings - std::min(off, sizeof df.strings)));
+            const int id = name == "*" ? -1 : c->hdr.find_ref(name);
+            if (id < 0 && name != "*") { o.kind = (o.cmp == 4) ? 12 : 6; continue; }     // unknown name: never equal
+            o.kind = 2;
+            o.field = o.field ? 4 : 0;
+            o.value = id;
+        }
         SBX_HIP(hipMemcpyAsync(c->d_filter.p, &df, sizeof df, hipMemcpyHostToDevice, s));
         RgTable rg{nullptr, nullptr, nullptr, 0, 0};
         std::string ids;

@@ -418,6 +418,32 @@ private:
     std::string s_;
     size_t p_ = 0;
     sbx_filter* out_;
+    // 'text' with \' and \\ escapes (queryparser.d string literal) -> (offset | length << 32) into the string pool
+    int64_t string_literal() {
+        skip();
+        if (p_ >= s_.size() || s_[p_] != '\'') throw Error(SBX_EUNSUPPORTED, "filter: string literal expected");
+        ++p_;
+        std::string v;
+        for (;;) {
+            if (p_ >= s_.size()) throw Error(SBX_EUNSUPPORTED, "filter: unterminated string literal");
+            char ch = s_[p_++];
+            if (ch == '\\' && p_ < s_.size()) { v.push_back(s_[p_++]); continue; }
+            if (ch == '\'') break;
+            v.push_back(ch);
+        }
+        if (pool_ + v.size() > SBX_FILTER_STRINGS) throw Error(SBX_EUNSUPPORTED, "filter: string literals too long for the device program");
+        memcpy(out_->strings + pool_, v.data(), v.size());
+        const int64_t r = (int64_t)pool_ | ((int64_t)v.size() << 32);
+        pool_ += v.size();
+        return r;
+    }
+    size_t pool_ = 0;
+    int cmp_op() {      // 0 > 1 < 2 >= 3 <= 4 == 5 !=, or -1
+        static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
+        static const int opid[] = {2, 3, 4, 5, 0, 1};
+        for (int k = 0; k < 6; ++k) if (eat(ops[k], false)) return opid[k];
+        return -1;
+    }
     void emit(uint8_t kind, uint32_t mask = 0, uint8_t field = 0, uint8_t cmp = 0, int64_t value = 0) {
         if (out_->n_ops >= SBX_FILTER_MAX_OPS) throw Error(SBX_EUNSUPPORTED, "filter: expression too long for the device program");
         sbx_filter_op& o = out_->ops[out_->n_ops++];
@@ -463,6 +489,32 @@ private:
                     }
                 throw Error(SBX_EUNSUPPORTED, "filter: comparison operator expected");
             }
+        // string fields (StringFieldFilter, filtering.d:255-273)
+        if (eat("read_name", true)) {
+            const int op = cmp_op();
+            if (op < 0) throw Error(SBX_EUNSUPPORTED, "filter: regex conditions are outside the device-compilable subset");
+            emit(10, 0, 0, (uint8_t)op, string_literal());
+            return;
+        }
+        for (int which = 0; which < 2; ++which)
+            if (eat(which ? "mate_ref_name" : "ref_name", true)) {
+                const int op = cmp_op();
+                if (op != 4 && op != 5) throw Error(SBX_EUNSUPPORTED, "filter: reference names can be compared with == and != on the device path");
+                emit(11, 0, (uint8_t)which, (uint8_t)op, string_literal());
+                return;
+            }
+        if (eat("strand", true)) {          // a.strand is '+' or '-' (read.d strand property)
+            const int op = cmp_op();
+            if (op != 4 && op != 5) throw Error(SBX_EUNSUPPORTED, "filter: strand can be compared with == and != on the device path");
+            const int64_t lit = string_literal();
+            const size_t off = (size_t)(lit & 0xFFFFFFFF), len = (size_t)(lit >> 32);
+            const char ch = len ? out_->strings[off] : 0;      // the reference compares with the first character
+            if (ch == '-') emit(0, 0x10);
+            else if (ch == '+') { emit(0, 0x10); emit(5); }
+            else emit(12);
+            if (op == 5) emit(5);
+            return;
+        }
         if (eat("[", false)) {      // [XX] op integer | [XX] == null | [XX] != null (queryparser.d:285-300)
             if (p_ + 3 > s_.size() || s_[p_ + 2] != ']') throw Error(SBX_EUNSUPPORTED, "filter: tag name of two characters expected");
             const uint32_t key = (uint8_t)s_[p_] | ((uint32_t)(uint8_t)s_[p_ + 1] << 8);
@@ -477,11 +529,12 @@ private:
                         return;
                     }
                     skip();
+                    if (p_ < s_.size() && s_[p_] == '\'') { emit(9, key, 0, opid[k], string_literal()); return; }   // StringTagFilter
                     size_t q = p_;
                     if (q < s_.size() && (s_[q] == '-' || s_[q] == '+')) ++q;
                     size_t d0 = q;
                     while (q < s_.size() && isdigit((unsigned char)s_[q])) ++q;
-                    if (q == d0) throw Error(SBX_EUNSUPPORTED, "filter: string / regex tag comparisons are outside the device-compilable subset");
+                    if (q == d0) throw Error(SBX_EUNSUPPORTED, "filter: regex tag comparisons are outside the device-compilable subset");
                     emit(7, key, 0, opid[k], atoll(s_.substr(p_, q - p_).c_str()));
                     p_ = q;
                     return;

@@ -286,6 +286,15 @@ __device__ __forceinline__ bool cmp_op(uint32_t op, T x, T y) {
     }
 }
 
+// lexicographic comparison of two byte strings with a comparison operator (D's string comparison for ASCII)
+__device__ bool cmp_str(uint32_t op, const uint8_t* a, uint32_t na, const char* b, uint32_t nb) {
+    int c = 0;
+    const uint32_t n = na < nb ? na : nb;
+    for (uint32_t i = 0; i < n && c == 0; ++i) c = (int)a[i] - (int)(uint8_t)b[i];
+    if (c == 0) c = na < nb ? -1 : na > nb ? 1 : 0;
+    return cmp_op<int>(op, c, 0);
+}
+
 __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID */, int32_t ref, int32_t pos, uint32_t bmn,
                             uint32_t fnc, int32_t l_seq, const uint8_t* tags, const uint8_t* tags_end) {
     // postfix program over a tiny bool stack (bit stack in a 64-bit word); the fields every record's
@@ -339,6 +348,26 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
                 else v = false;
                 break;
             }
+            case 9: {     // StringTagFilter (filtering.d:276-297): Z strings, A characters against one-character literals
+                const uint8_t* tv = nullptr;
+                const uint32_t ty = find_tag(tags, tags_end, op.mask, &tv);
+                const char* lit = f->strings + (uint32_t)(op.value & 0xFFFFFFFF);
+                const uint32_t nl = (uint32_t)(op.value >> 32);
+                if (ty == 'Z') {
+                    uint32_t n = 0;
+                    while (tv + n < tags_end && tv[n]) ++n;
+                    v = cmp_str(op.cmp, tv, n, lit, nl);
+                } else if (ty == 'A') {
+                    v = nl == 1 && cmp_op<int>(op.cmp, (int)tv[0], (int)(uint8_t)lit[0]);
+                } else v = false;
+                break;
+            }
+            case 10: {    // StringFieldFilter on read_name (filtering.d:264)
+                const uint32_t l_name = bmn & 0xFF;
+                v = cmp_str(op.cmp, p + 32, l_name ? l_name - 1 : 0, f->strings + (uint32_t)(op.value & 0xFFFFFFFF), (uint32_t)(op.value >> 32));
+                break;
+            }
+            case 12: v = false; break;
             case 8: {     // TagExistenceFilter (filtering.d:216-230)
                 const uint8_t* tv = nullptr;
                 const bool present = find_tag(tags, tags_end, op.mask, &tv) != 0;

@@ -49,6 +49,7 @@ struct SortedRegion {       // regions of the raw BED list sorted by (ref, start
 struct DeviceFilter {       // compiled -F program (sbx_filter), evaluated per record
     int32_t n_ops;
     sbx_filter_op ops[SBX_FILTER_MAX_OPS];
+    char strings[SBX_FILTER_STRINGS];
 };
 
 struct RefTable {           // per-reference device arrays

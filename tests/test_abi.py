@@ -41,9 +41,12 @@ def test_filter_compiler_default_and_errors():
     h = sambamba_amd.compile_filter("[NM] < 3 and [XS] == null")      # integer tags and tag existence compile
     assert [h.ops[i].kind for i in range(h.n_ops)] == [7, 8, 3]
     assert h.ops[0].mask == ord("N") | (ord("M") << 8) and h.ops[0].cmp == 1 and h.ops[0].value == 3
+    k = sambamba_amd.compile_filter("[RG] == 'lane\\'1' and strand == '-' and ref_name != 'chrM'")
+    assert [k.ops[i].kind for i in range(k.n_ops)] == [9, 0, 3, 11, 3]
+    assert k.strings[:6] == b"lane'1" and k.ops[0].value == (6 << 32)
     with pytest.raises(sambamba_amd.SbxError) as ei:
-        sambamba_amd.compile_filter("[RG] == 'a'")
-    assert ei.value.code == -5   # SBX_EUNSUPPORTED: string / regex tag conditions are outside the device subset
+        sambamba_amd.compile_filter("[RG] =~ /a/")
+    assert ei.value.code == -5   # SBX_EUNSUPPORTED: regular expressions are outside the device subset
     with pytest.raises(sambamba_amd.SbxError):
         sambamba_amd.compile_filter("read_name =~ /abc/")
 

@@ -54,6 +54,23 @@ def test_tag_filters_reference_fixtures(flt, bam):
     assert a == b
 
 
-def test_string_tag_filter_is_reported_unsupported(tagged):
-    r = run_cli(["base", "-F", "[RG] == 'g1'", tagged], check=False)
+@pytest.mark.parametrize("flt", [
+    "[RG] == 'g1'", "[RG] != 'g1'", "[NM] == '7'", "[NM] >= '7'", "[XS] == 'q'", "[XS] < 'r'", "[XS] == 'qq'", "[MD] > '3'",
+    "read_name == 'r2_5'", "read_name > 'r3'", "read_name <= 'r1_9' and [NM] != null", "read_name != 'it\\'s'",
+    "ref_name == 'c1'", "ref_name != 'c1'", "ref_name == 'nope'", "ref_name != 'nope'", "mate_ref_name == '*'", "mate_ref_name != '*'",
+    "strand == '+'", "strand == '-'", "strand != '+'", "strand == 'x'", "not (strand == '-' or [RG] == 'g1')",
+])
+def test_string_filters_synthetic(tagged, flt):
+    args = ["base", "-F", flt, tagged]
+    assert run_cli(args) == run_oracle(args)
+
+
+@pytest.mark.parametrize("flt", ["[RG] != null and ref_name == '2'", "strand == '-' and [MD] >= '5'", "mate_ref_name == '2' and read_name > 'H'"])
+def test_string_filters_reference_fixture(flt):
+    args = ["base", "-F", flt, "issue_204.bam"]
+    assert run_cli(args, cwd=GOLDEN) == run_oracle(args, cwd=GOLDEN)
+
+
+def test_regex_filter_is_reported_unsupported(tagged):
+    r = run_cli(["base", "-F", "read_name =~ /^r1/", tagged], check=False)
     assert r.returncode != 0 and b"device-compilable subset" in r.stderr
