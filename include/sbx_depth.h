@@ -93,7 +93,7 @@ typedef struct {
                              the header when the filter is installed)  12 FALSE
                           strings: value = offset into sbx_filter.strings | length << 32 */
     uint8_t  field;    /* INTCMP: 0 ref_id 1 position 2 mapping_quality 3 sequence_length
-                                  4 mate_ref_id 5 mate_position 6 template_length            */
+                                  4 mate_ref_id 5 mate_position 6 template_length 7 avg_base_quality */
     uint8_t  cmp;      /* INTCMP: 0 >  1 <  2 >=  3 <=  4 ==  5 !=                           */
     uint8_t  pad;
     uint32_t mask;
@@ -142,7 +142,7 @@ const char* sbx_header_text(sbx_ctx*, size_t* len);
 
 /* createFilterFromQuery (filtering.d:40-51).  query == NULL compiles the default
  * "mapping_quality > 0 and not duplicate and not failed_quality_control" (depth.d:1159).
- * Everything but regular expressions (=~), avg_base_quality and the sequence / cigar string fields compiles;
+ * Everything but regular expressions (=~) and the sequence / cigar string fields compiles;
  * those return SBX_EUNSUPPORTED. */
 int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t errlen);
 int sbx_set_filter(sbx_ctx*, const sbx_filter* f);

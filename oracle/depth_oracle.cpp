@@ -198,6 +198,19 @@ struct FilterNode {
             case CHIMERIC:  // filtering.d:172-177
                 return (r.flag() & 1) && !(r.flag() & 4) && !(r.flag() & 8) && r.ref_id() != r.mate_ref_id();
             case INTCMP: {
+                if (field == 7) {   // avg_base_quality (filtering.d:189-191): float sum / sequence_length
+                    float sum = 0.0f;
+                    for (int32_t k = 0; k < r.l_seq(); ++k) sum += (float)r.qual()[k];
+                    const float avg = sum / (float)r.l_seq(), fv = (float)value;
+                    switch (op) {
+                        case 0: return avg > fv;
+                        case 1: return avg < fv;
+                        case 2: return avg >= fv;
+                        case 3: return avg <= fv;
+                        case 4: return avg == fv;
+                        default: return avg != fv;
+                    }
+                }
                 long v = 0;
                 switch (field) {
                     case 0: v = r.ref_id(); break;
@@ -379,8 +392,8 @@ private:
             return n;
         }
         static const char* fields[] = {"ref_id", "position", "mapping_quality", "sequence_length",
-                                       "mate_ref_id", "mate_position", "template_length"};
-        for (int i = 0; i < 7; ++i)
+                                       "mate_ref_id", "mate_position", "template_length", "avg_base_quality"};
+        for (int i = 0; i < 8; ++i)
             if (eat(fields[i], true)) {
                 static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
                 static const int opid[] = {2, 3, 4, 5, 0, 1};

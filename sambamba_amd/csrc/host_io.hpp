@@ -470,8 +470,8 @@ private:
         for (auto& f : flags) if (eat(f.name, true)) { emit(0, f.mask); return; }
         if (eat("chimeric", true)) { emit(1); return; }
         static const char* fields[] = {"ref_id", "position", "mapping_quality", "sequence_length",
-                                       "mate_ref_id", "mate_position", "template_length"};
-        for (int i = 0; i < 7; ++i)
+                                       "mate_ref_id", "mate_position", "template_length", "avg_base_quality"};
+        for (int i = 0; i < 8; ++i)
             if (eat(fields[i], true)) {
                 static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
                 static const uint8_t opid[] = {2, 3, 4, 5, 0, 1};

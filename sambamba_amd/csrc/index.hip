@@ -309,6 +309,14 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
             case 0: v = (flag & op.mask) != 0; break;
             case 1: v = (flag & 1) && !(flag & 4) && !(flag & 8) && ref != (int32_t)ld32(p + 20); break;
             case 2: {
+                if (op.field == 7) {      // avg_base_quality: float32 sum / length against the integer (filtering.d:189-191,206)
+                    const uint32_t l_name = bmn & 0xFF, n_cigar = fnc & 0xFFFF;
+                    const uint8_t* q = p + 32 + l_name + 4 * n_cigar + (((uint32_t)l_seq + 1) >> 1);
+                    float sum = 0.0f;
+                    for (int32_t k = 0; k < l_seq; ++k) sum += (float)q[k];
+                    v = cmp_op<float>(op.cmp, sum / (float)l_seq, (float)op.value);
+                    break;
+                }
                 int64_t x = 0;
                 switch (op.field) {
                     case 0: x = ref; break;

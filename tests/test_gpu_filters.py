@@ -71,6 +71,13 @@ def test_string_filters_reference_fixture(flt):
     assert run_cli(args, cwd=GOLDEN) == run_oracle(args, cwd=GOLDEN)
 
 
+@pytest.mark.parametrize("flt", ["avg_base_quality >= 30", "avg_base_quality < 37 and mapping_quality > 10", "avg_base_quality == 30"])
+@pytest.mark.parametrize("bam", ["issue_204.bam", "issue225.bam"])
+def test_avg_base_quality(flt, bam):
+    args = ["base", "-F", flt, bam]
+    assert run_cli(args, cwd=GOLDEN) == run_oracle(args, cwd=GOLDEN)
+
+
 def test_regex_filter_is_reported_unsupported(tagged):
     r = run_cli(["base", "-F", "read_name =~ /^r1/", tagged], check=False)
     assert r.returncode != 0 and b"device-compilable subset" in r.stderr
