@@ -52,7 +52,8 @@ __device__ __forceinline__ uint32_t base5_of_nibble(uint32_t nib) {
 // consecutive positions (the dword fast path) and a lane owning 1 position (D/N runs) both spread
 // over all 32 banks: dword index of position p = (p & 3) * sub_dw + (p >> 2) * (S * 7),
 // sub_dw = (T / 4) * S * 7 + 8.
-__device__ __forceinline__ uint32_t pos_dw(uint32_t p, uint32_t sub_dw, uint32_t s7) { return (p & 3u) * sub_dw + (p >> 2) * s7; }
+// (24-bit multiplies: full rate on CDNA, and p < 2^12, sub_dw < 2^12 -- the 32-bit v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ uint32_t pos_dw(uint32_t p, uint32_t sub_dw, uint32_t s7) { return __umul24(p & 3u, sub_dw) + __umul24(p >> 2, s7); }
 
 struct RecU {   // wave-uniform view of one record (values live in SGPRs)
     const uint8_t* seq;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
                             const uint32_t byte = (uint32_t)(sw >> (8u * (qi >> 1))) & 0xFFu;
                             const uint32_t nib = (qi & 1u) ? (byte & 15u) : (byte >> 4);
                             const uint32_t ql = (uint32_t)(qw >> (8u * k)) & 0xFFu;
-                            if (ql >= min_bq) atomicAdd(&cnt[pos_dw(t0 + j + k, sub_dw, s7) + smp * 7 + base5_of_nibble(nib)], 1u);
+                            if (ql >= min_bq) atomicAdd(&cnt[pos_dw(t0 + j + k, sub_dw, s7) + __umul24(smp, 7u) + base5_of_nibble(nib)], 1u);
                         }
                     }
                 }
@@ -264,8 +265,10 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     // write the tile once, coalesced (undoing the (p & 3) split)
     const uint32_t n_cnt = T * s7;
     uint32_t* out = counters + (size_t)blockIdx.x * n_cnt;
+    // i / s7 by reciprocal multiplication (exact for i < 2^16; one real division per thread instead of 28)
+    const uint32_t inv_s7 = 0xFFFFFFFFu / s7 + 1u;
     for (uint32_t i = threadIdx.x; i < n_cnt; i += kAccThreads) {
-        const uint32_t p = i / s7, k = i - p * s7;
+        const uint32_t p = __umulhi(i, inv_s7), k = i - __umul24(p, s7);
         out[i] = cnt[pos_dw(p, sub_dw, s7) + k];
     }
     if (kSpan) {
