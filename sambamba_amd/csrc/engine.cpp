@@ -69,7 +69,7 @@ struct sbx_ctx {
     uint64_t u_base = 0;      // stream offset held at d_U.p[0]: d_U covers the BGZF block range of the current run only
     const uint8_t* U() const { return d_U.p - u_base; }     // address of stream offset 0 (only offsets >= u_base are backed)
     DevBuf<uint32_t> d_ent, d_nent;
-    DevBuf<uint64_t> d_entry, d_exit, d_base;
+    DevBuf<uint64_t> d_entry, d_exit, d_base, d_ckpt;
     DevBuf<uint32_t> d_count, d_flag;
     DevBuf<RecDesc> d_desc;
     DevBuf<int32_t> d_rec_ref;
@@ -527,6 +527,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
 
         c->d_entry.ensure(nb + 1);
         c->d_exit.ensure(nb + 1);
+        c->d_ckpt.ensure(3 * (size_t)nb + 3);
         c->d_count.ensure(nb + 1);
         c->d_base.ensure(nb + 2);
         c->d_flag.ensure(4);
@@ -543,7 +544,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         lap("start-index");
         t2.start(s);
         launch_block_walk(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, refs, c->d_entry.p,
-                          c->d_exit.p, c->d_count.p, s);
+                          c->d_exit.p, c->d_count.p, c->d_ckpt.p, s);
         lap("block_walk");
         uint32_t verify_iters = 0;   // number of blocks whose guessed entry had to be re-walked
         {
@@ -563,7 +564,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
                 if (first_bad == 0xFFFFFFFFu || first_bad >= nb) break;
                 const bool to_the_end = forced || round >= 16;
                 launch_chain_repair(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, first_bad,
-                                    !to_the_end, c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_flag.p + 1, s);
+                                    !to_the_end, c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_ckpt.p, c->d_flag.p + 1, s);
                 if (round > 64) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
             }
             SBX_HIP(hipMemcpyAsync(&verify_iters, c->d_flag.p + 1, 4, hipMemcpyDeviceToHost, s));
@@ -649,7 +650,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         c->d_stats.ensure(1);
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
         lap("scan+setup");
-        launch_describe(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, c->d_entry.p, c->d_base.p, refs, c->d_filter.p, rg,
+        launch_describe(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, c->d_entry.p, c->d_ckpt.p, c->d_base.p, refs, c->d_filter.p, rg,
                         T, c->d_desc.p, c->d_rec_ref.p, c->fix_mate ? c->d_name_hash.p : nullptr, c->d_tile_lo.p, c->d_tile_hi.p,
                         c->d_stats.p, s);
         lap("describe");

@@ -105,10 +105,15 @@ __device__ uint64_t guess_entry(const uint8_t* U, uint64_t total, uint64_t from,
 }
 
 // walk the chain from `entry` until it leaves [.., block_end); returns exit offset or kOffInvalid
-__device__ uint64_t walk_block(const uint8_t* U, uint64_t total, uint64_t entry, uint64_t block_end, uint32_t* count) {
+// ck (optional): offsets of the block's records number 64, 128 and 192 -- `describe` starts a lane at each of them, so
+// that a block's ~230 records are described by four lanes with chains of 64 instead of one lane with a chain of 230
+__device__ uint64_t walk_block(const uint8_t* U, uint64_t total, uint64_t entry, uint64_t block_end, uint32_t* count,
+                               uint64_t* ck = nullptr) {
     uint64_t o = entry;
     uint32_t n = 0;
+    if (ck) { ck[0] = kOffInvalid; ck[1] = kOffInvalid; ck[2] = kOffInvalid; }
     while (o < block_end) {
+        if (ck && n && (n & 63u) == 0 && n <= 192u) ck[(n >> 6) - 1] = o;
         if (o + 4 > total) { *count = n; return kOffInvalid; }
         int64_t bs = (int32_t)ld32(U + o);
         if (bs < 32 || o + 4 + (uint64_t)bs > total) { *count = n; return kOffInvalid; }
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_block_walk(const uint8_t* __re
                                                               const uint32_t* __restrict__ isize, uint32_t n_blocks,
                                                               uint64_t first_record_off, RefTable refs,
                                                               uint64_t* __restrict__ entry, uint64_t* __restrict__ exit_,
-                                                              uint32_t* __restrict__ count) {
+                                                              uint32_t* __restrict__ count, uint64_t* __restrict__ ckpt) {
     uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
     if (b >= n_blocks) return;
     uint64_t beg = out_off[b], end = beg + isize[b];
@@ -135,13 +140,15 @@ __global__ __launch_bounds__(kWalkThreads) void k_block_walk(const uint8_t* __re
         entry[b] = first_record_off;
         exit_[b] = first_record_off;
         count[b] = 0;
+        ckpt[3 * (size_t)b] = kOffInvalid; ckpt[3 * (size_t)b + 1] = kOffInvalid; ckpt[3 * (size_t)b + 2] = kOffInvalid;
         return;
     }
     if (beg <= first_record_off) e = first_record_off;       // exactly known
     else e = guess_entry(U, total, beg, end, refs);
     uint32_t n = 0;
     uint64_t x = kOffUnknown;
-    if (e != kOffUnknown) x = walk_block(U, total, e, end, &n);
+    if (e != kOffUnknown) x = walk_block(U, total, e, end, &n, ckpt + 3 * (size_t)b);
+    else { ckpt[3 * (size_t)b] = kOffInvalid; ckpt[3 * (size_t)b + 1] = kOffInvalid; ckpt[3 * (size_t)b + 2] = kOffInvalid; }
     entry[b] = e;
     exit_[b] = x;
     count[b] = n;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
                                                       const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize,
                                                       uint32_t n_blocks, uint64_t first_record_off, uint32_t from,
                                                       uint32_t stop_at_trusted, uint64_t* entry, uint64_t* exit_, uint32_t* count,
-                                                      uint32_t* n_rewalked) {
+                                                      uint64_t* ckpt, uint32_t* n_rewalked) {
     const uint32_t lane = threadIdx.x;
     uint64_t cur = (from == 0) ? first_record_off : exit_[from - 1];
     uint32_t rewalked = 0;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
             }
             else {
                 uint32_t c = 0;
-                nx = walk_block(U, total, cur, end_i, &c);     // wave-uniform re-walk
+                nx = walk_block(U, total, cur, end_i, &c, ckpt + 3 * (size_t)(b0 + i));     // wave-uniform re-walk (every lane writes the same checkpoints)
                 ne = cur;
                 nn = c;
                 ++rewalked;
@@ -434,17 +441,22 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
                                                             const uint64_t* __restrict__ out_off,
                                                             const uint32_t* __restrict__ isize, uint32_t n_blocks,
                                                             const uint64_t* __restrict__ entry,
+                                                            const uint64_t* __restrict__ ckpt,
                                                             const uint64_t* __restrict__ base, RefTable refs,
                                                             const DeviceFilter* __restrict__ filt, RgTable rg,
                                                             uint32_t tile_pos, RecDesc* __restrict__ desc,
                                                             int32_t* __restrict__ rec_ref, uint64_t* __restrict__ name_hash,
                                                             uint32_t* tile_lo, uint32_t* tile_hi, IndexStats* stats) {
-    uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    // four lanes per BGZF block: lane `seg` describes records 64*seg .. 64*seg+63 of the block (the last one: the rest),
+    // starting at the checkpoint the walk left for it
+    const uint32_t gl = blockIdx.x * kWalkThreads + threadIdx.x;
+    const uint32_t b = gl >> 2, seg = gl & 3u;
     if (b >= n_blocks) return;
     uint64_t end = out_off[b] + isize[b];
     if (end > total) end = total;
-    uint64_t o = entry[b];
-    uint64_t idx = base[b];
+    uint64_t o = seg == 0 ? entry[b] : ckpt[3 * (size_t)b + seg - 1];
+    uint64_t idx = base[b] + 64u * seg;
+    uint32_t left = seg < 3 ? 64u : 0xFFFFFFFFu;
     unsigned long long n_rec = 0, n_adm = 0, n_bad = 0, n_urg = 0;
     // tile-range bookkeeping aggregated per lane: flush on tile change
     uint32_t cur_t0 = 0xFFFFFFFFu, cur_t1 = 0, cur_lo = 0, cur_hi = 0;
@@ -479,7 +491,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __rest
         uint32_t n_cigar = fnc & 0xFFFF, flag = fnc >> 16;
         int32_t l_seq = (int32_t)fx.w[5];
         const uint64_t o_next = o + 4 + (uint64_t)bs;
-        const bool have_next = bs >= 32 && o_next < end;
+        --left;
+        const bool have_next = bs >= 32 && o_next < end && left != 0;
         Fixed fn = {{0, 0, 0, 0, 0, 0}};
         if (have_next) fn = load_fixed(o_next);
         RecDesc d;
@@ -640,11 +653,11 @@ void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream
 
 void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                        uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry, uint64_t* d_exit,
-                       uint32_t* d_count, hipStream_t stream) {
+                       uint32_t* d_count, uint64_t* d_ckpt, hipStream_t stream) {
     if (!n_blocks) return;
     dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
     hipLaunchKernelGGL(k_block_walk, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, first_record_off,
-                       refs, d_entry, d_exit, d_count);
+                       refs, d_entry, d_exit, d_count, d_ckpt);
     SBX_HIP(hipGetLastError());
 }
 
@@ -659,9 +672,9 @@ void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint
 
 void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                          uint32_t n_blocks, uint64_t first_record_off, uint32_t from, bool stop_at_trusted, uint64_t* d_entry,
-                         uint64_t* d_exit, uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream) {
+                         uint64_t* d_exit, uint32_t* d_count, uint64_t* d_ckpt, uint32_t* d_n_rewalked, hipStream_t stream) {
     hipLaunchKernelGGL(k_chain_repair, dim3(1), dim3(64), 0, stream, d_U, total, d_out_off, d_isize, n_blocks,
-                       first_record_off, from, stop_at_trusted ? 1u : 0u, d_entry, d_exit, d_count, d_n_rewalked);
+                       first_record_off, from, stop_at_trusted ? 1u : 0u, d_entry, d_exit, d_count, d_ckpt, d_n_rewalked);
     SBX_HIP(hipGetLastError());
 }
 
@@ -673,12 +686,12 @@ void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_b
 }
 
 void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
+                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_ckpt, const uint64_t* d_base, RefTable refs,
                      const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
                      uint64_t* d_name_hash, uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream) {
     if (!n_blocks) return;
-    dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
-    hipLaunchKernelGGL(k_describe, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, d_entry, d_base,
+    dim3 grid((uint32_t)(((uint64_t)n_blocks * 4 + kWalkThreads - 1) / kWalkThreads)), block(kWalkThreads);
+    hipLaunchKernelGGL(k_describe, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, d_entry, d_ckpt, d_base,
                        refs, d_filter, rg, tile_pos, d_desc, d_rec_ref, d_name_hash, d_tile_lo, d_tile_hi, d_stats);
     SBX_HIP(hipGetLastError());
 }

@@ -88,7 +88,7 @@ const char* inflate_status_string(uint32_t s);
 // guess + walk: per BGZF block, first record start g[b] >= out_off[b], record count and exit.
 void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                        uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry,
-                       uint64_t* d_exit, uint32_t* d_count, hipStream_t stream);
+                       uint64_t* d_exit, uint32_t* d_count, uint64_t* d_ckpt, hipStream_t stream);
 // parallel consistency check of the guessed chain: *d_first_bad = lowest inconsistent block (or unchanged)
 void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint32_t n_blocks, uint64_t first_record_off,
                         const uint64_t* d_entry, const uint64_t* d_exit, uint32_t* d_first_bad, hipStream_t stream);
@@ -96,7 +96,7 @@ void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint
 // block after a fix whose guessed entry is confirmed (the caller re-checks); *d_n_rewalked += wrong guesses
 void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
                          uint32_t n_blocks, uint64_t first_record_off, uint32_t from, bool stop_at_trusted, uint64_t* d_entry,
-                         uint64_t* d_exit, uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream);
+                         uint64_t* d_exit, uint32_t* d_count, uint64_t* d_ckpt, uint32_t* d_n_rewalked, hipStream_t stream);
 // exclusive scan of per-block record counts -> d_base[n_blocks+1]
 void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void* d_tmp, size_t tmp_bytes,
                        hipStream_t stream);
@@ -107,7 +107,7 @@ struct IndexStats {         // device-side accumulators of the describe pass
 };
 // walk again, decode fixed fields + CIGAR span, apply filter, write descriptors, mark tile ranges
 void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_base, RefTable refs,
+                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_ckpt, const uint64_t* d_base, RefTable refs,
                      const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
                      uint64_t* d_name_hash /* may be null */, uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats,
                      hipStream_t stream);
