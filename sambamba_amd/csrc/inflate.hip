@@ -26,7 +26,7 @@
 //
 //  K1b `lz77_resolve`    -- copying matches is data-parallel once positions are known, so the
 //      mapping is ONE WAVE PER BGZF BLOCK: 64 entries at a time, output offsets by a DPP prefix sum.
-//      The wave keeps the last 2-3.5 KiB of its output in a linear LDS window: NEAR matches -- the
+//      The wave keeps the last 2-3 KiB of its output in a linear LDS window: NEAR matches -- the
 //      record -> previous record -> ... chain that makes a BAM stream serial -- are resolved LDS -> LDS
 //      in rounds (a match may start once everything below its source end is final, i.e. lies below
 //      the start of the first unfinished match; self-overlapping matches are extended periodically),
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
 constexpr int kResThreads = 256;
 constexpr uint32_t kHist = 2048;            // bytes of history guaranteed to be in LDS
 constexpr uint32_t kSpanMax = 1536;         // output bytes per batch (a batch is <= 64 entries AND <= this)
-constexpr uint32_t kCap = 5120;             // LDS bytes per wave: kHist + slide hysteresis + kSpanMax
+constexpr uint32_t kCap = 4608;             // LDS bytes per wave: kHist + slide hysteresis + kSpanMax
 constexpr uint32_t kWaveLds = kCap + 16;
 
 // inclusive prefix sum over the 64 lanes: four row-shift steps inside each row of 16 lanes, then the row
