@@ -628,7 +628,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
 // ---- K1b -----------------------------------------------------------------------------------------
 // One wave per BGZF block, four blocks per workgroup.  The wave keeps the most recent kHist..kCap
 // bytes of its output in a linear LDS buffer (offset = position - base; the buffer is slid down every
-// ~1.5 KiB of output, so there is no wrap-around anywhere):
+// ~1 KiB of output, so there is no wrap-around anywhere):
 //   * literal runs and FAR matches (source below `base`, i.e. output this wave flushed to HBM at least
 //     a batch ago -- final, no dependency) are fetched from global memory, all loads of a batch in
 //     flight together: one memory round trip per batch;
