@@ -90,7 +90,7 @@ typedef struct {
                           7 TAGCMP (mask = key chars c0 | c1 << 8; cmp; value)  8 TAGNULL (cmp 4: absent, 5: present)
                           9 TAGSTR (mask = key; cmp; value = string)  10 NAMESTR (read_name; cmp; value = string)
                           11 REFNAME (field 0 ref_name, 1 mate_ref_name; cmp 4 / 5; value = string; resolved against
-                             the header when the filter is installed)  12 FALSE
+                             the header when the filter is installed)  12 FALSE  13 SEQSTR / 14 CIGARSTR (sequence / cigar as text)
                           strings: value = offset into sbx_filter.strings | length << 32 */
     uint8_t  field;    /* INTCMP: 0 ref_id 1 position 2 mapping_quality 3 sequence_length
                                   4 mate_ref_id 5 mate_position 6 template_length 7 avg_base_quality */
@@ -142,8 +142,7 @@ const char* sbx_header_text(sbx_ctx*, size_t* len);
 
 /* createFilterFromQuery (filtering.d:40-51).  query == NULL compiles the default
  * "mapping_quality > 0 and not duplicate and not failed_quality_control" (depth.d:1159).
- * Everything but regular expressions (=~) and the sequence / cigar string fields compiles;
- * those return SBX_EUNSUPPORTED. */
+ * Everything but regular expressions (=~) compiles; those return SBX_EUNSUPPORTED. */
 int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t errlen);
 int sbx_set_filter(sbx_ctx*, const sbx_filter* f);
 

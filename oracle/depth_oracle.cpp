@@ -250,6 +250,16 @@ struct FilterNode {
                     case 0: return cmp_strs(op, std::string((const char*)r.name(), (size_t)r.name_len()), text);
                     case 1: return cmp_strs(op, ref_name(r.ref_id()), text);
                     case 2: return cmp_strs(op, ref_name(r.mate_ref_id()), text);
+                    case 4: {   // cmp(a.sequence, value)
+                        std::string sq;
+                        for (int32_t i = 0; i < r.l_seq(); ++i) sq.push_back(seq_char(r, (uint32_t)i));
+                        return cmp_strs(op, sq, text);
+                    }
+                    case 5: {   // a.cigarString() (read.d:265-276)
+                        std::string cs;
+                        for (uint32_t i = 0; i < r.n_cigar(); ++i) { cs += std::to_string(op_len(r.cigar_op(i))); cs.push_back(op_char(r.cigar_op(i))); }
+                        return cmp_strs(op, cs, text);
+                    }
                     default: {
                         if (text.empty()) return false;
                         char strand = (r.flag() & 0x10) ? '-' : '+';
@@ -350,9 +360,9 @@ private:
     std::unique_ptr<FilterNode> primary() {
         skip();
         {
-            static const char* sf[] = {"read_name", "mate_ref_name", "ref_name", "strand"};
-            static const int sid[] = {0, 2, 1, 3};
-            for (int k = 0; k < 4; ++k)
+            static const char* sf[] = {"read_name", "mate_ref_name", "ref_name", "strand", "sequence", "cigar"};
+            static const int sid[] = {0, 2, 1, 3, 4, 5};
+            for (int k = 0; k < 6; ++k)
                 if (eat(sf[k], true)) {
                     auto n = std::make_unique<FilterNode>();
                     n->kind = FilterNode::FIELDSTR;

@@ -497,6 +497,13 @@ private:
             return;
         }
         for (int which = 0; which < 2; ++which)
+            if (eat(which ? "cigar" : "sequence", true)) {      // compared as text (cmp(a.sequence, v), a.cigarString())
+                const int op = cmp_op();
+                if (op < 0) throw Error(SBX_EUNSUPPORTED, "filter: regex conditions are outside the device-compilable subset");
+                emit((uint8_t)(13 + which), 0, 0, (uint8_t)op, string_literal());
+                return;
+            }
+        for (int which = 0; which < 2; ++which)
             if (eat(which ? "mate_ref_name" : "ref_name", true)) {
                 const int op = cmp_op();
                 if (op != 4 && op != 5) throw Error(SBX_EUNSUPPORTED, "filter: reference names can be compared with == and != on the device path");

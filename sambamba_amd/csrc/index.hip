@@ -382,6 +382,44 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
                 v = cmp_str(op.cmp, p + 32, l_name ? l_name - 1 : 0, f->strings + (uint32_t)(op.value & 0xFFFFFFFF), (uint32_t)(op.value >> 32));
                 break;
             }
+            case 13: {    // sequence as text against the literal (StringFieldFilter, filtering.d:265)
+                const uint32_t l_name = bmn & 0xFF, n_cigar = fnc & 0xFFFF;
+                const uint8_t* sq = p + 32 + l_name + 4 * n_cigar;
+                const char* lit = f->strings + (uint32_t)(op.value & 0xFFFFFFFF);
+                const uint32_t nl = (uint32_t)(op.value >> 32), ns = l_seq > 0 ? (uint32_t)l_seq : 0u;
+                int c = 0;
+                for (uint32_t i = 0; i < ns && i < nl && c == 0; ++i) {
+                    const uint32_t nib = (i & 1u) ? (sq[i >> 1] & 15u) : (sq[i >> 1] >> 4);
+                    c = (int)(uint8_t)"=ACMGRSVTWYHKDBN"[nib] - (int)(uint8_t)lit[i];
+                }
+                if (c == 0) c = ns < nl ? -1 : ns > nl ? 1 : 0;
+                v = cmp_op<int>(op.cmp, c, 0);
+                break;
+            }
+            case 14: {    // cigarString(): decimal length + operation character per op, "" for no CIGAR (read.d:265-276)
+                const uint32_t l_name = bmn & 0xFF, n_cigar = fnc & 0xFFFF;
+                const uint8_t* cg = p + 32 + l_name;
+                const char* lit = f->strings + (uint32_t)(op.value & 0xFFFFFFFF);
+                const uint32_t nl = (uint32_t)(op.value >> 32);
+                uint32_t k = 0;        // characters of the literal matched so far
+                int c = 0;
+                for (uint32_t i = 0; i < n_cigar && c == 0; ++i) {
+                    const uint32_t raw = ld32(cg + 4 * i);
+                    uint32_t len = raw >> 4, div = 1;
+                    while (len / div >= 10) div *= 10;
+                    for (; div && c == 0; div /= 10) {
+                        const int ch = '0' + (int)((len / div) % 10);
+                        if (k >= nl) c = 1; else c = ch - (int)(uint8_t)lit[k++];
+                    }
+                    if (c == 0) {
+                        const int ch = (raw & 15u) < 9 ? (int)"MIDNSHP=X"[raw & 15u] : (int)'?';
+                        if (k >= nl) c = 1; else c = ch - (int)(uint8_t)lit[k++];
+                    }
+                }
+                if (c == 0 && k < nl) c = -1;
+                v = cmp_op<int>(op.cmp, c, 0);
+                break;
+            }
             case 12: v = false; break;
             case 8: {     // TagExistenceFilter (filtering.d:216-230)
                 const uint8_t* tv = nullptr;

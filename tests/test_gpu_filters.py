@@ -59,13 +59,16 @@ def test_tag_filters_reference_fixtures(flt, bam):
     "read_name == 'r2_5'", "read_name > 'r3'", "read_name <= 'r1_9' and [NM] != null", "read_name != 'it\\'s'",
     "ref_name == 'c1'", "ref_name != 'c1'", "ref_name == 'nope'", "ref_name != 'nope'", "mate_ref_name == '*'", "mate_ref_name != '*'",
     "strand == '+'", "strand == '-'", "strand != '+'", "strand == 'x'", "not (strand == '-' or [RG] == 'g1')",
+    "cigar == '40M'", "cigar != '40M'", "cigar > '4'", "cigar < '40M1'", "sequence == 'ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT'",
+    "sequence > 'ACGTACGTAC'", "sequence < 'ACGU'", "sequence != ''",
 ])
 def test_string_filters_synthetic(tagged, flt):
     args = ["base", "-F", flt, tagged]
     assert run_cli(args) == run_oracle(args)
 
 
-@pytest.mark.parametrize("flt", ["[RG] != null and ref_name == '2'", "strand == '-' and [MD] >= '5'", "mate_ref_name == '2' and read_name > 'H'"])
+@pytest.mark.parametrize("flt", ["[RG] != null and ref_name == '2'", "strand == '-' and [MD] >= '5'", "mate_ref_name == '2' and read_name > 'H'",
+                                 "cigar == '101M' or cigar > '5'", "sequence >= 'G' and cigar != '101M'"])
 def test_string_filters_reference_fixture(flt):
     args = ["base", "-F", flt, "issue_204.bam"]
     assert run_cli(args, cwd=GOLDEN) == run_oracle(args, cwd=GOLDEN)
