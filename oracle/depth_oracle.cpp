@@ -345,7 +345,7 @@ private:
         for (;;) {
             if (p_ >= s_.size()) throw Error("filter: unterminated string literal");
             char ch = s_[p_++];
-            if (ch == '\\' && p_ < s_.size()) { v.push_back(s_[p_++]); continue; }
+            if (ch == '\\' && p_ < s_.size() && s_[p_] == '\'') { v.push_back('\''); ++p_; continue; }   // the only escape (queryparser.d:343-377)
             if (ch == '\'') break;
             v.push_back(ch);
         }

@@ -418,7 +418,7 @@ private:
     std::string s_;
     size_t p_ = 0;
     sbx_filter* out_;
-    // 'text' with \' and \\ escapes (queryparser.d string literal) -> (offset | length << 32) into the string pool
+    // 'text' with \' as the only escape (queryparser.d:343-377) -> (offset | length << 32) into the string pool
     int64_t string_literal() {
         skip();
         if (p_ >= s_.size() || s_[p_] != '\'') throw Error(SBX_EUNSUPPORTED, "filter: string literal expected");
@@ -427,7 +427,7 @@ private:
         for (;;) {
             if (p_ >= s_.size()) throw Error(SBX_EUNSUPPORTED, "filter: unterminated string literal");
             char ch = s_[p_++];
-            if (ch == '\\' && p_ < s_.size()) { v.push_back(s_[p_++]); continue; }
+            if (ch == '\\' && p_ < s_.size() && s_[p_] == '\'') { v.push_back('\''); ++p_; continue; }   // the only escape (queryparser.d:343-377)
             if (ch == '\'') break;
             v.push_back(ch);
         }
