@@ -85,12 +85,27 @@ typedef struct {
  * Built by sbx_compile_filter() from the query string. */
 #define SBX_FILTER_MAX_OPS 64
 #define SBX_FILTER_STRINGS 512
+#define SBX_FILTER_REGEXES 2
+#define SBX_REGEX_STATES 64
+#define SBX_REGEX_CLASSES 8
+/* A regular expression (`read_name =~ /^chr[0-9]+/`) compiled to a Thompson NFA of at most 64 states, so that a
+ * state set is one 64-bit mask: type 0 CHAR c, 1 ANY, 2 CLASS classes[c], 3 SPLIT a|b, 4 JMP a, 5 BOL, 6 EOL, 7 MATCH;
+ * consuming states continue at a. */
+typedef struct { uint8_t type, a, b, c; } sbx_regex_state;
+typedef struct {
+    uint8_t n_states, n_classes, start, reserved;
+    sbx_regex_state states[SBX_REGEX_STATES];
+    uint8_t classes[SBX_REGEX_CLASSES][32];
+} sbx_regex;
 typedef struct {
     uint8_t  kind;     /* 0 FLAG_ANY(mask)  1 CHIMERIC  2 INTCMP  3 AND  4 OR  5 NOT  6 TRUE
                           7 TAGCMP (mask = key chars c0 | c1 << 8; cmp; value)  8 TAGNULL (cmp 4: absent, 5: present)
                           9 TAGSTR (mask = key; cmp; value = string)  10 NAMESTR (read_name; cmp; value = string)
                           11 REFNAME (field 0 ref_name, 1 mate_ref_name; cmp 4 / 5; value = string; resolved against
                              the header when the filter is installed)  12 FALSE  13 SEQSTR / 14 CIGARSTR (sequence / cigar as text)
+                          15 REGEX (field 0 read_name 1 sequence 2 cigar 3 tag [mask = key] 4 ref_name 5 mate_ref_name;
+                             value = index into sbx_filter.regex)  16 REFSET (internal: 15 on a reference name, resolved
+                             against the header when the filter is installed)
                           strings: value = offset into sbx_filter.strings | length << 32 */
     uint8_t  field;    /* INTCMP: 0 ref_id 1 position 2 mapping_quality 3 sequence_length
                                   4 mate_ref_id 5 mate_position 6 template_length 7 avg_base_quality */
@@ -104,6 +119,9 @@ typedef struct {
     int32_t reserved;
     sbx_filter_op ops[SBX_FILTER_MAX_OPS];
     char strings[SBX_FILTER_STRINGS];
+    int32_t n_regex;
+    int32_t reserved2;
+    sbx_regex regex[SBX_FILTER_REGEXES];
 } sbx_filter;
 
 /* ---- codec seam -------------------------------------------------------------
@@ -142,9 +160,14 @@ const char* sbx_header_text(sbx_ctx*, size_t* len);
 
 /* createFilterFromQuery (filtering.d:40-51).  query == NULL compiles the default
  * "mapping_quality > 0 and not duplicate and not failed_quality_control" (depth.d:1159).
- * Everything but regular expressions (=~) compiles; those return SBX_EUNSUPPORTED. */
+ * The whole query language compiles; regular expressions in the common core of D's std.regex and ECMAScript
+ * (no back-references, look-around or word boundaries; option i only; at most 2 per filter and 64 NFA states each),
+ * anything else returns SBX_EUNSUPPORTED. */
 int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t errlen);
 int sbx_set_filter(sbx_ctx*, const sbx_filter* f);
+/* Host-side evaluation of one `=~` condition (the same NFA simulation the device runs): 1 = the pattern matches
+ * somewhere in text[0, n), 0 = it does not, < 0 = the pattern is outside the supported subset (message in err). */
+int sbx_regex_search(const char* pattern, const char* options, const char* text, size_t n, char* err, size_t errlen);
 
 /* -q, -m, --combined (depth.d:1127-1132); window/overlap and -T (depth.d:712-715,1015-1018). */
 int sbx_set_params(sbx_ctx*, int mode, uint8_t min_base_quality, int fix_mate_overlaps, int combined,

@@ -29,6 +29,7 @@
 #include <chrono>
 #include <cmath>
 #include <functional>
+#include <regex>
 
 namespace orc {
 
@@ -182,7 +183,8 @@ static inline bool cmp_int(int op, long x, long y) {
 static inline bool cmp_strs(int op, const std::string& a, const std::string& b) { return cmp_int(op, a.compare(b) < 0 ? -1 : a.compare(b) > 0 ? 1 : 0, 0); }
 
 struct FilterNode {
-    enum Kind { FLAG, CHIMERIC, INTCMP, AND, OR, NOT, TRUE_, TAGCMP, TAGNULL, TAGSTR, FIELDSTR } kind = TRUE_;
+    enum Kind { FLAG, CHIMERIC, INTCMP, AND, OR, NOT, TRUE_, TAGCMP, TAGNULL, TAGSTR, FIELDSTR, REGEX } kind = TRUE_;
+    std::shared_ptr<std::regex> rx;   // REGEX: sfield 0 read_name 1 ref_name 2 mate_ref_name 4 sequence 5 cigar 6 tag (key)
     std::string text;       // TAGSTR / FIELDSTR: the literal
     int sfield = 0;         // FIELDSTR: 0 read_name 1 ref_name 2 mate_ref_name 3 strand
     char key[2] = {0, 0};   // TAGCMP / TAGNULL: the aux key
@@ -266,6 +268,28 @@ struct FilterNode {
                         return cmp_int(op, (long)strand, (long)text[0]);
                     }
                 }
+            }
+            case REGEX: {     // RegexpFieldFilter / RegexpTagFilter (filtering.d:299-345): !match(text, re).empty
+                auto ref_name = [&](int id) -> std::string {
+                    if (id < 0 || !g_filter_ref_names || (size_t)id >= g_filter_ref_names->size()) return "*";
+                    return (*g_filter_ref_names)[(size_t)id];
+                };
+                std::string t;
+                switch (sfield) {
+                    case 0: t.assign((const char*)r.name(), (size_t)r.name_len()); break;
+                    case 1: t = ref_name(r.ref_id()); break;
+                    case 2: t = ref_name(r.mate_ref_id()); break;
+                    case 4: for (int32_t i = 0; i < r.l_seq(); ++i) t.push_back(seq_char(r, (uint32_t)i)); break;
+                    case 5: for (uint32_t i = 0; i < r.n_cigar(); ++i) { t += std::to_string(op_len(r.cigar_op(i))); t.push_back(op_char(r.cigar_op(i))); } break;
+                    default: {
+                        const uint8_t* v = nullptr;
+                        if (find_tag(r, key[0], key[1], &v) != 'Z') return false;
+                        const uint8_t* e = v;
+                        while (e < r.end() && *e) ++e;
+                        t.assign((const char*)v, (size_t)(e - v));
+                    }
+                }
+                return std::regex_search(t, *rx);
             }
             case TAGNULL: {   // TagExistenceFilter (filtering.d:216-230): op 4 "== null", 5 "!= null"
                 const uint8_t* v = nullptr;
@@ -351,6 +375,33 @@ private:
         }
         return v;
     }
+    // =~ /pattern/i after a string field or a tag
+    bool regex_literal(FilterNode& n) {
+        skip();
+        if (s_.compare(p_, 2, "=~") != 0) return false;
+        p_ += 2;
+        skip();
+        if (p_ >= s_.size() || s_[p_] != '/') throw Error("filter: regular expression literal expected");
+        size_t i = p_ + 1;
+        std::string pat;
+        for (;; ++i) {
+            if (i >= s_.size()) throw Error("filter: unterminated regular expression");
+            if (s_[i] == '\\' && i + 1 < s_.size() && s_[i + 1] == '/') { pat += "\\/"; ++i; continue; }
+            if (s_[i] == '/') break;
+            pat.push_back(s_[i]);
+        }
+        ++i;
+        auto flags = std::regex::ECMAScript;
+        while (i < s_.size() && !isspace((unsigned char)s_[i]) && s_[i] != ')') {
+            if (s_[i] == 'i') flags |= std::regex::icase;
+            else throw Error("filter: regular expression option not in the oracle");
+            ++i;
+        }
+        p_ = i;
+        n.kind = FilterNode::REGEX;
+        n.rx = std::make_shared<std::regex>(pat, flags);
+        return true;
+    }
     int cmp_operator() {
         static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
         static const int opid[] = {2, 3, 4, 5, 0, 1};
@@ -365,8 +416,9 @@ private:
             for (int k = 0; k < 6; ++k)
                 if (eat(sf[k], true)) {
                     auto n = std::make_unique<FilterNode>();
-                    n->kind = FilterNode::FIELDSTR;
                     n->sfield = sid[k];
+                    if (sid[k] != 3 && regex_literal(*n)) return n;
+                    n->kind = FilterNode::FIELDSTR;
                     n->op = cmp_operator();
                     if (n->op < 0) throw Error("filter: comparison operator expected (regex conditions are not in the oracle)");
                     n->text = string_literal();
@@ -430,6 +482,8 @@ private:
             n->key[0] = s_[p_];
             n->key[1] = s_[p_ + 1];
             p_ += 3;
+            n->sfield = 6;
+            if (regex_literal(*n)) return n;
             static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
             static const int opid[] = {2, 3, 4, 5, 0, 1};
             for (int k = 0; k < 6; ++k)

@@ -6,5 +6,5 @@ from sambamba_amd/csrc/ by sambamba_amd.build.  This package only binds the C AB
 for tests and bench.py; there is no Python or CPU implementation of the hot path, and loading
 fails loudly when the library has not been built.
 """
-from ._lib import (SbxError, Depth, lib, lib_path, inflate_blocks, compile_filter, cli_path,  # noqa: F401
+from ._lib import (SbxError, Depth, lib, lib_path, inflate_blocks, compile_filter, regex_search, cli_path,  # noqa: F401
                    SBX_MODE_BASE, SBX_MODE_REGION, SBX_MODE_WINDOW)

@@ -39,9 +39,18 @@ class FilterOp(C.Structure):
                 ("mask", C.c_uint32), ("value", C.c_int64)]
 
 
+class RegexState(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("a", C.c_uint8), ("b", C.c_uint8), ("c", C.c_uint8)]
+
+
+class Regex(C.Structure):
+    _fields_ = [("n_states", C.c_uint8), ("n_classes", C.c_uint8), ("start", C.c_uint8), ("reserved", C.c_uint8),
+                ("states", RegexState * 64), ("classes", (C.c_uint8 * 32) * 8)]
+
+
 class Filter(C.Structure):
     _fields_ = [("n_ops", C.c_int32), ("reserved", C.c_int32), ("ops", FilterOp * SBX_FILTER_MAX_OPS),
-                ("strings", C.c_char * 512)]
+                ("strings", C.c_char * 512), ("n_regex", C.c_int32), ("reserved2", C.c_int32), ("regex", Regex * 2)]
 
 
 class RunStats(C.Structure):
@@ -65,7 +74,7 @@ class Batch(C.Structure):
 
 EXPORTS = [
     "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
-    "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_set_params",
+    "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_regex_search", "sbx_set_params",
     "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_window_stats",
     "sbx_format_base_rows", "sbx_plan_batches", "sbx_run_batch", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
 ]
@@ -145,6 +154,18 @@ def inflate_blocks(comp, comp_off, comp_len, isize, out_off, out_size):
     if rc != 0:
         raise SbxError(rc, err.value.decode())
     return out
+
+
+def regex_search(pattern, text, options=""):
+    """Host-side evaluation of `text =~ /pattern/options` with the NFA the device runs (sbx_regex_search)."""
+    L = lib()
+    L.sbx_regex_search.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    err = C.create_string_buffer(512)
+    data = text if isinstance(text, bytes) else text.encode()
+    rc = L.sbx_regex_search(pattern.encode(), options.encode(), data, len(data), err, 512)
+    if rc < 0:
+        raise SbxError(rc, err.value.decode())
+    return bool(rc)
 
 
 def compile_filter(query):

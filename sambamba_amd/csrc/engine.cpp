@@ -80,6 +80,7 @@ struct sbx_ctx {
     DevBuf<uint32_t> d_counters, d_span;
     DevBuf<uint32_t> d_covm, d_addm;     // per-column quantities of region/window runs with --fix-mate-overlaps
     DevBuf<DeviceFilter> d_filter;
+    DevBuf<uint8_t> d_ref_sets;
     DevBuf<char> d_rg_ids;
     DevBuf<uint32_t> d_rg_off;
     DevBuf<uint16_t> d_rg_sample;
@@ -354,6 +355,24 @@ int sbx_compile_filter(const char* query, sbx_filter* out, char* err, size_t err
     }
 }
 
+int sbx_regex_search(const char* pattern, const char* options, const char* text, size_t n, char* err, size_t errlen) {
+    if (!pattern || (!text && n)) return SBX_EINVAL;
+    try {
+        bool icase = false;
+        for (const char* o = options; o && *o; ++o) {
+            if (*o == 'i') icase = true;
+            else throw Error(SBX_EUNSUPPORTED, std::string("filter: regular expression option '") + *o + "' is not supported on the device path");
+        }
+        sbx_regex re;
+        RegexCompiler rc(pattern, icase, &re);
+        rc.compile();
+        return re_search(re, (uint32_t)n, [&](uint32_t k) { return (uint8_t)text[k]; }) ? 1 : 0;
+    } catch (const Error& e) {
+        set_err(err, errlen, e.what());
+        return e.code;
+    }
+}
+
 int sbx_set_filter(sbx_ctx* c, const sbx_filter* f) {
     if (!c || !f || f->n_ops < 0 || f->n_ops > SBX_FILTER_MAX_OPS) return SBX_EINVAL;
     for (sbx_ctx* m : files_of(c)) { m->filter = *f; m->have_run = false; }
@@ -621,9 +640,24 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         df.n_ops = c->filter.n_ops;
         memcpy(df.ops, c->filter.ops, sizeof(sbx_filter_op) * (size_t)c->filter.n_ops);
         memcpy(df.strings, c->filter.strings, sizeof df.strings);
+        memcpy(df.regex, c->filter.regex, sizeof df.regex);
+        df.n_ref = n_ref;
+        std::vector<uint8_t> ref_sets;
         for (int i = 0; i < df.n_ops; ++i) {
             // ref_name / mate_ref_name == 'x' becomes a comparison of the reference id ("*" is the name of id -1)
             sbx_filter_op& o = df.ops[i];
+            if (o.kind == 15 && o.field >= 4) {
+                // ref_name =~ /re/: one byte per reference id + 1 ("*", the name of id -1, first)
+                const sbx_regex& re = df.regex[o.value & 1];
+                const size_t at0 = ref_sets.size();
+                auto hit = [&](const std::string& nm) { return re_search(re, (uint32_t)nm.size(), [&](uint32_t k) { return (uint8_t)nm[k]; }) ? 1 : 0; };
+                ref_sets.push_back((uint8_t)hit("*"));
+                for (auto& r : c->hdr.refs) ref_sets.push_back((uint8_t)hit(r.name));
+                o.kind = 16;
+                o.field = (uint8_t)(o.field - 4);
+                o.value = (int64_t)at0;
+                continue;
+            }
             if (o.kind != 11) continue;
             const size_t off = (size_t)(o.value & 0xFFFFFFFF), len = (size_t)(o.value >> 32);
             const std::string name(df.strings + std::min(off, sizeof df.strings), std::min(len, sizeof df.strings - std::min(off, sizeof df.strings)));
@@ -633,7 +667,11 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
             o.field = o.field ? 4 : 0;
             o.value = id;
         }
+        c->d_ref_sets.ensure(ref_sets.size() + 1);
+        if (!ref_sets.empty()) SBX_HIP(hipMemcpyAsync(c->d_ref_sets.p, ref_sets.data(), ref_sets.size(), hipMemcpyHostToDevice, s));
+        df.ref_sets = c->d_ref_sets.p;
         SBX_HIP(hipMemcpyAsync(c->d_filter.p, &df, sizeof df, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipStreamSynchronize(s));      // df / ref_sets are locals
         RgTable rg{nullptr, nullptr, nullptr, 0, 0};
         std::string ids;
         std::vector<uint32_t> id_off;

@@ -23,6 +23,8 @@
 
 #include "common.hpp"
 
+#include "regex_nfa.hpp"
+
 namespace sbx {
 
 inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -438,6 +440,36 @@ private:
         return r;
     }
     size_t pool_ = 0;
+    // `=~ /pattern/options` after a string field or a tag (queryparser.d:427-476): emits a REGEX op
+    bool regex_condition(uint8_t field, uint32_t key) {
+        skip();
+        if (s_.compare(p_, 2, "=~") != 0) return false;
+        p_ += 2;
+        skip();
+        if (p_ >= s_.size() || s_[p_] != '/') throw Error(SBX_EUNSUPPORTED, "filter: regular expression literal /.../ expected after =~");
+        size_t i = p_ + 1;
+        std::string pat;
+        for (;; ++i) {
+            if (i >= s_.size()) throw Error(SBX_EUNSUPPORTED, "filter: unterminated regular expression");
+            if (s_[i] == '\\' && i + 1 < s_.size() && s_[i + 1] == '/') { pat += "\\/"; ++i; continue; }
+            if (s_[i] == '/') break;
+            pat.push_back(s_[i]);
+        }
+        ++i;
+        bool icase = false;
+        while (i < s_.size() && !isspace((unsigned char)s_[i]) && s_[i] != ')') {
+            if (s_[i] == 'i') icase = true;
+            else throw Error(SBX_EUNSUPPORTED, std::string("filter: regular expression option '") + s_[i] + "' is not supported on the device path");
+            ++i;
+        }
+        p_ = i;
+        if (out_->n_regex >= SBX_FILTER_REGEXES) throw Error(SBX_EUNSUPPORTED, "filter: more than two regular expressions");
+        RegexCompiler rc(pat, icase, &out_->regex[out_->n_regex]);
+        rc.compile();
+        emit(15, key, field, 0, out_->n_regex);
+        out_->n_regex += 1;
+        return true;
+    }
     int cmp_op() {      // 0 > 1 < 2 >= 3 <= 4 == 5 !=, or -1
         static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
         static const int opid[] = {2, 3, 4, 5, 0, 1};
@@ -491,6 +523,7 @@ private:
             }
         // string fields (StringFieldFilter, filtering.d:255-273)
         if (eat("read_name", true)) {
+            if (regex_condition(0, 0)) return;
             const int op = cmp_op();
             if (op < 0) throw Error(SBX_EUNSUPPORTED, "filter: regex conditions are outside the device-compilable subset");
             emit(10, 0, 0, (uint8_t)op, string_literal());
@@ -498,6 +531,7 @@ private:
         }
         for (int which = 0; which < 2; ++which)
             if (eat(which ? "cigar" : "sequence", true)) {      // compared as text (cmp(a.sequence, v), a.cigarString())
+                if (regex_condition((uint8_t)(1 + which), 0)) return;
                 const int op = cmp_op();
                 if (op < 0) throw Error(SBX_EUNSUPPORTED, "filter: regex conditions are outside the device-compilable subset");
                 emit((uint8_t)(13 + which), 0, 0, (uint8_t)op, string_literal());
@@ -505,6 +539,7 @@ private:
             }
         for (int which = 0; which < 2; ++which)
             if (eat(which ? "mate_ref_name" : "ref_name", true)) {
+                if (regex_condition((uint8_t)(4 + which), 0)) return;
                 const int op = cmp_op();
                 if (op != 4 && op != 5) throw Error(SBX_EUNSUPPORTED, "filter: reference names can be compared with == and != on the device path");
                 emit(11, 0, (uint8_t)which, (uint8_t)op, string_literal());
@@ -526,6 +561,7 @@ private:
             if (p_ + 3 > s_.size() || s_[p_ + 2] != ']') throw Error(SBX_EUNSUPPORTED, "filter: tag name of two characters expected");
             const uint32_t key = (uint8_t)s_[p_] | ((uint32_t)(uint8_t)s_[p_ + 1] << 8);
             p_ += 3;
+            if (regex_condition(3, key)) return;
             static const char* ops[] = {">=", "<=", "==", "!=", ">", "<"};
             static const uint8_t opid[] = {2, 3, 4, 5, 0, 1};
             for (int k = 0; k < 6; ++k)

@@ -23,6 +23,7 @@
 // and the [lo,hi) record range of every position tile the record overlaps.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "regex_nfa.hpp"
 
 #include <algorithm>
 
@@ -418,6 +419,47 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
                 }
                 if (c == 0 && k < nl) c = -1;
                 v = cmp_op<int>(op.cmp, c, 0);
+                break;
+            }
+            case 15: {    // RegexpFieldFilter / RegexpTagFilter (filtering.d:299-345): does the pattern match anywhere?
+                const sbx_regex& re = f->regex[op.value & 1];
+                const uint32_t l_name = bmn & 0xFF, n_cigar = fnc & 0xFFFF;
+                if (op.field == 0) {
+                    const uint8_t* nm = p + 32;
+                    v = re_search(re, l_name ? l_name - 1 : 0, [&](uint32_t i) { return nm[i]; });
+                } else if (op.field == 1) {
+                    const uint8_t* sq = p + 32 + l_name + 4 * n_cigar;
+                    v = re_search(re, l_seq > 0 ? (uint32_t)l_seq : 0u, [&](uint32_t i) {
+                        const uint32_t nib = (i & 1u) ? (sq[i >> 1] & 15u) : (sq[i >> 1] >> 4);
+                        return (uint8_t)"=ACMGRSVTWYHKDBN"[nib];
+                    });
+                } else if (op.field == 2) {
+                    // cigarString(), generated character by character (the search reads positions in order)
+                    const uint8_t* cg = p + 32 + l_name;
+                    uint32_t total = 0;
+                    for (uint32_t i = 0; i < n_cigar; ++i) { uint32_t len = ld32(cg + 4 * i) >> 4; do { ++total; len /= 10; } while (len); ++total; }
+                    uint32_t oi = 0, div = 0;     // current op, divisor of its next digit (0: none left, the op character is next)
+                    bool fresh = true;
+                    v = re_search(re, total, [&](uint32_t) {
+                        const uint32_t raw = ld32(cg + 4 * oi), len = raw >> 4;
+                        if (fresh) { div = 1; while (len / div >= 10) div *= 10; fresh = false; }
+                        if (div) { const uint8_t ch = (uint8_t)('0' + (len / div) % 10); div /= 10; return ch; }
+                        ++oi; fresh = true;
+                        return (uint8_t)((raw & 15u) < 9 ? "MIDNSHP=X"[raw & 15u] : '?');
+                    });
+                } else if (op.field == 3) {
+                    const uint8_t* tv = nullptr;
+                    if (find_tag(tags, tags_end, op.mask, &tv) == 'Z') {
+                        uint32_t n = 0;
+                        while (tv + n < tags_end && tv[n]) ++n;
+                        v = re_search(re, n, [&](uint32_t i) { return tv[i]; });
+                    } else v = false;
+                } else v = false;
+                break;
+            }
+            case 16: {    // a regular expression on ref_name / mate_ref_name: evaluated per reference on the host
+                const int32_t id = op.field ? (int32_t)ld32(p + 20) : ref;
+                v = id >= -1 && id < f->n_ref && f->ref_sets[(uint32_t)op.value + (uint32_t)(id + 1)] != 0;
                 break;
             }
             case 12: v = false; break;

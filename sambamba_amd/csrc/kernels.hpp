@@ -50,6 +50,9 @@ struct DeviceFilter {       // compiled -F program (sbx_filter), evaluated per r
     int32_t n_ops;
     sbx_filter_op ops[SBX_FILTER_MAX_OPS];
     char strings[SBX_FILTER_STRINGS];
+    sbx_regex regex[SBX_FILTER_REGEXES];
+    const uint8_t* ref_sets;    // REFSET ops: one byte per reference id + 1 ("*" = id -1 first), at op.value
+    int32_t n_ref;
 };
 
 struct RefTable {           // per-reference device arrays

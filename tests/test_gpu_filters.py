@@ -81,6 +81,23 @@ def test_avg_base_quality(flt, bam):
     assert run_cli(args, cwd=GOLDEN) == run_oracle(args, cwd=GOLDEN)
 
 
-def test_regex_filter_is_reported_unsupported(tagged):
-    r = run_cli(["base", "-F", "read_name =~ /^r1/", tagged], check=False)
-    assert r.returncode != 0 and b"device-compilable subset" in r.stderr
+@pytest.mark.parametrize("flt", [
+    "read_name =~ /^r1_/", "read_name =~ /_1[0-5]$/", "not (read_name =~ /^r[0-2]/)", "read_name =~ /R3_/i", "[RG] =~ /^g/",
+    "[NM] =~ /7/", "[XS] =~ /q/", "[ZZ] =~ /./", "cigar =~ /^40M$/", "cigar =~ /S/", "sequence =~ /^(ACGT)+$/", "sequence =~ /TT/",
+    "ref_name =~ /^c[0-9]$/", "ref_name =~ /x/", "mate_ref_name =~ /^\\*$/", "read_name =~ /^r[0-9]+_(3|5)$/ and [NM] != null",
+])
+def test_regex_filters_synthetic(tagged, flt):
+    args = ["base", "-F", flt, tagged]
+    assert run_cli(args) == run_oracle(args)
+
+
+@pytest.mark.parametrize("flt", ["read_name =~ /:1[0-9]{3}:/", "cigar =~ /[IDS]/ and ref_name =~ /^[0-9]+$/", "[MD] =~ /^[0-9]+$/",
+                                 "sequence =~ /^[ACGT]+$/i and not (cigar =~ /^101M$/)"])
+def test_regex_filters_reference_fixture(flt):
+    args = ["base", "-F", flt, "issue_204.bam"]
+    assert run_cli(args, cwd=GOLDEN) == run_oracle(args, cwd=GOLDEN)
+
+
+def test_unsupported_regex_is_reported(tagged):
+    r = run_cli(["base", "-F", "read_name =~ /(r)\\1/", tagged], check=False)
+    assert r.returncode != 0 and b"back-references" in r.stderr
