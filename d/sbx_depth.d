@@ -43,6 +43,7 @@ extern (C) nothrow @nogc {
     int sbx_run_batch(sbx_ctx*, uint first_ref, uint n_refs);
     int sbx_depth_base_tile(sbx_ctx*, uint ref_id, uint beg, uint end, uint* counters, ubyte* covered);
     int sbx_depth_region_stats(sbx_ctx*, const(sbx_region)*, size_t, sbx_region_stats*, uint* cov_counts, ubyte* seen);
+    int sbx_depth_region_stats_from(sbx_ctx*, const(sbx_region)*, size_t, const(uint)* min_start, sbx_region_stats*, uint* cov_counts, ubyte* seen);
     int sbx_depth_window_stats(sbx_ctx*, uint ref_id, ulong first_win, ulong n_win, sbx_region_stats*, uint* cov_counts);
     int sbx_format_base_rows(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
                              char* out_buf, size_t cap, size_t* out_len);

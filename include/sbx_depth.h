@@ -211,6 +211,13 @@ int sbx_depth_base_tile(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, u
 int sbx_depth_region_stats(sbx_ctx*, const sbx_region* raw_regions, size_t n_regions,
                            sbx_region_stats* stats, uint32_t* cov_counts, uint8_t* seen);
 
+/* The same with a per-region lower bound on the read start (min_start[r] != 0: only reads with position >= min_start[r]
+ * are counted for region r, n_bases being the sum over those reads).  This is what the reference's first ring of
+ * OVERLAPPING windows computes (is_first_occurrence starts out false, depth.d:1031-1032): the host composes
+ * `window --overlap` from this call and plain region statistics (cli.cpp WindowPrinter). */
+int sbx_depth_region_stats_from(sbx_ctx*, const sbx_region* raw_regions, size_t n_regions, const uint32_t* min_start,
+                                sbx_region_stats* stats, uint32_t* cov_counts, uint8_t* seen);
+
 /* depth window: the same for windows [k*step, k*step + window) of ref_id, k in
  * [first_win, first_win + n_win) (PerWindowPrinter, depth.d:933-1077). */
 int sbx_depth_window_stats(sbx_ctx*, uint32_t ref_id, uint64_t first_win, uint64_t n_win,

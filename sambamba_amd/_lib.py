@@ -75,7 +75,8 @@ class Batch(C.Structure):
 EXPORTS = [
     "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
     "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_regex_search", "sbx_set_params",
-    "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_window_stats",
+    "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_region_stats_from",
+    "sbx_depth_window_stats",
     "sbx_format_base_rows", "sbx_plan_batches", "sbx_run_batch", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
 ]
 

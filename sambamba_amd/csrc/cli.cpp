@@ -136,6 +136,8 @@ bool parse_args(int argc, char** argv, Options* o, std::string* err) {
     return true;
 }
 
+constexpr size_t kMaxCliThresholds = 64;
+
 struct Out {
     FILE* fp = stdout;
     std::string buf;
@@ -497,7 +499,18 @@ bool first_column(sbx_ctx* c, int r0, int r1, int* ref_out, uint64_t* pos_out) {
     return false;
 }
 
-// PerWindowPrinter (depth.d:933-1077), overlap == 0; fed one batch of contigs at a time
+// PerWindowPrinter (depth.d:933-1077), fed one batch of contigs at a time.  Windows k = [k*step, k*step + w),
+// step = w - overlap, live in a ring of n = ceil(w / step) slots in the reference; what it prints is, per window:
+//   * n_reads / n_bases of the window as a region -- except in the FIRST ring of the run (windows 1 .. n-1 of contig 0
+//     when the first pileup column lies on it): is_first_occurrence starts out false there (depth.d:1031-1032), so only
+//     reads starting inside the window are counted;
+//   * coverage thresholds over the columns in [cs, k*step + w), cs = (k - n)*step + w for k >= n: every column updates
+//     all n slots of the ring (depth.d:215-226), including a slot whose window has not begun when w is not a multiple
+//     of the step;
+//   * all k with k*step + w <= length for a contig with columns, length / step all-zero windows for a read-less contig;
+//     nothing for windows finished before the first column of the run (the sample list does not exist yet);
+//   * the first read-less contig AFTER the last contig with columns continues that contig's window coordinates and
+//     shows the statistics its unfinished windows held: close() does not reset the ring (depth.d:1070-1076).
 struct WindowPrinter {
     sbx_ctx* c;
     const Options& o;
@@ -506,37 +519,143 @@ struct WindowPrinter {
     bool have_first = false;     // the first pileup column of the whole run has been seen
     int fref = 0;
     uint64_t fpos = 0;
+    int last_cols_ref = -1;      // the last contig with columns so far, the number of windows it printed,
+    uint64_t last_nl = 0;
+    std::vector<sbx_region_stats> stale_st;      // and what its n unfinished windows hold
+    std::vector<uint32_t> stale_cov;
+    std::vector<int> pending_empty;              // read-less contigs seen since
 
+    uint32_t S() const { return o.combined ? 1u : (uint32_t)samples.size(); }
+    uint64_t step() const { return (uint64_t)o.window - (uint64_t)o.overlap; }
+    uint64_t ring() const { return ((uint64_t)o.window + step() - 1) / step(); }
+
+    // statistics of windows [k0, k1) of contig r (st: [k][S], cov: [k][S][n_thr])
+    void window_stats(int r, uint64_t k0, uint64_t k1, std::vector<sbx_region_stats>& st, std::vector<uint32_t>& cov) {
+        const uint32_t s_n = S();
+        const size_t n_thr = o.thresholds.size(), cstride = std::max<size_t>(1, n_thr);
+        const uint64_t w = o.window, st_ = step(), n = ring();
+        st.assign((size_t)(k1 - k0) * s_n, sbx_region_stats{0, 0});
+        cov.assign((size_t)(k1 - k0) * s_n * cstride, 0);
+        if (k1 <= k0) return;
+        const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r));
+        if (o.overlap == 0 && k1 * w <= len) {      // full, disjoint windows: the engine's own window statistics
+            check(c, sbx_depth_window_stats(c, (uint32_t)r, k0, k1 - k0, st.data(), cov.data()));
+            return;
+        }
+        // the first ring of the run
+        const uint64_t anom_from = (r == 0 && fref == 0) ? (fpos < w ? 0 : (fpos - w) / st_ + 1) : n;
+        std::vector<sbx_region> reg, creg;
+        std::vector<uint32_t> min_start;
+        bool any_min = false, extended = false;
+        for (uint64_t k = k0; k < k1; ++k) {
+            reg.push_back({(uint32_t)r, (uint32_t)(k * st_), (uint32_t)(k * st_ + w)});
+            const bool anom = k >= 1 && k >= anom_from && k < n;
+            min_start.push_back(anom ? (uint32_t)(k * st_) : 0u);
+            any_min |= anom;
+            const uint64_t cs = k < n ? k * st_ : (k - n) * st_ + w;
+            extended |= cs != k * st_;
+            creg.push_back({(uint32_t)r, (uint32_t)cs, (uint32_t)(k * st_ + w)});
+        }
+        std::vector<uint8_t> seen(reg.size());
+        std::vector<uint32_t> cov1(reg.size() * s_n * cstride);
+        if (any_min) check(c, sbx_depth_region_stats_from(c, reg.data(), reg.size(), min_start.data(), st.data(), cov1.data(), seen.data()));
+        else check(c, sbx_depth_region_stats(c, reg.data(), reg.size(), st.data(), cov1.data(), seen.data()));
+        if (extended && n_thr) {
+            std::vector<sbx_region_stats> st2(reg.size() * s_n);
+            check(c, sbx_depth_region_stats(c, creg.data(), creg.size(), st2.data(), cov1.data(), seen.data()));
+        }
+        for (size_t i = 0; i < reg.size() * s_n; ++i)
+            for (size_t t = 0; t < n_thr; ++t) cov[i * cstride + t] = cov1[i * n_thr + t];
+    }
+    void rows(const std::string& name, uint64_t start, const sbx_region_stats* st, const uint32_t* cov) {
+        const std::string prefix = name + "\t" + std::to_string(start) + "\t" + std::to_string(start + o.window) + "\t";
+        static const sbx_region_stats zero{0, 0};
+        static const uint32_t zcov[kMaxCliThresholds] = {0};
+        const size_t cstride = std::max<size_t>(1, o.thresholds.size());
+        for (uint32_t s2 = 0; s2 < S(); ++s2)
+            print_region_row(out, o, prefix, (uint32_t)o.window, st ? st[s2] : zero, cov ? cov + s2 * cstride : zcov, samples[s2]);
+    }
+    void zero_windows(int r) {       // printEmptyWindows (depth.d:1039-1044)
+        const uint64_t cnt = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r)) / step();
+        const std::string name = sbx_ref_name(c, r);
+        for (uint64_t k = 0; k < cnt; ++k) rows(name, k * step(), nullptr, nullptr);
+    }
+    // position of the last pileup column of contig r (it has one)
+    uint64_t last_column(int r) {
+        uint64_t from = 0, lb = 0, le = 0;
+        for (;;) {
+            uint64_t b, e;
+            check(c, sbx_next_active_range(c, (uint32_t)r, from, &b, &e));
+            if (b == ~0ULL) break;
+            lb = b; le = e; from = e;
+        }
+        uint32_t T = 0, Sn = 0;
+        check(c, sbx_tile_info(c, &T, &Sn));
+        std::vector<uint32_t> cnt;
+        std::vector<uint8_t> cov;
+        for (uint64_t q = le; q > lb;) {
+            const uint64_t p = q > lb + 65536 ? q - 65536 : lb;
+            cnt.resize((size_t)(q - p) * Sn * SBX_NCOUNTERS);
+            cov.resize((size_t)(q - p));
+            check(c, sbx_depth_base_tile(c, (uint32_t)r, (uint32_t)p, (uint32_t)q, cnt.data(), cov.data()));
+            for (uint64_t x = q; x > p; --x) if (cov[(size_t)(x - 1 - p)]) return x - 1;
+            q = p;
+        }
+        return 0;
+    }
+    void contig(int r) {
+        const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r)), w = o.window;
+        // windows are finished as the columns advance (push) and then up to the contig's length (close / contig change):
+        // alignments hanging over the end of the contig can finish windows that end beyond it
+        const uint64_t lastcol = last_column(r);
+        const uint64_t nw = std::max<uint64_t>(len >= w ? (len - w) / step() + 1 : 0, lastcol >= w ? (lastcol - w) / step() + 1 : 0);
+        const std::string name = sbx_ref_name(c, r);
+        const size_t cstride = std::max<size_t>(1, o.thresholds.size());
+        std::vector<sbx_region_stats> st;
+        std::vector<uint32_t> cov;
+        const uint64_t CH = 1u << 18;
+        for (uint64_t k0 = 0; k0 < nw; k0 += CH) {
+            const uint64_t k1 = std::min(nw, k0 + CH);
+            window_stats(r, k0, k1, st, cov);
+            for (uint64_t k = k0; k < k1; ++k) {
+                if (r == fref && k * step() + w <= fpos) continue;       // finished before the first column of the run
+                rows(name, k * step(), &st[(size_t)(k - k0) * S()], &cov[(size_t)(k - k0) * S() * cstride]);
+            }
+        }
+        // what the ring still holds when this contig ends
+        last_cols_ref = r;
+        last_nl = nw;
+        window_stats(r, nw, nw + ring(), stale_st, stale_cov);
+    }
     void run_refs(int r0, int r1) {
-        const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
-        const size_t n_thr = o.thresholds.size();
+        if (o.overlap > 0 && o.fix_mate) throw Fail{"--fix-mate-overlaps with --overlap > 0 is not supported on the device path"};
         if (!have_first) {
             if (!first_column(c, r0, r1, &fref, &fpos)) return;   // no column yet: windows so far print nothing
             have_first = true;
         }
-        const uint64_t w = o.window;
-        std::vector<sbx_region_stats> st;
-        std::vector<uint32_t> cov;
         for (int r = std::max(r0, fref); r < r1; ++r) {
-            const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r));
-            const uint64_t n_full = len / w;
-            if (!n_full) continue;
-            const std::string name = sbx_ref_name(c, r);
-            const uint64_t CH = 1u << 18;
-            for (uint64_t k0 = 0; k0 < n_full; k0 += CH) {
-                const uint64_t k1 = std::min(n_full, k0 + CH);
-                st.assign((size_t)(k1 - k0) * S, sbx_region_stats{0, 0});
-                cov.assign((size_t)(k1 - k0) * S * std::max<size_t>(1, n_thr), 0);
-                check(c, sbx_depth_window_stats(c, (uint32_t)r, k0, k1 - k0, st.data(), cov.data()));
-                for (uint64_t k = k0; k < k1; ++k) {
-                    // windows finished before the first column of the run print nothing (samples not created yet)
-                    if (r == fref && (k + 1) * w <= fpos) continue;
-                    std::string prefix = name + "\t" + std::to_string(k * w) + "\t" + std::to_string((k + 1) * w) + "\t";
-                    for (uint32_t s = 0; s < S; ++s)
-                        print_region_row(out, o, prefix, (uint32_t)w, st[(size_t)(k - k0) * S + s],
-                                         &cov[((size_t)(k - k0) * S + s) * n_thr], samples[s]);
+            uint64_t b0 = 0, e0 = 0;
+            check(c, sbx_next_active_range(c, (uint32_t)r, 0, &b0, &e0));
+            if (b0 == ~0ULL) { pending_empty.push_back(r); continue; }
+            for (int e : pending_empty) zero_windows(e);      // read-less contigs between two with columns: push() resets first
+            pending_empty.clear();
+            contig(r);
+        }
+    }
+    void finish() {
+        if (!have_first) return;
+        bool first = true;
+        const size_t cstride = std::max<size_t>(1, o.thresholds.size());
+        for (int e : pending_empty) {
+            if (first && last_cols_ref >= 0) {
+                const uint64_t cnt = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, e)) / step();
+                const std::string name = sbx_ref_name(c, e);
+                for (uint64_t i = 0; i < cnt; ++i) {
+                    if (i < ring()) rows(name, (last_nl + i) * step(), &stale_st[(size_t)i * S()], &stale_cov[(size_t)i * S() * cstride]);
+                    else rows(name, (last_nl + i) * step(), nullptr, nullptr);
                 }
-            }
+            } else zero_windows(e);
+            first = false;
         }
     }
 };
@@ -696,7 +815,7 @@ int depth_main(int argc, char** argv) {
         if (n_batches) check(ctx, sbx_plan_batches(ctx, budget, plan.data(), plan.size(), &n_batches));
         BasePrinter bp(ctx, o, out, samples);
         if (o.mode == "base" && o.has_regions) bp.set_bed(merged);
-        WindowPrinter wp{ctx, o, out, samples};
+        WindowPrinter wp{ctx, o, out, samples, false, 0, 0, -1, 0, {}, {}, {}};
         RegionPrinter rp{ctx, o, out, samples, raw, raw_lines, {}, {}, {}};
         for (auto& b : plan) {
             if (plan.size() == 1) check(ctx, sbx_run(ctx));
@@ -708,6 +827,7 @@ int depth_main(int argc, char** argv) {
             else bp.run_refs(r0, r1);
         }
         if (o.mode == "region") rp.finish();
+        else if (o.mode == "window") wp.finish();
         else if (o.mode == "base") bp.finish();
         out.flush();
         if (out.fp != stdout) fclose(out.fp);

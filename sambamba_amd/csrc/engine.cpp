@@ -985,9 +985,11 @@ int sbx_depth_base_tile(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end,
 
 // Shared implementation of region / window statistics over an explicit list of ranges.
 // ranges[i] gets id i; stats/cov are [i][S] / [i][S][n_thr]; seen[i] (optional).
+// min_start (optional, per range): != 0 -> only reads starting at or after it are counted for that range, and its
+// n_bases is the sum over those reads instead of the sum over the position counters.
 static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool windows, uint32_t window,
                         const std::vector<uint64_t>& win_base, const std::vector<uint64_t>& n_win, sbx_region_stats* stats,
-                        uint32_t* cov_counts, uint8_t* seen) {
+                        uint32_t* cov_counts, uint8_t* seen, const uint32_t* min_start = nullptr) {
     if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
     SBX_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -1001,7 +1003,9 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
     const uint32_t CH = 16384;
     for (size_t i = 0; i < n; ++i)
         for (uint64_t p = ranges[i].start; p < ranges[i].end; p += CH)
-            chunks.push_back({ranges[i].ref_id, (uint32_t)p, (uint32_t)std::min<uint64_t>(ranges[i].end, p + CH), (uint32_t)i});
+            chunks.push_back({ranges[i].ref_id, (uint32_t)p, (uint32_t)std::min<uint64_t>(ranges[i].end, p + CH),
+                              (uint32_t)i | ((min_start && min_start[i]) ? 0x40000000u : 0u)});
+    if (n > 0x3FFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "too many regions / windows");
     DevBuf<RangeChunk> d_chunks(chunks.size() + 1);
     DevBuf<uint32_t> d_nb(n * S + 1), d_nr(n * S + 1), d_cov(n * S * std::max<uint32_t>(1, n_thr) + 1), d_seen(n + 1), d_thr(n_thr + 1);
     if (!chunks.empty()) SBX_HIP(hipMemcpyAsync(d_chunks.p, chunks.data(), chunks.size() * sizeof(RangeChunk), hipMemcpyHostToDevice, s));
@@ -1063,7 +1067,8 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
         SBX_HIP(hipMemcpyAsync(d_unfirst.p, un_first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
         for (sbx_ctx* f : files)
             launch_count_reads_mates(f->U(), f->d_desc.p, records_of(f), f->d_rec_ref.p, f->d_mate.p, d_regs2.p, d_pmax2.p, d_first2.p,
-                                     d_un.p, d_unfirst.p, windows, d_firstcol.p, S, c->min_bq, d_nb.p, d_nr.p, s);
+                                     d_un.p, d_unfirst.p, windows || c->mode == SBX_MODE_WINDOW /* every column lies in some window */, d_firstcol.p, S,
+                                     c->min_bq, d_nb.p, d_nr.p, s);
         SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
     } else {
     launch_range_reduce(d_chunks.p, (uint32_t)chunks.size(), c->d_counters.p, c->span_valid ? c->d_span.p : nullptr, c->d_slot_of.p,
@@ -1109,9 +1114,15 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
             SBX_HIP(hipMemcpyAsync(d_pmax.p, pmax.data(), n * 4, hipMemcpyHostToDevice, s));
         }
         SBX_HIP(hipMemcpyAsync(d_first.p, first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+        DevBuf<uint32_t> d_min_start;
+        if (min_start) {
+            if (c->fix_mate) throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps together with overlapping windows is not on the device path");
+            d_min_start.alloc(n + 1);
+            if (n) SBX_HIP(hipMemcpyAsync(d_min_start.p, min_start, n * 4, hipMemcpyHostToDevice, s));
+        }
         for (sbx_ctx* f : files)
             launch_count_reads_regions(f->U(), f->d_desc.p, records_of(f), f->d_rec_ref.p, d_regs.p, d_pmax.p, d_first.p, S, c->min_bq,
-                                       d_nr.p, s);
+                                       d_nr.p, min_start ? d_min_start.p : nullptr, d_nb.p, s);
         SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
     }
     }
@@ -1139,6 +1150,19 @@ int sbx_depth_region_stats(sbx_ctx* c, const sbx_region* raw, size_t n, sbx_regi
             if (r.end < r.start) r.end = r.start;
         }
         range_stats(c, ranges, false, 0, {}, {}, stats, cov_counts, seen);
+    });
+}
+
+int sbx_depth_region_stats_from(sbx_ctx* c, const sbx_region* raw, size_t n, const uint32_t* min_start, sbx_region_stats* stats,
+                                uint32_t* cov_counts, uint8_t* seen) {
+    return guarded(c, [&] {
+        if (!c || (!raw && n) || !stats) throw Error(SBX_EINVAL, "null argument");
+        std::vector<sbx_region> ranges(raw, raw + n);
+        for (auto& r : ranges) {
+            if (r.ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
+            if (r.end < r.start) r.end = r.start;
+        }
+        range_stats(c, ranges, false, 0, {}, {}, stats, cov_counts, seen, min_start);
     });
 }
 

@@ -146,7 +146,8 @@ void launch_count_reads_windows(const uint8_t* d_U, const RecDesc* d_desc, uint6
                                 uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);
 void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
                                 const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first, uint32_t S,
-                                uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);
+                                uint32_t min_bq, uint32_t* d_n_reads, const uint32_t* d_min_start, uint32_t* d_n_bases,
+                                hipStream_t stream);
 
 // region / window statistics with --fix-mate-overlaps (mates.hip: per-column quantities; reduce.hip: the rest)
 void launch_mates_columns(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,

@@ -42,7 +42,9 @@ __global__ __launch_bounds__(kRedThreads) void k_range_reduce(
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t ci = blockIdx.x * (kRedThreads / 64) + wv;
     if (ci >= n_chunks) return;
-    const RangeChunk ch = chunks[ci];
+    RangeChunk ch = chunks[ci];
+    const bool no_bases = (ch.id >> 30) & 1u;     // n_bases of this range is gathered per read (count_reads with min_start)
+    ch.id &= 0x3FFFFFFFu;
     const uint32_t tb = tile_base[ch.ref_id];
     const uint32_t t_end = tile_base[ch.ref_id + 1];
     const uint32_t row = S * 7;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(kRedThreads) void k_range_reduce(
                 if ((uint32_t)t < n_thr && cov >= thresholds[t]) cc[t] += 1;
         }
         nb = wave_sum(nb);
-        if (lane == 0 && nb) atomicAdd(&n_bases[(size_t)ch.id * S + s], nb);
+        if (lane == 0 && nb && !no_bases) atomicAdd(&n_bases[(size_t)ch.id * S + s], nb);
 #pragma unroll
         for (int t = 0; t < kMaxThresholds; ++t) {
             if ((uint32_t)t < n_thr) {
@@ -80,6 +82,8 @@ __global__ __launch_bounds__(kRedThreads) void k_range_reduce(
     const uint64_t am = __ballot(any != 0);
     if (lane == 0 && am) seen[ch.id] = 1;
 }
+
+__device__ uint32_t count_good(const uint8_t* U, const RecDesc& d, uint32_t min_bq, int64_t lo, int64_t hi);
 
 // does the read have an M/=/X base with quality >= min_bq at a reference position inside [rs, re)?
 // (countOverlappingBases > 0, depth.d:671-698; zero-length reference-consuming ops occupy one column,
@@ -146,7 +150,8 @@ __global__ __launch_bounds__(kRedThreads) void k_count_reads_windows(
 __global__ __launch_bounds__(kRedThreads) void k_count_reads_regions(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, uint64_t n_records, const int32_t* __restrict__ rec_ref,
     const SortedRegion* __restrict__ regs, const uint32_t* __restrict__ pmax_end, const uint32_t* __restrict__ ref_first /*[n_ref+1]*/,
-    uint32_t S, uint32_t min_bq, uint32_t* n_reads /*[id][S]*/) {
+    uint32_t S, uint32_t min_bq, uint32_t* n_reads /*[id][S]*/, const uint32_t* __restrict__ min_start /*[id] or nullptr*/,
+    uint32_t* n_bases /*[id][S], for ranges with min_start != 0*/) {
     const uint64_t i = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x;
     if (i >= n_records) return;
     const RecDesc d = desc[i];
@@ -161,9 +166,17 @@ __global__ __launch_bounds__(kRedThreads) void k_count_reads_regions(
     for (uint32_t j = a; j > lo0;) {
         --j;
         if ((int64_t)pmax_end[j] <= (int64_t)d.pos) break;      // nothing at or before j reaches the read
-        if ((int64_t)regs[j].end > (int64_t)d.pos &&
-            has_good_base(U, d, min_bq, (int64_t)regs[j].start, (int64_t)regs[j].end))
+        if ((int64_t)regs[j].end <= (int64_t)d.pos) continue;
+        const uint32_t ms = min_start ? min_start[regs[j].id] : 0u;
+        if (ms) {
+            // a window that only counts the reads starting at or after `ms` (the reference's first ring of overlapping
+            // windows, depth.d:1031-1032): both numbers come from the reads themselves
+            if ((int64_t)d.pos < (int64_t)ms) continue;
+            const uint32_t B = count_good(U, d, min_bq, (int64_t)regs[j].start, (int64_t)regs[j].end);
+            if (B) { atomicAdd(&n_reads[(size_t)regs[j].id * S + s], 1u); atomicAdd(&n_bases[(size_t)regs[j].id * S + s], B); }
+        } else if (has_good_base(U, d, min_bq, (int64_t)regs[j].start, (int64_t)regs[j].end)) {
             atomicAdd(&n_reads[(size_t)regs[j].id * S + s], 1u);
+        }
     }
 }
 
@@ -377,10 +390,12 @@ void launch_count_reads_windows(const uint8_t* d_U, const RecDesc* d_desc, uint6
 
 void launch_count_reads_regions(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
                                 const SortedRegion* d_regs, const uint32_t* d_pmax_end, const uint32_t* d_ref_first, uint32_t S,
-                                uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream) {
+                                uint32_t min_bq, uint32_t* d_n_reads, const uint32_t* d_min_start, uint32_t* d_n_bases,
+                                hipStream_t stream) {
     if (!n_records) return;
     hipLaunchKernelGGL(k_count_reads_regions, dim3((uint32_t)((n_records + kRedThreads - 1) / kRedThreads)), dim3(kRedThreads), 0,
-                       stream, d_U, d_desc, n_records, d_rec_ref, d_regs, d_pmax_end, d_ref_first, S, min_bq, d_n_reads);
+                       stream, d_U, d_desc, n_records, d_rec_ref, d_regs, d_pmax_end, d_ref_first, S, min_bq, d_n_reads, d_min_start,
+                       d_n_bases);
     SBX_HIP(hipGetLastError());
 }
 
