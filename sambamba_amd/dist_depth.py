@@ -7,6 +7,10 @@ own disjoint outputs, so the only exchange is an all-gather of the small per-reg
 never leaves a GPU.  Rank 0 prints exactly what `sbx-depth` prints on one GPU.
 
     python -m torch.distributed.run --nproc-per-node N -m sambamba_amd.dist_depth region -L x.bed -T 10 in.bam
+
+Window mode here covers disjoint windows (no --overlap) of genomes whose read-less contigs, if any, are followed by a
+contig with reads; the ring quirks the single-GPU CLI reproduces for the other cases are not
+replicated in this driver.
 """
 import argparse
 import os
