@@ -49,5 +49,6 @@ def test_sharded_equals_single_gpu_cli(genome, args, world):
         args = [a for a in args if a != "--combined"]      # (undefined in the reference with several samples)
     a = [bed if x == "BED" else x for x in args]
     want = run_cli([a[0]] + a[1:] + [bam])
-    got = run_sharded([a[0], bam] + a[1:], world, 29700 + world)
+    port = 29700 + 10 * world + (sum(map(ord, " ".join(args))) % 10)      # one port per case: no reuse while a socket lingers
+    got = run_sharded([a[0], bam] + a[1:], world, port)
     assert got == want
