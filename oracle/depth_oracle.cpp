@@ -235,7 +235,7 @@ struct FilterNode {
             case TAGSTR: {    // StringTagFilter (filtering.d:276-297)
                 const uint8_t* v = nullptr;
                 char ty = find_tag(r, key[0], key[1], &v);
-                if (ty == 'Z') {
+                if (ty == 'Z' || ty == 'H') {   // Value.is_string: 'Z' or 'H' (tagvalue.d:426-427)
                     const uint8_t* e = v;
                     while (e < r.end() && *e) ++e;
                     return cmp_strs(op, std::string((const char*)v, (size_t)(e - v)), text);
@@ -283,7 +283,8 @@ struct FilterNode {
                     case 5: for (uint32_t i = 0; i < r.n_cigar(); ++i) { t += std::to_string(op_len(r.cigar_op(i))); t.push_back(op_char(r.cigar_op(i))); } break;
                     default: {
                         const uint8_t* v = nullptr;
-                        if (find_tag(r, key[0], key[1], &v) != 'Z') return false;
+                        const char tty = find_tag(r, key[0], key[1], &v);
+                        if (tty != 'Z' && tty != 'H') return false;
                         const uint8_t* e = v;
                         while (e < r.end() && *e) ++e;
                         t.assign((const char*)v, (size_t)(e - v));

@@ -369,7 +369,7 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
                 const uint32_t ty = find_tag(tags, tags_end, op.mask, &tv);
                 const char* lit = f->strings + (uint32_t)(op.value & 0xFFFFFFFF);
                 const uint32_t nl = (uint32_t)(op.value >> 32);
-                if (ty == 'Z') {
+                if (ty == 'Z' || ty == 'H') {     // Value.is_string: 'Z' or 'H' (tagvalue.d:426-427)
                     uint32_t n = 0;
                     while (tv + n < tags_end && tv[n]) ++n;
                     v = cmp_str(op.cmp, tv, n, lit, nl);
@@ -449,7 +449,8 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
                     });
                 } else if (op.field == 3) {
                     const uint8_t* tv = nullptr;
-                    if (find_tag(tags, tags_end, op.mask, &tv) == 'Z') {
+                    const uint32_t tty = find_tag(tags, tags_end, op.mask, &tv);
+                    if (tty == 'Z' || tty == 'H') {
                         uint32_t n = 0;
                         while (tv + n < tags_end && tv[n]) ++n;
                         v = re_search(re, n, [&](uint32_t i) { return tv[i]; });
