@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- `sambamba depth base` hot path on MI355X: BGZF inflate -> BAM record index ->
+"""bench.py -- the `sambamba depth` hot path on MI355X: BGZF inflate -> BAM record index ->
 CIGAR-walk per-position coverage counters, all on the device (libsbx_depth.so).
 
 Contract (driver): python bench.py --gpus N --steps K --warmup W   (N>1: launched under
 torch.distributed.run, one rank per GPU).  One "step" = one full pass of the hot path over the
 synthetic coordinate-sorted BAM of BASELINE.json configs[1] (chr1, L=248,956,422, 30x, 2x150 bp
 paired reads), whose compressed bytes are already resident in HBM when the timed
-region starts.  Each rank processes its own contig-sized BAM (seed + rank): weak scaling, no
-data-path collective (position-sharded outputs are disjoint).
+region starts.
+
+N == 1: the whole BAM on one GPU.  N > 1: ONE BAM sharded over the ranks by reference position
+(sambamba_amd.shard.plan_position_shards: every rank takes a contiguous slice of the positions, fetches
+the reads overlapping it through the BAI and clips its contributions to the slice) -- the total work is
+fixed as N grows ("scaling": "strong"), ranks never exchange per-position data, and `value` is the reads
+of the whole BAM divided by the slowest rank's time.  --mode replicas keeps round 1's weak-scaling form
+(every rank processes the same full BAM).
+
+Other BASELINE configs (builder-run lines, committed under profiles/): --config 3 (window -w 1000 on the
+25-contig genome, streamed in batches), --config 4 (region -L exome BED on the same BAM), --config 5
+(base --fix-mate-overlaps -q20 on a 300x contig).  --scale shrinks contig lengths for development.
 
 Prints ONE JSON line on rank 0 with the driver's fields plus `roofline` (dominant kernel,
-algorithmic bytes / HIP-event kernel time) and `cpu_baseline` (the CPU oracle -- a literal port
-of the reference algorithm -- timed on a bounded sample of the same BAM on this box's host).
+algorithmic bytes / HIP-event kernel time), `cpu_baseline` (the CPU oracle -- a literal port
+of the reference algorithm -- timed on a bounded sample of the same BAM on this box's host),
+`parity_checked` (device results of THIS run compared with the oracle on sampled windows; a mismatch
+makes the process exit non-zero) and `e2e` (the product CLI, file in page cache -> text to /dev/null).
 """
 import argparse
 import hashlib
 import json
 import os
+import random
 import subprocess
 import sys
 import time
@@ -26,6 +39,11 @@ sys.path.insert(0, ROOT)
 
 CHR1_LEN = 248_956_422
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# GRCh38 primary assembly: chr1-22, X, Y, M
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+          133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+          58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569]
+GRCH38_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY", "chrM"]
 
 
 def ensure_built():
@@ -35,31 +53,79 @@ def ensure_built():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, d)])
 
 
-def workload_path(length, coverage, seed, level, codec):
-    key = "chr1_%d_%g_%x_%d_%s" % (length, coverage, seed, level, codec)
-    tmp = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    return os.path.join(tmp, "sbx_bench_%s.bam" % hashlib.sha1(key.encode()).hexdigest()[:12]), key
+def tmp_dir():
+    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
 
 
-def generate(path, length, coverage, seed, level, codec):
+def workload(args):
+    """(contigs string, coverage, seed, extra gen_bam options, description) of the selected BASELINE config."""
+    sc = args.scale
+    if args.config == 2:
+        return "chr1:%d" % args.length, args.coverage, 0x5A4D0002, [], "configs[1]"
+    if args.config in (3, 4):
+        contigs = ",".join("%s:%d" % (n, max(2000, int(l * sc))) for n, l in zip(GRCH38_NAMES, GRCH38))
+        return contigs, args.coverage, 0x5A4D0003, [], "configs[%d]" % (args.config - 1)
+    if args.config == 5:
+        return "chr1:%d" % max(2000, int(50_000_000 * sc)), 300.0 if args.coverage == 30.0 else args.coverage, 0x5A4D0005, \
+            ["--insert-mean", "250", "--insert-sd", "40", "--tie-free-overlaps"], "configs[4]"
+    raise SystemExit("unknown --config")
+
+
+def generate(path, contigs, coverage, seed, level, codec, extra):
     """Seeded synthetic BAM+BAI (tools/gen_bam.cpp); cached on tmpfs across invocations on the same box."""
     meta = path + ".json"
     if os.path.exists(path) and os.path.exists(path + ".bai") and os.path.exists(meta):
         return json.load(open(meta))
     t0 = time.time()
     tmp_out = path + ".tmp%d" % os.getpid()
-    out = subprocess.check_output([os.path.join(ROOT, "tools", "gen_bam"), "--out", tmp_out, "--contigs",
-                                   "chr1:%d" % length, "--coverage", str(coverage), "--seed", hex(seed),
-                                   "--level", str(level), "--codec", codec])
-    info = json.loads(out.decode().strip().splitlines()[-1])
+    env = dict(os.environ, GEN_TIMING="1")
+    r = subprocess.run([os.path.join(ROOT, "tools", "gen_bam"), "--out", tmp_out, "--contigs", contigs, "--coverage", str(coverage),
+                        "--seed", hex(seed), "--level", str(level), "--codec", codec] + list(extra),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, check=True)
+    info = json.loads(r.stdout.decode().strip().splitlines()[-1])
     info["gen_seconds"] = time.time() - t0
+    info["gen_phases"] = r.stderr.decode().strip().splitlines()[-1:] or [""]
     os.replace(tmp_out + ".bai", path + ".bai")
     os.replace(tmp_out, path)
     json.dump(info, open(meta, "w"))
     return info
 
 
-def cpu_baseline(bam, sample_reads):
+def exome_bed(path, names, lengths, seed=0x5A4D0004, n_intervals=200_000, scale=1.0):
+    """Exome-like BED: intervals clustered into `genes` (8-12 exons a few kb apart), lengths
+    lognormal with median 150 bp, sorted, non-overlapping, seed-fixed; total ~ 35 Mbp at scale 1."""
+    if os.path.exists(path):
+        return
+    rng = random.Random(seed)
+    total = sum(lengths)
+    n_intervals = max(25, int(n_intervals * scale))
+    rows = []
+    for name, L in zip(names, lengths):
+        want = max(1, int(n_intervals * L / total))
+        got, ivs = 0, []
+        while got < want:
+            g0 = rng.randrange(0, max(1, L - 60_000))
+            p = g0
+            for _ in range(rng.randint(8, 12)):
+                ln = max(30, min(5000, int(rng.lognormvariate(5.01, 0.6))))
+                if p + ln >= L:
+                    break
+                ivs.append((p, p + ln))
+                got += 1
+                p += ln + rng.randint(200, 6000)
+        ivs.sort()
+        last = -1
+        for a, b in ivs:
+            if a <= last:
+                continue
+            rows.append("%s\t%d\t%d\n" % (name, a, b))
+            last = b
+    with open(path + ".tmp", "w") as fh:
+        fh.writelines(rows)
+    os.replace(path + ".tmp", path)
+
+
+def cpu_baseline(bam, sample_reads, mode_args):
     """Reference-algorithm CPU stand-in: the oracle CLI on the first `sample_reads` records of the same
     BAM, output to /dev/null.  Structured like the reference: zlib inflate on a pool of worker threads
     with in-order delivery (`-t`), then the single-threaded sweep-line pileup + text formatting.  Timed
@@ -70,7 +136,7 @@ def cpu_baseline(bam, sample_reads):
     runs = []
     for workers in (0, max(1, min(16, (os.cpu_count() or 2) - 1))):
         t0 = time.time()
-        r = subprocess.run([exe, "base", "-t", str(workers), "--max-reads", str(sample_reads), bam],
+        r = subprocess.run([exe] + mode_args + ["-t", str(workers), "--max-reads", str(sample_reads), bam],
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
         dt = time.time() - t0
         if r.returncode != 0:
@@ -86,10 +152,68 @@ def cpu_baseline(bam, sample_reads):
         return None
     best = max(runs, key=lambda x: x["mreads_per_s"])
     return {"value": round(best["mreads_per_s"], 4), "unit": "Mreads/s", "cores": best["workers"] + 1, "kind": "port",
-            "sample": "first %d records of the same BAM, depth base -> /dev/null, %.1f s wall" % (best["seen"], best["secs"]),
+            "sample": "first %d records of the same BAM, depth %s -> /dev/null, %.1f s wall" % (best["seen"], " ".join(mode_args), best["secs"]),
             "runs": [{"inflate_workers": x["workers"], "Mreads_per_s": round(x["mreads_per_s"], 4)} for x in runs],
             "threads_note": "sambamba depth default is 0 worker threads (fully serial); the sweep-line pileup and the "
                             "text output are single-threaded in the reference whatever -t says; nproc=%d" % (os.cpu_count() or 0)}
+
+
+def parity_windows(d, bam, intervals, n_windows, seed, min_bq=0, fix_mate=False):
+    """Compare the device counters of THIS run with the CPU oracle (which fetches the reads through the BAI) on sampled
+    50 kb windows of the processed intervals [(ref, beg, end)]: the first and the last window of the work, one just
+    past position 2^27 when there is one, the rest random.  Returns (checked, mismatching windows)."""
+    import numpy as np
+    from tests.util import oracle_base_counters
+    rng = random.Random(seed)
+    W = 50_000
+    picks = []
+    ref, beg, end = intervals[0]
+    picks.append((ref, beg, min(end, beg + W)))
+    ref, beg, end = intervals[-1]
+    picks.append((ref, max(beg, end - W), end))
+    for ref, beg, end in intervals:
+        if beg <= (1 << 27) and end >= (1 << 27) + W:
+            picks.append((ref, (1 << 27) - 1000, (1 << 27) - 1000 + W))
+            break
+    while len(picks) < n_windows:
+        ref, beg, end = intervals[rng.randrange(len(intervals))]
+        if end - beg <= W:
+            picks.append((ref, beg, end))
+            continue
+        a = rng.randrange(beg, end - W)
+        picks.append((ref, a, a + W))
+    bad = []
+    S = d.n_samples_eff
+    for ref, a, b in picks:
+        got = d.base_counters(ref, a, b)
+        want = oracle_base_counters(bam, ref, a, b, n_samples=S, min_bq=min_bq, fix_mate=fix_mate)
+        if not np.array_equal(got, want):
+            bad.append([ref, a, b])
+    return len(picks), bad
+
+
+def parity_text(d, bam, ref_name, ref, beg, end, extra_args):
+    """md5 of the device-formatted rows of [beg, end) against the oracle CLI's text for the same region."""
+    got = d.format_base_rows(ref, beg, end)
+    r = subprocess.run([os.path.join(ROOT, "oracle", "depth_oracle"), "base"] + extra_args +
+                       ["-L", "%s:%d-%d" % (ref_name, beg + 1, end), bam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    want = r.stdout.split(b"\n", 1)[1] if r.stdout else b""      # drop the header line
+    return hashlib.md5(got).hexdigest(), hashlib.md5(want).hexdigest(), len(got)
+
+
+def cli_e2e(bam, mode_args, reads):
+    """The product CLI end to end: file (page cache) -> device -> text on /dev/null, wall clock of the process."""
+    from sambamba_amd import cli_path
+    out = []
+    for _ in range(2):     # first call pays the page-in of the shared libraries
+        t0 = time.time()
+        r = subprocess.run([cli_path()] + mode_args + ["-o", "/dev/null", bam], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        out.append(time.time() - t0)
+        if r.returncode != 0:
+            return {"error": r.stderr.decode()[-300:]}
+    best = min(out)
+    return {"seconds": round(best, 3), "Mreads_per_s": round(reads / best / 1e6, 2), "what": "sbx-depth %s -o /dev/null <bam> (file in page cache, "
+            "H2D + device pipeline + device text formatting + D2H + write), best of 2" % " ".join(mode_args)}
 
 
 def main():
@@ -97,13 +221,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=int(os.environ.get("SBX_BENCH_CONFIG", 2)), help="BASELINE.json config number (2..5)")
+    ap.add_argument("--mode", choices=["auto", "shard", "replicas"], default=os.environ.get("SBX_BENCH_MODE", "auto"))
     ap.add_argument("--length", type=int, default=int(os.environ.get("SBX_BENCH_LEN", CHR1_LEN)),
-                    help="contig length (default: chr1; smaller values are for development only)")
+                    help="contig length of config 2 (default: chr1; smaller values are for development only)")
+    ap.add_argument("--scale", type=float, default=float(os.environ.get("SBX_BENCH_SCALE", 1.0)),
+                    help="configs 3-5: shrink every contig by this factor (development)")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--codec", default=os.environ.get("SBX_BENCH_CODEC", "zlib"))
     ap.add_argument("--cpu-sample-reads", type=int, default=int(os.environ.get("SBX_BENCH_CPU_READS", 3_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--parity-windows", type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,21 +261,95 @@ def main():
     if dist:
         dist.barrier()
     import sambamba_amd
+    from sambamba_amd import shard as shardmod
 
-    # One seeded contig-sized BAM per node, generated once (rank 0, all host cores) and processed by every
-    # rank on its own GPU: per-GPU work is fixed as N grows (weak scaling) and ranks never exchange data.
-    seed = 0x5A4D0002
-    path, key = workload_path(args.length, args.coverage, seed, args.level, args.codec)
+    contigs, coverage, seed, extra, cfg_name = workload(args)
+    key = "%s_%g_%x_%d_%s_%s" % (contigs, coverage, seed, args.level, args.codec, " ".join(extra))
+    path = os.path.join(tmp_dir(), "sbx_bench_%s.bam" % hashlib.sha1(key.encode()).hexdigest()[:12])
     if rank == 0:
-        info = generate(path, args.length, args.coverage, seed, args.level, args.codec)
+        info = generate(path, contigs, coverage, seed, args.level, args.codec, extra)
     if dist:
         dist.barrier()
     if rank != 0:
         info = json.load(open(path + ".json"))
 
+    sharded = world > 1 and args.mode != "replicas"
     d = sambamba_amd.Depth(path, device=dev_index)
-    d.set_params()             # depth base, default filter, -q 0
-    d.preload()                # compressed BAM resident in HBM before the timed region
+    SBX = sambamba_amd
+    mode_args, min_bq, fix_mate = ["base"], 0, False
+    regions = None
+    if args.config == 2:
+        d.set_params()             # depth base, default filter, -q 0
+    elif args.config == 3:
+        d.set_params(mode=SBX.SBX_MODE_WINDOW, window=1000)
+        mode_args = ["window", "-w", "1000"]
+    elif args.config == 4:
+        bed = path + ".exome.bed"
+        if rank == 0:
+            exome_bed(bed, d.ref_names, d.ref_lengths, scale=args.scale)
+        if dist:
+            dist.barrier()
+        d.set_params(mode=SBX.SBX_MODE_REGION)
+        regions = shardmod.read_bed_regions(bed, d.ref_names)
+        mode_args = ["region", "-L", bed]
+    elif args.config == 5:
+        min_bq, fix_mate = 20, True
+        d.set_params(min_bq=20, fix_mate_overlaps=True)
+        mode_args = ["base", "-m", "-q", "20"]
+
+    # ---- the work of this rank: a list of steps [(kind, args)] that together make one pass ----------------------
+    ref_lengths = d.ref_lengths
+    if sharded:
+        align = 1000 if args.config == 3 else 1024
+        my = shardmod.plan_position_shards(ref_lengths, world, align=align)[rank]      # [(ref, beg, end)]
+        if regions is not None:
+            my = shardmod.clip_regions_to_shards(regions, my)
+    else:
+        my = None
+    if my is None:
+        if args.config in (3, 4) and regions is None:
+            d.preload()
+            plan = d.plan_batches()
+        elif regions is not None:
+            d.set_regions(shardmod.merge_regions(regions))
+            plan = [None]
+        else:
+            d.preload()                # compressed BAM resident in HBM before the timed region
+            plan = [None]
+    window_rows = [0]
+
+    def one_pass():
+        """One pass of the hot path over this rank's share; returns the list of per-run statistics."""
+        sts = []
+        if my is not None:
+            if regions is not None:
+                d.set_regions(shardmod.merge_regions(my))
+                sts.append(d.run())
+                if my:
+                    d.region_stats(my)
+            else:
+                for ref, beg, end in my:
+                    sts.append(d.run_interval(ref, beg, end))
+                    if args.config == 3:
+                        n = (min(end, ref_lengths[ref]) // 1000) - beg // 1000
+                        if n > 0:
+                            d.window_stats(ref, beg // 1000, n)
+                            window_rows[0] += n
+            return sts
+        for b in plan:
+            if b is None:
+                sts.append(d.run())
+                if regions is not None:
+                    d.region_stats(regions)
+            else:
+                sts.append(d.run_batch(b[0], b[1]))
+                if args.config == 3:
+                    for r in range(b[0], b[0] + b[1]):
+                        n = ref_lengths[r] // 1000
+                        if n:
+                            d.window_stats(r, 0, n)
+                            window_rows[0] += n
+        return sts
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -153,77 +357,129 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    last = None
     for _ in range(args.warmup):
-        last = d.run()
+        one_pass()
     sync()
     t0 = time.perf_counter()
     kstats = []
     for _ in range(args.steps):
-        last = d.run()
-        kstats.append(last)
+        kstats.append(one_pass())
     sync()
     elapsed = time.perf_counter() - t0
+    last = kstats[-1]
+    my_reads = float(sum(s["n_records"] for s in last))
+    my_adm = float(sum(s["n_admitted"] for s in last))
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([float(last["n_records"]), float(last["n_admitted"])], dtype=torch.float64, device=red_dev)
+        r = torch.tensor([my_reads, my_adm], dtype=torch.float64, device=red_dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        total_reads, total_admitted = float(r[0].item()), float(r[1].item())
+        sum_reads, sum_adm = float(r[0].item()), float(r[1].item())
     else:
-        total_reads, total_admitted = float(last["n_records"]), float(last["n_admitted"])
+        sum_reads, sum_adm = my_reads, my_adm
+    # sharded: reads near a cut are seen by both neighbours, the job's reads are the file's
+    total_reads = float(info["reads"]) if sharded else sum_reads
+    total_admitted = sum_adm * (total_reads / sum_reads) if (sharded and sum_reads) else sum_adm
+
+    # ---- parity of THIS run's results at scale (every rank checks its own share) --------------------------------
+    par = {"windows": 0, "ok": True, "mismatches": []}
+    if args.parity_windows > 0 and args.config in (2, 5):
+        if my is not None:
+            ivs = [iv for iv in my]
+        else:
+            ivs = [(r, 0, ref_lengths[r]) for r in range(len(ref_lengths)) if ref_lengths[r] > 0]
+        if ivs:
+            if my is not None:     # the last run of the pass left the last interval resident
+                ivs = [ivs[-1]]
+            n, bad = parity_windows(d, path, ivs, args.parity_windows, seed ^ rank, min_bq=min_bq, fix_mate=fix_mate)
+            par = {"windows": n, "ok": not bad, "mismatches": bad[:4]}
+            ref, a, b = ivs[-1]
+            a2 = a + (b - a) // 3 // 1024 * 1024
+            b2 = min(b, a2 + 1_000_000)
+            md_got, md_want, nbytes = parity_text(d, path, d.ref_names[ref], ref, a2, b2, mode_args[1:])
+            par.update({"text_slab": [ref, a2, b2], "text_bytes": nbytes, "text_md5": md_got, "text_ok": md_got == md_want})
+            par["ok"] = par["ok"] and md_got == md_want
+    if dist:
+        okt = torch.tensor([1.0 if par["ok"] else 0.0, float(par["windows"])], dtype=torch.float64, device=red_dev)
+        allok = okt.clone()
+        dist.all_reduce(allok, op=dist.ReduceOp.MIN)
+        dist.all_reduce(okt, op=dist.ReduceOp.SUM)
+        par["ok_all_ranks"] = bool(allok[0].item() >= 1.0)
+        par["windows_all_ranks"] = int(okt[1].item())
+    parity_ok = par.get("ok_all_ranks", par["ok"])
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         reads_per_s = total_reads / (elapsed / args.steps)
         read_len = 150
-        avg = lambda k: sum(s[k] for s in kstats) / len(kstats)
-        kern = {"huffman_decode": avg("ms_huffman"), "lz77_resolve": avg("ms_lz77"), "record_index": avg("ms_index"),
-                "decode_accumulate": avg("ms_accumulate")}
+        names = {"huffman_decode": "ms_huffman", "lz77_resolve": "ms_lz77", "record_index": "ms_index", "decode_accumulate": "ms_accumulate"}
+        # per-kernel time of one pass on rank 0: summed over the runs of a pass, averaged over the steps
+        kern = {k: sum(sum(s[v] for s in p) for p in kstats) / len(kstats) for k, v in names.items()}
         dom = max(kern, key=kern.get)
-        comp, unc, cnt = last["compressed_bytes"], last["uncompressed_bytes"], last["counter_bytes"]
-        # algorithmic bytes per launch
+        comp = sum(s["compressed_bytes"] for s in last)
+        unc = sum(s["uncompressed_bytes"] for s in last)
+        cnt = sum(s["counter_bytes"] for s in last)
+        nrec = sum(s["n_records"] for s in last)
+        # algorithmic bytes per pass of rank 0
         alg = {"huffman_decode": comp + 0.57 * unc,          # compressed in; literal + match-entry streams out (~0.57 B per output byte)
                "lz77_resolve": 0.57 * unc + unc,              # token streams in; inflated bytes out
-               "record_index": unc * 0 + last["n_records"] * (36 + 32),   # fixed part of each record read, 32-B descriptor written
+               "record_index": unc + nrec * 32,               # the inflated stream read once, 32-B descriptor written per record
                "decode_accumulate": unc + cnt}               # record bytes read once + 28 B/position/sample written once
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(alg[dom] / (kern[dom] * 1e-3) / 1e9, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "algorithmic_bytes_per_launch": int(alg[dom]), "kernel_ms": round(kern[dom], 4)}
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
-        if args.length == CHR1_LEN:
+        if args.config == 2 and args.length == CHR1_LEN and world == 1:
             roof.update(pmc_traffic(dom))
         per_kernel = {k: {"ms": round(kern[k], 4), "algorithmic_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 2),
-                          "frac_of_hbm_peak": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in kern}
+                          "frac_of_hbm_peak": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in kern if kern[k] > 0}
+        # the fused-path figure of SURVEY.md 8(d): compressed bytes in + counters out over the whole pass
+        fused = (comp + cnt) / (sum(kern.values()) * 1e-3) / 1e9 if sum(kern.values()) > 0 else 0.0
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(path, min(args.cpu_sample_reads, int(last["n_records"])))
+            cpu = cpu_baseline(path, min(args.cpu_sample_reads, int(info["reads"])), mode_args)
+        e2e = None
+        if not args.no_e2e and world == 1:
+            e2e = cli_e2e(path, mode_args, int(info["reads"]))
+            if cpu and e2e.get("Mreads_per_s"):
+                e2e["vs_cpu_baseline"] = round(e2e["Mreads_per_s"] / cpu["value"], 1)
+        what = {2: "depth base", 3: "depth window -w 1000", 4: "depth region -L exome.bed", 5: "depth base --fix-mate-overlaps -q20"}[args.config]
+        full = (args.config == 2 and args.length == CHR1_LEN) or (args.config != 2 and args.scale == 1.0)
         line = {
-            "metric": "depth_base_Mreads_per_s", "value": round(reads_per_s / 1e6, 3), "unit": "Mreads/s",
+            "metric": "depth_%s_Mreads_per_s" % mode_args[0], "value": round(reads_per_s / 1e6, 3), "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
-            "config": {"workload": "depth base on synthetic chr1 %dx coordinate-sorted BAM (L=%d, %d reads of %d bp per GPU, "
-                                   "BGZF %s level %d, ratio %.2f), compressed bytes resident in HBM" % (
-                                       int(args.coverage), args.length, int(last["n_records"]), read_len, args.codec,
-                                       args.level, unc / max(1, comp)),
-                       "baseline_config": "configs[1]" if args.length == CHR1_LEN else "configs[1] scaled down (development)",
-                       "sharding": "every GPU runs the full contig-sized workload (same seeded BAM), no data-path collective"},
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
+            "config": {"workload": "%s on synthetic %dx coordinate-sorted BAM (%d contig(s), %d Mbp, %d reads of %d bp, BGZF %s level %d, "
+                                   "ratio %.2f), compressed bytes resident in HBM" % (
+                                       what, int(coverage), len(ref_lengths), sum(ref_lengths) // 1_000_000, int(info["reads"]), read_len,
+                                       args.codec, args.level, unc / max(1, comp)),
+                       "baseline_config": cfg_name if full else cfg_name + " scaled down (development)",
+                       "sharding": ("one BAM sharded over the ranks by reference position (BAI fetch per slice, contributions clipped "
+                                    "to the slice), no data-path collective" if sharded else
+                                    "every GPU runs the full workload (same seeded BAM), no data-path collective") if world > 1 else "single GPU"},
             "gbases_per_s": round(total_admitted * read_len / (elapsed / args.steps) / 1e9, 3),
             "reads_total": int(total_reads), "reads_admitted": int(total_admitted),
-            "roofline": roof, "kernels": per_kernel, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": per_kernel,
+            "fused_path": {"algorithmic_GBps": round(fused, 1), "frac_of_hbm_peak": round(fused / HBM_PEAK_GBS, 5),
+                           "what": "(compressed bytes in + counter bytes out) / sum of the kernel times of a pass, rank 0"},
+            "cpu_baseline": cpu, "parity_checked": par, "e2e": e2e,
             "host": {"nproc": os.cpu_count(), "bam_gen_seconds": round(info.get("gen_seconds", 0.0), 1),
-                     "h2d_ms": round(last.get("ms_h2d", 0.0), 1)},
+                     "bam_gen_phases": info.get("gen_phases"), "h2d_ms": round(max(s.get("ms_h2d", 0.0) for s in last), 1),
+                     "runs_per_pass": len(last), "chain_runs": int(sum(s["n_runs"] for s in last)),
+                     "window_rows_per_pass": window_rows[0] // max(1, args.steps + args.warmup)},
         }
         print(json.dumps(line))
     d.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if not parity_ok:
+        sys.exit(3)
 
 
 PMC_KERNELS = {"huffman_decode": ["k_huffman_decode"], "lz77_resolve": ["k_lz77_resolve"],
-               "record_index": ["k_block_walk", "k_chain_check", "k_chain_repair", "k_count_scan", "k_describe", "k_tile_compact"],
+               "record_index": ["k_index_blocks", "k_tile_compact", "k_chain_repair", "k_block_walk", "k_chain_check", "k_count_scan", "k_describe"],
                "decode_accumulate": ["k_accumulate"]}
 
 
@@ -231,8 +487,11 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same workload
     (tools/profile_round.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, KiB).
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is."""
-    path = os.path.join(ROOT, "profiles", "round1", "pmc_fetch_write_chr1_30x.csv")
-    if not os.path.exists(path):
+    for rnd in ("round2", "round1"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_fetch_write_chr1_30x.csv")
+        if os.path.exists(path):
+            break
+    else:
         return {}
     fetch = write = 0.0
     best = {}
@@ -250,8 +509,8 @@ def pmc_traffic(kernel):
     if not fetch and not write:
         return {}
     return {"traffic": int(2 * fetch + write), "traffic_unit": "bytes per launch",
-            "traffic_source": "profiles/round1/pmc_fetch_write_chr1_30x.csv (rocprofv3 PMC, separate passes; "
-                              "FETCH_SIZE raw %.2f GB doubled, WRITE_SIZE %.2f GB)" % (fetch / 1e9, write / 1e9)}
+            "traffic_source": "profiles/%s/pmc_fetch_write_chr1_30x.csv (rocprofv3 PMC, separate passes; "
+                              "FETCH_SIZE raw %.2f GB doubled, WRITE_SIZE %.2f GB)" % (rnd, fetch / 1e9, write / 1e9)}
 
 
 if __name__ == "__main__":

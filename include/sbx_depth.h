@@ -46,6 +46,12 @@ extern "C" {
 
 typedef struct sbx_ctx sbx_ctx;
 
+/* sizeof() of the named struct of this header as the library was compiled ("sbx_filter", "sbx_regex",
+ * "sbx_filter_op", "sbx_region", "sbx_region_stats", "sbx_header_info", "sbx_batch", "sbx_run_stats",
+ * "sbx_regex_state"); 0 for an unknown name.  Lets a foreign-language binding (d/sbx_depth.d, the ctypes
+ * binding) verify its struct layouts against the library it loaded. */
+size_t sbx_abi_sizeof(const char* type_name);
+
 /* Counter layout of one reference position of one sample, `depth base`
  * (PerBasePrinter.writeColumn, depth.d:495-556): A, C, G, T, other (N/IUPAC/'='),
  * DEL, REFSKIP.  COV = sum of all seven (code 4 counts towards COV but has no column). */
@@ -177,6 +183,17 @@ int sbx_set_params(sbx_ctx*, int mode, uint8_t min_base_quality, int fix_mate_ov
  * randomaccessmanager.d:316-338).  n == 0 means "all reads" (bam.reads, depth.d:1214). */
 int sbx_set_regions(sbx_ctx*, const sbx_region* regions, size_t n);
 
+/* The -L argument of depth_main turned into regions the way the reference does it (depth.d:1184-1208): a BED file
+ * (readIntervals / parseBed, sambamba/utils/common/bed.d:59-152: two-column lines mean [beg, beg+1), empty intervals
+ * become one base long, lines naming contigs the BAM does not have are dropped) or, when the argument cannot be read
+ * as one, a region string "ref[:beg[-end]]" (BioD/bio/core/region.d:97-246).  Afterwards sbx_parsed_regions copies out
+ * the merged, sorted list (merged != 0: what sbx_set_regions wants) or the raw list in input order (what region mode
+ * reports on), and sbx_parsed_region_line returns the input line that precedes the rows of raw region i
+ * (depth.d:902-906; for a region string the synthetic "ref\tstart\tend", depth.d:1203-1206). */
+int sbx_parse_regions(sbx_ctx*, const char* bed_path_or_region, size_t* n_merged, size_t* n_raw);
+int sbx_parsed_regions(sbx_ctx*, int merged, sbx_region* out, size_t cap);
+const char* sbx_parsed_region_line(sbx_ctx*, size_t raw_index);
+
 /* Run BGZF inflate -> record index -> decode+accumulate on the device for everything the
  * current filter/params/regions select.  Results stay resident in HBM until the next
  * sbx_run()/sbx_close(); the sbx_depth_* getters below copy them out.  */
@@ -196,6 +213,13 @@ typedef struct {
 } sbx_batch;
 int sbx_plan_batches(sbx_ctx*, uint64_t budget_bytes, sbx_batch* out, size_t cap, size_t* n_out);
 int sbx_run_batch(sbx_ctx*, uint32_t first_ref, uint32_t n_refs);
+/* sbx_run() restricted to the reads overlapping [beg, end) of ref_id (intersected with the regions of
+ * sbx_set_regions, if any) -- the unit of sub-contig streaming and of position sharding across GPUs
+ * (the analogue of one element of pileupChunks, BioD/bio/std/hts/bam/pileup.d:1011-1015; the reads come
+ * through the BAI exactly as bam[ref][beg .. end] fetches them, randomaccessmanager.d:247-338).  Afterwards
+ * the getters answer for positions in [beg, end) only: counters there are complete (every read overlapping
+ * the interval was seen), outside they are partial. */
+int sbx_run_interval(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end);
 
 /* depth base: counters[(pos-beg)*n_samples*7 + s*7 + k] for pos in [beg,end) of ref_id
  * (k = A,C,G,T,other,DEL,REFSKIP; n_samples = 1 when --combined).  Positions no admitted read
@@ -237,6 +261,10 @@ typedef struct {
     uint64_t compressed_bytes, uncompressed_bytes, counter_bytes, covered_positions;
     uint64_t launches_inflate, launches_index, launches_accumulate;
     double ms_huffman, ms_lz77;   /* the two kernels of ms_inflate */
+    uint64_t n_malformed;         /* records dropped as malformed (always 0 after a successful run: they raise SBX_EFORMAT) */
+    uint64_t n_runs;              /* record-chain runs of the device work list (1 for a whole file, one per merged BAI chunk group with -L) */
+    uint64_t uploaded_bytes;      /* compressed bytes resident in HBM for this run (the BGZF blocks of the work list only) */
+    uint64_t reserved0;
 } sbx_run_stats;
 int sbx_last_run_stats(sbx_ctx*, sbx_run_stats* out);
 

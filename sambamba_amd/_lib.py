@@ -59,7 +59,8 @@ class RunStats(C.Structure):
                 ("n_records", C.c_uint64), ("n_admitted", C.c_uint64), ("n_bgzf_blocks", C.c_uint64),
                 ("compressed_bytes", C.c_uint64), ("uncompressed_bytes", C.c_uint64), ("counter_bytes", C.c_uint64),
                 ("covered_positions", C.c_uint64), ("launches_inflate", C.c_uint64), ("launches_index", C.c_uint64),
-                ("launches_accumulate", C.c_uint64), ("ms_huffman", C.c_double), ("ms_lz77", C.c_double)]
+                ("launches_accumulate", C.c_uint64), ("ms_huffman", C.c_double), ("ms_lz77", C.c_double),
+                ("n_malformed", C.c_uint64), ("n_runs", C.c_uint64), ("uploaded_bytes", C.c_uint64), ("reserved0", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -73,7 +74,7 @@ class Batch(C.Structure):
     _fields_ = [("first_ref", C.c_uint32), ("n_refs", C.c_uint32), ("est_bytes", C.c_uint64)]
 
 EXPORTS = [
-    "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
+    "sbx_abi_sizeof", "sbx_run_interval", "sbx_parse_regions", "sbx_parsed_regions", "sbx_parsed_region_line", "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
     "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_regex_search", "sbx_set_params",
     "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_region_stats_from",
     "sbx_depth_window_stats",
@@ -136,6 +137,22 @@ def lib():
     L.sbx_tile_info.argtypes = [C.c_void_p, u32p, u32p]
     L.sbx_next_active_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, u64p, u64p]
     L.sbx_preload.argtypes = [C.c_void_p]
+    L.sbx_run_interval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.sbx_parse_regions.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.sbx_parsed_regions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.sbx_parsed_region_line.argtypes = [C.c_void_p, C.c_size_t]
+    L.sbx_parsed_region_line.restype = C.c_char_p
+    L.sbx_abi_sizeof.argtypes = [C.c_char_p]
+    L.sbx_abi_sizeof.restype = C.c_size_t
+    L.sbx_depth_region_stats_from.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sbx_regex_search.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    # the structures above must have the layout the library was compiled with
+    for name, ty in (("sbx_region", Region), ("sbx_header_info", HeaderInfo), ("sbx_region_stats", RegionStats),
+                     ("sbx_filter_op", FilterOp), ("sbx_regex_state", RegexState), ("sbx_regex", Regex), ("sbx_filter", Filter),
+                     ("sbx_run_stats", RunStats), ("sbx_batch", Batch)):
+        if L.sbx_abi_sizeof(name.encode()) != C.sizeof(ty):
+            raise ImportError("ctypes layout of %s (%d bytes) differs from libsbx_depth.so (%d bytes)" % (
+                name, C.sizeof(ty), L.sbx_abi_sizeof(name.encode())))
     _lib = L
     return L
 
@@ -227,6 +244,19 @@ class Depth:
         arr = (Region * len(regions))(*[Region(*r) for r in regions])
         self._check(self._L.sbx_set_regions(self._ctx, arr, len(regions)))
 
+    def parse_regions(self, arg):
+        """-L argument (BED file or region string) -> (merged [(ref, start, end)], raw [(ref, start, end)], raw input lines),
+        parsed by the library exactly as the CLI parses it."""
+        nm, nr = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.sbx_parse_regions(self._ctx, arg.encode(), C.byref(nm), C.byref(nr)))
+        out = []
+        for merged, n in ((1, nm.value), (0, nr.value)):
+            arr = (Region * max(1, n))()
+            self._check(self._L.sbx_parsed_regions(self._ctx, merged, arr, n))
+            out.append([(arr[i].ref_id, arr[i].start, arr[i].end) for i in range(n)])
+        lines = [self._L.sbx_parsed_region_line(self._ctx, i).decode() for i in range(nr.value)]
+        return out[0], out[1], lines
+
     def preload(self):
         self._check(self._L.sbx_preload(self._ctx))
 
@@ -264,6 +294,13 @@ class Depth:
     def run_batch(self, first_ref, n_refs):
         """sbx_run restricted to the reads of contigs [first_ref, first_ref + n_refs)."""
         self._check(self._L.sbx_run_batch(self._ctx, int(first_ref), int(n_refs)))
+        st = RunStats()
+        self._check(self._L.sbx_last_run_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def run_interval(self, ref_id, beg, end):
+        """sbx_run restricted to the reads overlapping [beg, end) of ref_id (position sharding / streaming)."""
+        self._check(self._L.sbx_run_interval(self._ctx, int(ref_id), int(beg), int(end)))
         st = RunStats()
         self._check(self._L.sbx_last_run_stats(self._ctx, C.byref(st)))
         return st.as_dict()

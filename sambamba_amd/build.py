@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsbx_depth.so")
 CLI = os.path.join(CSRC, "sbx-depth")
 SOURCES = ["inflate.hip", "index.hip", "depth.hip", "reduce.hip", "mates.hip", "format.hip", "engine.cpp"]
-HEADERS = ["common.hpp", "kernels.hpp", "host_io.hpp", os.path.join("..", "..", "include", "sbx_depth.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "sbx_depth.h")]
 
 
 def _hipcc():

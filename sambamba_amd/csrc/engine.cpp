@@ -1,11 +1,18 @@
 // engine.cpp -- the C ABI of libsbx_depth.so (include/sbx_depth.h) and the device pipeline
-//   compressed BAM in HBM -> K1 inflate -> K2 record index -> K3 decode+accumulate -> counters in HBM.
+//   compressed BGZF blocks in HBM -> K1 inflate -> K2 record index -> K3 decode+accumulate -> counters in HBM.
 // Host code here is orchestration only; every byte of BGZF payload, every record and every
 // counter is produced on the device.  There is no CPU fallback: without a HIP device the compute
 // entry points fail with SBX_ENODEVICE.
+//
+// The unit of work is a WORK LIST of chain runs (kernels.hpp ChainRun): the whole file from its first record on,
+// or -- with -L, with sbx_run_batch / sbx_run_interval -- the BGZF block runs that hold the merged BAI chunks of the
+// requested regions (RandomAccessManager.getChunks / getReads, randomaccessmanager.d:247-348; StreamChunksSupplier,
+// inputstream.d:257-345), every run starting at a record boundary the index names.  Only those blocks are uploaded
+// and inflated; the inflated pieces are laid out back to back in one device buffer.
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <thread>
 
 #include "common.hpp"
 #include "host_io.hpp"
@@ -33,6 +40,36 @@ static uint32_t floor_pow2(uint32_t x) {
     return p;
 }
 
+// One run of the work list in FILE coordinates: BGZF blocks [blk0, blk1), inflated-stream offsets [ub, ue).
+struct FileRun {
+    uint32_t blk0, blk1;
+    uint64_t ub, ue;
+    bool operator==(const FileRun& o) const { return blk0 == o.blk0 && blk1 == o.blk1 && ub == o.ub && ue == o.ue; }
+};
+
+// The work list of a launch: file runs, and the per-block tables of the launch in compacted coordinates
+// (block i of the launch is file block file_blk[i]; its payload sits at comp_off[i] of d_comp, its inflated
+// bytes at out_off[i] of d_U).
+struct WorkList {
+    std::vector<FileRun> runs;
+    std::vector<uint32_t> file_blk, comp_len, isize, run_of;
+    std::vector<uint64_t> comp_off, out_off;        // out_off has n + 1 entries
+    std::vector<ChainRun> chain;
+    struct Range { uint64_t file_off, len, dst; };
+    std::vector<Range> ranges;                      // file bytes -> d_comp (only when the file is not preloaded)
+    uint64_t comp_bytes = 0, u_bytes = 0;
+    size_t n_blocks() const { return file_blk.size(); }
+};
+
+// result words of a pass, written by async copies into pinned host memory and read after one synchronisation
+struct HostResults {
+    uint32_t flags[4];
+    uint32_t n_active, pad;
+    IndexStats st;
+    uint64_t last_state;
+    uint32_t max_partners, n_rewalked;
+};
+
 }  // namespace sbx
 
 using namespace sbx;
@@ -43,7 +80,7 @@ struct sbx_ctx {
     // every further file is a complete single-file context of its own
     std::vector<sbx_ctx*> members;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     FileMap file;
     BlockTable blocks;
     BamHeaderInfo hdr;
@@ -59,21 +96,30 @@ struct sbx_ctx {
     sbx_filter filter;
     std::vector<sbx_region> regions;
 
-    // device state
-    bool comp_resident = false;
+    // compressed input on the device: the whole file (sbx_preload) or the blocks of the current work list
+    bool preloaded = false;
     DevBuf<uint8_t> d_comp;
+    WorkList wl;                    // the work list whose tables (and, unless preloaded, payload bytes) are resident
+    bool wl_resident = false;
     DevBuf<uint64_t> d_comp_off, d_out_off;
-    DevBuf<uint32_t> d_comp_len, d_isize, d_status;
+    DevBuf<uint32_t> d_comp_len, d_isize, d_run_of, d_status;
+    DevBuf<ChainRun> d_runs;
+    // pinned staging for host -> device copies of file bytes
+    uint8_t* stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    hipEvent_t upload_done = nullptr;
+    HostResults* res = nullptr;     // pinned
+
     DevBuf<uint8_t> d_U, d_scratch, d_lit;
     uint64_t primary_records = 0;   // records of THIS file in the last run (stats.n_records is the sum over files after a merge)
-    uint64_t u_base = 0;      // stream offset held at d_U.p[0]: d_U covers the BGZF block range of the current run only
-    const uint8_t* U() const { return d_U.p - u_base; }     // address of stream offset 0 (only offsets >= u_base are backed)
+    const uint8_t* U() const { return d_U.p; }
     DevBuf<uint32_t> d_ent, d_nent;
-    DevBuf<uint64_t> d_entry, d_exit, d_base, d_ckpt;
+    DevBuf<uint64_t> d_entry, d_exit, d_state;
     DevBuf<uint32_t> d_count, d_flag;
     DevBuf<RecDesc> d_desc;
     DevBuf<int32_t> d_rec_ref;
     DevBuf<uint64_t> d_name_hash;
+    uint64_t desc_cap = 0;
     DevBuf<uint32_t> d_mate, d_n_partners;
     DevBuf<int32_t> d_ref_len;
     DevBuf<uint32_t> d_tile_base, d_tile_lo, d_tile_hi, d_active, d_slot_of, d_n_active;
@@ -85,11 +131,23 @@ struct sbx_ctx {
     DevBuf<uint32_t> d_rg_off;
     DevBuf<uint16_t> d_rg_sample;
     DevBuf<IndexStats> d_stats;
+    DevBuf<SortedRegion> d_sel;
+    DevBuf<uint32_t> d_sel_first;
     DevBuf<uint32_t> d_fmt_len, d_fmt_soff;
     DevBuf<uint64_t> d_fmt_off;
     DevBuf<uint8_t> d_fmt_text;
     DevBuf<char> d_fmt_names;
-    bool tables_uploaded = false;
+    // host images of the small tables (they must outlive the asynchronous copies that read them)
+    std::vector<int32_t> h_ref_len;
+    std::vector<uint32_t> h_tile_base_up, h_sel_first, h_rg_off;
+    std::vector<SortedRegion> h_sel;
+    std::vector<uint8_t> h_ref_sets;
+    std::string h_rg_ids;
+    DeviceFilter h_df;
+
+    // result of the last sbx_parse_regions
+    std::vector<sbx_region> parsed_merged, parsed_raw;
+    std::vector<std::string> parsed_lines;
 
     // results of the last run
     bool have_run = false;
@@ -97,9 +155,20 @@ struct sbx_ctx {
     bool span_valid = false;
     std::vector<uint32_t> h_tile_base, h_slot_of;
     sbx_run_stats stats{};
+
+    ~sbx_ctx() {
+        for (int i = 0; i < 2; ++i) {
+            if (stage[i]) (void)hipHostFree(stage[i]);
+            if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
+        }
+        if (upload_done) (void)hipEventDestroy(upload_done);
+        if (res) (void)hipHostFree(res);
+    }
 };
 
 namespace {
+
+constexpr size_t kStageBytes = 32u << 20;
 
 // the files of a (possibly multi-BAM) context, the primary first
 std::vector<sbx_ctx*> files_of(sbx_ctx* c) {
@@ -126,83 +195,239 @@ void set_err(char* err, size_t n, const std::string& m) {
     if (err && n) snprintf(err, n, "%s", m.c_str());
 }
 
-void upload_tables(sbx_ctx* c) {
-    if (c->tables_uploaded) return;
-    size_t n = c->blocks.size();
-    c->d_comp_off.alloc(n + 1);
-    c->d_comp_len.alloc(n + 1);
-    c->d_isize.alloc(n + 1);
-    c->d_out_off.alloc(n + 1);
+// ---- work list ---------------------------------------------------------------------------------------
+// virtual offset -> (file block, offset in the inflated stream of the file)
+uint64_t voffset_to_stream(const sbx_ctx* c, uint64_t v, uint32_t* blk) {
+    const uint32_t nb = (uint32_t)c->blocks.size();
+    const uint64_t co = v >> 16, uo = v & 0xFFFF;
+    const size_t bi = (size_t)(std::lower_bound(c->blocks.coffset.begin(), c->blocks.coffset.end(), co) - c->blocks.coffset.begin());
+    if (bi >= nb) { *blk = nb; return c->blocks.out_off.back(); }     // at / beyond the EOF block
+    if (c->blocks.coffset[bi] != co) throw Error(SBX_EFORMAT, "BAI virtual offset does not point at a BGZF block");
+    *blk = (uint32_t)bi;
+    return c->blocks.out_off[bi] + uo;
+}
+
+std::vector<sbx_region> sorted_regions(const std::vector<sbx_region>& sel) {
+    std::vector<sbx_region> regs = sel;
+    std::sort(regs.begin(), regs.end(), [](const sbx_region& a, const sbx_region& b) {
+        if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+        if (a.start != b.start) return a.start < b.start;
+        return a.end < b.end;
+    });
+    return regs;
+}
+
+// The runs of a pass.  restricted == false: every record of the file.  Otherwise: per contig, the merged BAI chunks
+// of its merged regions (getGroupChunks, randomaccessmanager.d:247-294); chunks that share a BGZF block or are at
+// most one block apart are joined into one run (what lies between two chunks is a whole number of records, which the
+// read selection of K2 drops again), everything else stays a run of its own -- so a sparse BED touches only the
+// blocks its chunks live in.
+std::vector<FileRun> build_runs(const sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
+    std::vector<FileRun> runs;
+    const uint32_t nb = (uint32_t)c->blocks.size();
+    const uint64_t total = c->blocks.out_off.back(), first = c->hdr.first_record_off;
+    if (!restricted) {
+        if (first < total) {
+            const uint32_t b0 = (uint32_t)(std::upper_bound(c->blocks.out_off.begin(), c->blocks.out_off.end(), first) - c->blocks.out_off.begin()) - 1;
+            runs.push_back({b0, nb, first, total});
+        }
+        return runs;
+    }
+    const std::vector<sbx_region> regs = sorted_regions(sel);
+    for (size_t i = 0; i < regs.size();) {
+        size_t j = i;
+        std::vector<sbx_region> group;
+        while (j < regs.size() && regs[j].ref_id == regs[i].ref_id) {
+            if (!group.empty() && group.back().end >= regs[j].start) group.back().end = std::max(group.back().end, regs[j].end);
+            else group.push_back(regs[j]);
+            ++j;
+        }
+        if (regs[i].ref_id < c->bai.refs.size())
+            for (auto& ch : group_chunks(c->bai, group)) {
+                if (ch.beg >= ch.end) continue;
+                uint32_t bb = 0, be = 0;
+                uint64_t ub = voffset_to_stream(c, ch.beg, &bb), ue = voffset_to_stream(c, ch.end, &be);
+                ub = std::max(ub, first);
+                ue = std::min(ue, total);
+                if (ub >= ue || bb >= nb) continue;
+                while (bb + 1 < nb && c->blocks.out_off[bb + 1] <= ub) ++bb;      // (a chunk start at the very end of a block)
+                const uint32_t b1 = (be < nb && ue > c->blocks.out_off[be]) ? be + 1 : be;
+                runs.push_back({bb, std::max(b1, bb + 1), ub, ue});
+            }
+        i = j;
+    }
+    std::sort(runs.begin(), runs.end(), [](const FileRun& a, const FileRun& b) { return a.ub != b.ub ? a.ub < b.ub : a.ue < b.ue; });
+    std::vector<FileRun> merged;
+    for (auto& r : runs) {
+        if (!merged.empty() && r.blk0 <= merged.back().blk1 + 1 && r.ub >= merged.back().ub) {
+            FileRun& m = merged.back();
+            m.ue = std::max(m.ue, r.ue);
+            m.blk1 = std::max(m.blk1, r.blk1);
+        } else merged.push_back(r);
+    }
+    return merged;
+}
+
+void build_worklist(const sbx_ctx* c, std::vector<FileRun> runs, bool file_resident, WorkList* w) {
+    *w = WorkList();
+    w->runs = std::move(runs);
+    uint64_t uo = 0, co = 0;
+    for (size_t ri = 0; ri < w->runs.size(); ++ri) {
+        const FileRun& r = w->runs[ri];
+        const uint32_t first_local = (uint32_t)w->file_blk.size();
+        const uint64_t cbase = c->blocks.coffset[r.blk0];
+        const uint64_t cend = c->blocks.comp_off[r.blk1 - 1] + c->blocks.comp_len[r.blk1 - 1] + 8;     // + CRC32, ISIZE
+        if (!file_resident) w->ranges.push_back({cbase, cend - cbase, co});
+        for (uint32_t b = r.blk0; b < r.blk1; ++b) {
+            w->file_blk.push_back(b);
+            w->comp_off.push_back(file_resident ? c->blocks.comp_off[b] : co + (c->blocks.comp_off[b] - cbase));
+            w->comp_len.push_back(c->blocks.comp_len[b]);
+            w->isize.push_back(c->blocks.isize[b]);
+            w->run_of.push_back((uint32_t)ri);
+            w->out_off.push_back(uo + (c->blocks.out_off[b] - c->blocks.out_off[r.blk0]));
+        }
+        const uint64_t ubase = c->blocks.out_off[r.blk0];
+        w->chain.push_back({uo + (r.ub - ubase), uo + (r.ue - ubase), first_local, (uint32_t)w->file_blk.size() - 1});
+        uo += c->blocks.out_off[r.blk1] - ubase;
+        co += (cend - cbase + 15) & ~15ull;
+    }
+    w->out_off.push_back(uo);
+    w->u_bytes = uo;
+    w->comp_bytes = file_resident ? c->file.size : co;
+}
+
+// ---- host -> device copies of file bytes: pread by a few threads into pinned staging buffers, asynchronous DMA from
+// there on the copy stream, two buffers in flight ------------------------------------------------------------------
+void ensure_staging(sbx_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        if (!c->stage[i]) SBX_HIP(hipHostMalloc((void**)&c->stage[i], kStageBytes, hipHostMallocDefault));
+        if (!c->stage_ev[i]) SBX_HIP(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+    }
+    if (!c->upload_done) SBX_HIP(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
+}
+
+void read_file_bytes(const sbx_ctx* c, uint64_t off, size_t n, uint8_t* dst) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t n_thr = n < (4u << 20) ? 1 : std::min<size_t>(8, hw);
+    auto work = [&](size_t lo, size_t hi) {
+        while (lo < hi) {
+            ssize_t k = pread(c->file.fd, dst + lo, hi - lo, (off_t)(off + lo));
+            if (k <= 0) { memcpy(dst + lo, c->file.data + off + lo, hi - lo); break; }     // (the mapping always works)
+            lo += (size_t)k;
+        }
+    };
+    if (n_thr == 1) { work(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + n_thr - 1) / n_thr;
+    for (size_t t = 0; t < n_thr; ++t) {
+        const size_t lo = std::min(n, t * per), hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back(work, lo, hi);
+    }
+    for (auto& t : th) t.join();
+}
+
+// copies the ranges into d_comp; the compute stream waits for the last DMA (no host synchronisation here)
+void upload_ranges(sbx_ctx* c, const std::vector<WorkList::Range>& ranges) {
+    ensure_staging(c);
+    int cur = 0;
+    bool used[2] = {false, false};
+    for (auto& r : ranges)
+        for (uint64_t done = 0; done < r.len;) {
+            const size_t n = (size_t)std::min<uint64_t>(kStageBytes, r.len - done);
+            if (used[cur]) SBX_HIP(hipEventSynchronize(c->stage_ev[cur]));
+            read_file_bytes(c, r.file_off + done, n, c->stage[cur]);
+            SBX_HIP(hipMemcpyAsync(c->d_comp.p + r.dst + done, c->stage[cur], n, hipMemcpyHostToDevice, c->copy_stream));
+            SBX_HIP(hipEventRecord(c->stage_ev[cur], c->copy_stream));
+            used[cur] = true;
+            cur ^= 1;
+            done += n;
+        }
+    SBX_HIP(hipEventRecord(c->upload_done, c->copy_stream));
+    SBX_HIP(hipStreamWaitEvent(c->stream, c->upload_done, 0));
+}
+
+// makes `runs` the resident work list: per-block tables on the device and (unless the file is preloaded) the payload bytes
+void make_resident(sbx_ctx* c, std::vector<FileRun> runs) {
+    if (c->wl_resident && c->wl.runs == runs) return;
+    c->wl_resident = false;
+    build_worklist(c, std::move(runs), c->preloaded, &c->wl);
+    const WorkList& w = c->wl;
+    const size_t n = w.n_blocks();
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    c->d_comp_off.ensure(n + 1);
+    c->d_comp_len.ensure(n + 1);
+    c->d_isize.ensure(n + 1);
+    c->d_run_of.ensure(n + 1);
+    c->d_out_off.ensure(n + 1);
+    c->d_runs.ensure(w.chain.size() + 1);
+    hipStream_t s = c->stream;
     if (n) {
-        SBX_HIP(hipMemcpy(c->d_comp_off.p, c->blocks.comp_off.data(), n * 8, hipMemcpyHostToDevice));
-        SBX_HIP(hipMemcpy(c->d_comp_len.p, c->blocks.comp_len.data(), n * 4, hipMemcpyHostToDevice));
-        SBX_HIP(hipMemcpy(c->d_isize.p, c->blocks.isize.data(), n * 4, hipMemcpyHostToDevice));
+        SBX_HIP(hipMemcpyAsync(c->d_comp_off.p, w.comp_off.data(), n * 8, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_comp_len.p, w.comp_len.data(), n * 4, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_isize.p, w.isize.data(), n * 4, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_run_of.p, w.run_of.data(), n * 4, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_runs.p, w.chain.data(), w.chain.size() * sizeof(ChainRun), hipMemcpyHostToDevice, s));
     }
-    SBX_HIP(hipMemcpy(c->d_out_off.p, c->blocks.out_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    c->tables_uploaded = true;
+    SBX_HIP(hipMemcpyAsync(c->d_out_off.p, w.out_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (!c->preloaded) {
+        c->d_comp.ensure((size_t)w.comp_bytes + 64);
+        upload_ranges(c, w.ranges);
+        SBX_HIP(hipStreamSynchronize(c->copy_stream));
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        c->stats.ms_h2d = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    }
+    c->wl_resident = true;
 }
 
-void upload_file(sbx_ctx* c) {
-    if (c->comp_resident) return;
-    EventTimer t;
-    t.start(c->stream);
-    c->d_comp.alloc(c->file.size + 64);
-    SBX_HIP(hipMemsetAsync(c->d_comp.p + c->file.size, 0, 64, c->stream));
-    if (c->file.size) SBX_HIP(hipMemcpyAsync(c->d_comp.p, c->file.data, c->file.size, hipMemcpyHostToDevice, c->stream));
-    t.stop(c->stream);
-    c->stats.ms_h2d = t.ms();
-    c->comp_resident = true;
-}
-
-// Inflate blocks [b0,b1) into d_U.  Every buffer is sized for this block range only (a whole-genome BAM
-// is processed in batches of contigs, sbx_run_batch); the kernels address by absolute stream offset / block
-// index, so they get pointers biased by the range's first offsets.
-void inflate_blocks(sbx_ctx* c, uint32_t b0, uint32_t b1, hipEvent_t ev_mid = nullptr) {
-    if (b1 <= b0) {
-        if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, c->stream));
-        return;
-    }
-    uint32_t n = b1 - b0;
-    const uint64_t o0 = c->blocks.out_off[b0], o1 = c->blocks.out_off[b1];
-    c->u_base = o0;
-    c->d_U.ensure((size_t)(o1 - o0) + 64);
+// Inflate the blocks of the resident work list into d_U.
+void inflate_worklist(sbx_ctx* c, hipEvent_t ev_mid) {
+    const WorkList& w = c->wl;
+    const uint32_t n = (uint32_t)w.n_blocks();
+    c->d_U.ensure((size_t)w.u_bytes + 128);
     c->d_status.ensure(n + 1);
     c->d_nent.ensure(n + 1);
     c->d_scratch.ensure(inflate_scratch_bytes(n));
-    const size_t lit0 = inflate_lit_bytes(o0, b0) - inflate_lit_bytes(0, 0), ent0 = inflate_ent_words(o0, b0) - inflate_ent_words(0, 0);
-    c->d_lit.ensure(inflate_lit_bytes(o1, b1) - lit0);
-    c->d_ent.ensure(inflate_ent_words(o1, b1) - ent0);
-    launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p + b0, c->d_comp_len.p + b0, c->d_isize.p + b0, c->d_out_off.p + b0,
-                        c->d_U.p - o0, n, b0, c->d_scratch.p, c->d_lit.p - lit0, c->d_ent.p - ent0, c->d_nent.p, c->d_status.p,
-                        c->stream, ev_mid);
+    c->d_lit.ensure(inflate_lit_bytes(w.u_bytes, n));
+    c->d_ent.ensure(inflate_ent_words(w.u_bytes, n));
+    launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p, c->d_comp_len.p, c->d_isize.p, c->d_out_off.p, c->d_U.p, n, 0, c->d_scratch.p,
+                        c->d_lit.p, c->d_ent.p, c->d_nent.p, c->d_status.p, c->stream, ev_mid);
 }
 
-void check_inflate_status(sbx_ctx* c, uint32_t b0, uint32_t b1) {
-    if (b1 <= b0) return;
-    std::vector<uint32_t> st(b1 - b0);
-    SBX_HIP(hipMemcpyAsync(st.data(), c->d_status.p, st.size() * 4, hipMemcpyDeviceToHost, c->stream));
+// inflates the first k BGZF blocks of the file into host memory (BAM header at open)
+void inflate_prefix(sbx_ctx* c, uint32_t k, std::vector<uint8_t>* host) {
+    const BlockTable& bt = c->blocks;
+    const uint64_t in_end = bt.comp_off[k - 1] + bt.comp_len[k - 1], out_end = bt.out_off[k];
+    DevBuf<uint8_t> d_in(in_end + 64), d_out(out_end + 128), d_scr(inflate_scratch_bytes(k)), d_lit(inflate_lit_bytes(out_end, k));
+    DevBuf<uint32_t> d_ent(inflate_ent_words(out_end, k)), d_nent(k), d_clen(k), d_isz(k), d_st(k);
+    DevBuf<uint64_t> d_coff(k), d_ooff(k);
+    SBX_HIP(hipMemset(d_in.p + in_end, 0, 64));
+    SBX_HIP(hipMemcpy(d_in.p, c->file.data, in_end, hipMemcpyHostToDevice));
+    SBX_HIP(hipMemcpy(d_coff.p, bt.comp_off.data(), k * 8ull, hipMemcpyHostToDevice));
+    SBX_HIP(hipMemcpy(d_ooff.p, bt.out_off.data(), k * 8ull, hipMemcpyHostToDevice));
+    SBX_HIP(hipMemcpy(d_clen.p, bt.comp_len.data(), k * 4ull, hipMemcpyHostToDevice));
+    SBX_HIP(hipMemcpy(d_isz.p, bt.isize.data(), k * 4ull, hipMemcpyHostToDevice));
+    launch_bgzf_inflate(d_in.p, d_coff.p, d_clen.p, d_isz.p, d_ooff.p, d_out.p, k, 0, d_scr.p, d_lit.p, d_ent.p, d_nent.p, d_st.p, c->stream);
+    std::vector<uint32_t> st(k);
     SBX_HIP(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < st.size(); ++i)
+    SBX_HIP(hipMemcpy(st.data(), d_st.p, k * 4ull, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < k; ++i)
         if (st[i] != 0)
-            throw Error(SBX_EFORMAT, "Error inflating BGZF block starting from offset " +
-                                         std::to_string(c->blocks.coffset[b0 + i]) + ": " + inflate_status_string(st[i]));
+            throw Error(SBX_EFORMAT, "Error inflating BGZF block starting from offset " + std::to_string(bt.coffset[i]) + ": " +
+                                         inflate_status_string(st[i]));
+    host->resize(out_end);
+    SBX_HIP(hipMemcpy(host->data(), d_out.p, out_end, hipMemcpyDeviceToHost));
 }
 
 void parse_header_on_device(sbx_ctx* c) {
     uint64_t total = c->blocks.out_off.back();
     if (total < 12) throw Error(SBX_EFORMAT, "BAM header is truncated");
-    upload_tables(c);
-    upload_file(c);
     uint32_t nb = (uint32_t)c->blocks.size();
     uint32_t k = std::min<uint32_t>(nb, 4);
     std::vector<uint8_t> host;
     for (;;) {
-        inflate_blocks(c, 0, k);
-        check_inflate_status(c, 0, k);
-        uint64_t have = c->blocks.out_off[k];
-        host.resize(have);
-        SBX_HIP(hipMemcpy(host.data(), c->d_U.p, have, hipMemcpyDeviceToHost));
-        if (parse_bam_header(host.data(), have, total, &c->hdr)) break;
+        inflate_prefix(c, k, &host);
+        if (parse_bam_header(host.data(), host.size(), total, &c->hdr)) break;
         if (k == nb) throw Error(SBX_EFORMAT, "BAM header is truncated");
         k = std::min<uint32_t>(nb, k * 4);
     }
@@ -216,6 +441,21 @@ void default_filter(sbx_filter* f) {
 }  // namespace
 
 extern "C" {
+
+size_t sbx_abi_sizeof(const char* name) {
+    if (!name) return 0;
+    const std::string n = name;
+    if (n == "sbx_region") return sizeof(sbx_region);
+    if (n == "sbx_region_stats") return sizeof(sbx_region_stats);
+    if (n == "sbx_header_info") return sizeof(sbx_header_info);
+    if (n == "sbx_regex_state") return sizeof(sbx_regex_state);
+    if (n == "sbx_regex") return sizeof(sbx_regex);
+    if (n == "sbx_filter_op") return sizeof(sbx_filter_op);
+    if (n == "sbx_filter") return sizeof(sbx_filter);
+    if (n == "sbx_batch") return sizeof(sbx_batch);
+    if (n == "sbx_run_stats") return sizeof(sbx_run_stats);
+    return 0;
+}
 
 int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len, const uint32_t* isize,
                        uint32_t n_blocks, uint8_t* out, const uint64_t* out_off, char* err, size_t errlen) {
@@ -264,6 +504,7 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
         require_device(device);
         SBX_HIP(hipGetDevice(&c->device));
         SBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        SBX_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         c->file.open(bam_paths[0]);
         c->blocks = scan_bgzf(c->file.data, c->file.size);
         c->has_index = load_bai(c->file.path, &c->bai);
@@ -306,6 +547,7 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
         set_err(err, errlen, e.what());
         if (c) for (sbx_ctx* m : c->members) sbx_close(m);
         if (c && c->stream) (void)hipStreamDestroy(c->stream);
+        if (c && c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         return nullptr;
     }
 }
@@ -314,6 +556,7 @@ void sbx_close(sbx_ctx* c) {
     if (!c) return;
     for (sbx_ctx* m : c->members) sbx_close(m);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     delete c;
 }
 
@@ -412,373 +655,378 @@ int sbx_set_regions(sbx_ctx* c, const sbx_region* r, size_t n) {
     });
 }
 
+// -L argument -> regions, exactly as depth_main does it (depth.d:1184-1208): a BED file (bed.d:59-152), or, when it
+// cannot be read as one, a region string (BioD/bio/core/region.d:97-246).
+int sbx_parse_regions(sbx_ctx* c, const char* arg, size_t* n_merged, size_t* n_raw) {
+    return guarded(c, [&] {
+        if (!c || !arg) throw Error(SBX_EINVAL, "null argument");
+        c->parsed_merged.clear(); c->parsed_raw.clear(); c->parsed_lines.clear();
+        std::vector<BedInterval> ivs;
+        std::vector<std::string> lines;
+        std::vector<size_t> line_of;
+        if (read_bed_file(arg, &ivs, &lines, &line_of)) {
+            c->parsed_merged = bed_merged(ivs, c->hdr);
+            // every kept region keeps its own input line (the reference pairs them by index, which misaligns when a
+            // line names a contig the BAM does not have -- SURVEY App. B-6)
+            for (size_t i = 0; i < ivs.size(); ++i) {
+                const int id = c->hdr.find_ref(ivs[i].chr);
+                if (id < 0) continue;
+                c->parsed_raw.push_back({(uint32_t)id, (uint32_t)ivs[i].beg, (uint32_t)ivs[i].end});
+                c->parsed_lines.push_back(lines[line_of[i]]);
+            }
+        } else {
+            const RegionString rs = parse_region_string(arg);
+            const int id = c->hdr.find_ref(rs.reference);
+            if (id < 0) throw Error(SBX_EINVAL, std::string("couldn't open file ") + arg + " or find reference " + rs.reference);
+            sbx_region g{(uint32_t)id, rs.beg, rs.end};
+            if (g.end == 0xFFFFFFFFu) g.end = (uint32_t)c->hdr.refs[(size_t)id].length;
+            c->parsed_merged.push_back(g);
+            c->parsed_raw.push_back(g);
+            c->parsed_lines.push_back(rs.reference + "\t" + std::to_string(g.start) + "\t" + std::to_string(g.end));
+        }
+        if (n_merged) *n_merged = c->parsed_merged.size();
+        if (n_raw) *n_raw = c->parsed_raw.size();
+    });
+}
+int sbx_parsed_regions(sbx_ctx* c, int merged, sbx_region* out, size_t cap) {
+    if (!c || (!out && cap)) return SBX_EINVAL;
+    const auto& v = merged ? c->parsed_merged : c->parsed_raw;
+    if (cap < v.size()) return SBX_ENOMEM;
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return SBX_OK;
+}
+const char* sbx_parsed_region_line(sbx_ctx* c, size_t raw_index) {
+    return (c && raw_index < c->parsed_lines.size()) ? c->parsed_lines[raw_index].c_str() : nullptr;
+}
+
 int sbx_preload(sbx_ctx* c) {
     return guarded(c, [&] {
         if (!c) throw Error(SBX_EINVAL, "null context");
         SBX_HIP(hipSetDevice(c->device));
         for (sbx_ctx* m : files_of(c)) {
-            upload_tables(m);
-            upload_file(m);
-            SBX_HIP(hipStreamSynchronize(m->stream));
+            if (m->preloaded) continue;
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            m->d_comp.alloc(m->file.size + 64);
+            SBX_HIP(hipMemsetAsync(m->d_comp.p + m->file.size, 0, 64, m->copy_stream));
+            upload_ranges(m, {{0, m->file.size, 0}});
+            SBX_HIP(hipStreamSynchronize(m->copy_stream));
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            m->stats.ms_h2d = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+            m->preloaded = true;
+            m->wl_resident = false;
         }
     });
 }
 
+// small tables of a pass that depend on the header, the filter and the read selection only
+static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted, uint32_t T, uint64_t* n_tiles,
+                          RefTable* refs_out, RgTable* rg_out) {
+    hipStream_t s = c->stream;
+    const int32_t n_ref = (int32_t)c->hdr.refs.size();
+    c->h_ref_len.assign((size_t)n_ref, 0);
+    c->h_tile_base_up.assign((size_t)n_ref + 1, 0);
+    uint64_t nt = 0;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        c->h_ref_len[(size_t)r] = c->hdr.refs[(size_t)r].length;
+        c->h_tile_base_up[(size_t)r] = (uint32_t)nt;
+        // one spare tile per contig for alignments hanging over the contig end
+        nt += ((uint64_t)std::max(0, c->hdr.refs[(size_t)r].length) + T - 1) / T + 1;
+        if (nt > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "too many position tiles");
+    }
+    c->h_tile_base_up[(size_t)n_ref] = (uint32_t)nt;
+    *n_tiles = nt;
+    c->d_ref_len.ensure((size_t)n_ref + 1);
+    c->d_tile_base.ensure((size_t)n_ref + 1);
+    if (n_ref) SBX_HIP(hipMemcpyAsync(c->d_ref_len.p, c->h_ref_len.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice, s));
+    SBX_HIP(hipMemcpyAsync(c->d_tile_base.p, c->h_tile_base_up.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+    // -L: merged, start-sorted regions per contig for the read selection in K2
+    if (restricted) {
+        const std::vector<sbx_region> regs = sorted_regions(sel);
+        c->h_sel.clear();
+        c->h_sel_first.assign((size_t)n_ref + 1, 0);
+        size_t j = 0;
+        for (int32_t r = 0; r < n_ref; ++r) {
+            c->h_sel_first[(size_t)r] = (uint32_t)c->h_sel.size();
+            bool open = false;
+            while (j < regs.size() && regs[j].ref_id == (uint32_t)r) {
+                if (open && c->h_sel.back().end >= regs[j].start) c->h_sel.back().end = std::max(c->h_sel.back().end, regs[j].end);
+                else { c->h_sel.push_back({regs[j].start, regs[j].end, 0}); open = true; }
+                ++j;
+            }
+        }
+        c->h_sel_first[(size_t)n_ref] = (uint32_t)c->h_sel.size();
+        c->d_sel.ensure(c->h_sel.size() + 1);
+        c->d_sel_first.ensure((size_t)n_ref + 2);
+        if (!c->h_sel.empty()) SBX_HIP(hipMemcpyAsync(c->d_sel.p, c->h_sel.data(), c->h_sel.size() * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_sel_first.p, c->h_sel_first.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+    }
+    *refs_out = RefTable{c->d_ref_len.p, c->d_tile_base.p, n_ref, restricted ? c->d_sel.p : nullptr, restricted ? c->d_sel_first.p : nullptr};
+    // filter
+    c->d_filter.ensure(1);
+    DeviceFilter& df = c->h_df;
+    memset(&df, 0, sizeof df);
+    df.n_ops = c->filter.n_ops;
+    memcpy(df.ops, c->filter.ops, sizeof(sbx_filter_op) * (size_t)c->filter.n_ops);
+    memcpy(df.strings, c->filter.strings, sizeof df.strings);
+    memcpy(df.regex, c->filter.regex, sizeof df.regex);
+    df.n_ref = n_ref;
+    c->h_ref_sets.clear();
+    for (int i = 0; i < df.n_ops; ++i) {
+        // ref_name / mate_ref_name == 'x' becomes a comparison of the reference id ("*" is the name of id -1)
+        sbx_filter_op& o = df.ops[i];
+        if (o.kind == 15 && o.field >= 4) {
+            // ref_name =~ /re/: one byte per reference id + 1 ("*", the name of id -1, first)
+            const sbx_regex& re = df.regex[o.value & 1];
+            const size_t at0 = c->h_ref_sets.size();
+            auto hit = [&](const std::string& nm) { return re_search(re, (uint32_t)nm.size(), [&](uint32_t k) { return (uint8_t)nm[k]; }) ? 1 : 0; };
+            c->h_ref_sets.push_back((uint8_t)hit("*"));
+            for (auto& r : c->hdr.refs) c->h_ref_sets.push_back((uint8_t)hit(r.name));
+            o.kind = 16;
+            o.field = (uint8_t)(o.field - 4);
+            o.value = (int64_t)at0;
+            continue;
+        }
+        if (o.kind != 11) continue;
+        const size_t off = (size_t)(o.value & 0xFFFFFFFF), len = (size_t)(o.value >> 32);
+        const std::string name(df.strings + std::min(off, sizeof df.strings), std::min(len, sizeof df.strings - std::min(off, sizeof df.strings)));
+        const int id = name == "*" ? -1 : c->hdr.find_ref(name);
+        if (id < 0 && name != "*") { o.kind = (o.cmp == 4) ? 12 : 6; continue; }     // unknown name: never equal
+        o.kind = 2;
+        o.field = o.field ? 4 : 0;
+        o.value = id;
+    }
+    c->d_ref_sets.ensure(c->h_ref_sets.size() + 1);
+    if (!c->h_ref_sets.empty()) SBX_HIP(hipMemcpyAsync(c->d_ref_sets.p, c->h_ref_sets.data(), c->h_ref_sets.size(), hipMemcpyHostToDevice, s));
+    df.ref_sets = c->d_ref_sets.p;
+    SBX_HIP(hipMemcpyAsync(c->d_filter.p, &df, sizeof df, hipMemcpyHostToDevice, s));
+    // read groups
+    *rg_out = RgTable{nullptr, nullptr, nullptr, 0, 0};
+    if (!c->hdr.read_groups.empty()) {
+        c->h_rg_ids.clear();
+        c->h_rg_off.clear();
+        for (auto& g : c->hdr.read_groups) { c->h_rg_off.push_back((uint32_t)c->h_rg_ids.size()); c->h_rg_ids += g.id; c->h_rg_ids.push_back('\0'); }
+        c->d_rg_ids.ensure(c->h_rg_ids.size());
+        c->d_rg_off.ensure(c->h_rg_off.size());
+        c->d_rg_sample.ensure(c->h_rg_off.size());
+        SBX_HIP(hipMemcpyAsync(c->d_rg_ids.p, c->h_rg_ids.data(), c->h_rg_ids.size(), hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_rg_off.p, c->h_rg_off.data(), c->h_rg_off.size() * 4, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_rg_sample.p, c->hdr.rg_sample.data(), c->h_rg_off.size() * 2, hipMemcpyHostToDevice, s));
+        *rg_out = RgTable{c->d_rg_ids.p, c->d_rg_off.p, c->d_rg_sample.p, (int32_t)c->h_rg_off.size(), 1};
+    }
+}
+
 // The whole device pipeline for the reads selected by `sel` (restricted == false: every read of the file).
 static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
-    {
-        if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
-        if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
-        SBX_HIP(hipSetDevice(c->device));
-        hipStream_t s = c->stream;
-        c->have_run = false;
-        double ms_h2d = c->stats.ms_h2d;
-        c->stats = sbx_run_stats{};
-        upload_tables(c);
-        upload_file(c);
-        if (c->stats.ms_h2d == 0) c->stats.ms_h2d = ms_h2d;
-        const uint32_t nb_file = (uint32_t)c->blocks.size();
-        const uint64_t total_file = c->blocks.out_off.back();
-        // ---- work list: the whole file, or (with -L) the contiguous run of BGZF blocks that holds every
-        // BAI chunk of the requested regions (RandomAccessManager.getGroupChunks, randomaccessmanager.d:247-294;
-        // chunk boundaries are record boundaries, so the record chain of the sub-stream is exact).  Records of
-        // the run that lie outside the regions cannot change any reported number.
-        uint32_t blk0 = 0, blk1 = nb_file;
-        uint64_t first_off = c->hdr.first_record_off, total = total_file;
-        if (restricted) {
-            std::vector<sbx_region> regs = sel;
-            std::sort(regs.begin(), regs.end(), [](const sbx_region& a, const sbx_region& b) {
-                if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
-                if (a.start != b.start) return a.start < b.start;
-                return a.end < b.end;
-            });
-            uint64_t vbeg = ~0ull, vend = 0;
-            for (size_t i = 0; i < regs.size();) {
-                size_t j = i;
-                std::vector<sbx_region> group;
-                while (j < regs.size() && regs[j].ref_id == regs[i].ref_id) {
-                    if (!group.empty() && group.back().end >= regs[j].start) group.back().end = std::max(group.back().end, regs[j].end);
-                    else group.push_back(regs[j]);
-                    ++j;
-                }
-                if (regs[i].ref_id < c->bai.refs.size())
-                    for (auto& ch : group_chunks(c->bai, group)) { vbeg = std::min(vbeg, ch.beg); vend = std::max(vend, ch.end); }
-                i = j;
-            }
-            auto to_u = [&](uint64_t v, uint32_t* blk) -> uint64_t {   // virtual offset -> offset in the inflated stream
-                uint64_t co = v >> 16, uo = v & 0xFFFF;
-                size_t bi = (size_t)(std::lower_bound(c->blocks.coffset.begin(), c->blocks.coffset.end(), co) - c->blocks.coffset.begin());
-                if (bi >= nb_file) { *blk = nb_file; return total_file; }     // at / beyond the EOF block
-                if (c->blocks.coffset[bi] != co) throw Error(SBX_EFORMAT, "BAI virtual offset does not point at a BGZF block");
-                *blk = (uint32_t)bi;
-                return c->blocks.out_off[bi] + uo;
-            };
-            if (vbeg >= vend) { blk0 = blk1 = 0; first_off = total = c->hdr.first_record_off; }
-            else {
-                uint32_t bb = 0, be = 0;
-                uint64_t ub = to_u(vbeg, &bb), ue = to_u(vend, &be);
-                first_off = std::max(ub, c->hdr.first_record_off);
-                total = std::max(first_off, std::min(ue, total_file));
-                blk0 = bb;
-                blk1 = (be < nb_file && total > c->blocks.out_off[be]) ? be + 1 : be;
-                if (blk1 < blk0) blk1 = blk0;
-            }
-        }
-        const uint32_t nb = blk1 - blk0;
-        EventTimer t_all, t1, t1m, t2, t3;
-        t_all.start(s);
+    if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
+    if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
+    SBX_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->have_run = false;
+    const double ms_h2d_prev = c->stats.ms_h2d;
+    c->stats = sbx_run_stats{};
+    if (!c->res) SBX_HIP(hipHostMalloc((void**)&c->res, sizeof(HostResults), hipHostMallocDefault));
+    HostResults& R = *c->res;
 
-        // ---- K1 ----
-        t1.start(s);
-        inflate_blocks(c, blk0, blk1, t1m.b);
-        t1.stop(s);
-        check_inflate_status(c, blk0, blk1);
+    // ---- work list, tables, compressed bytes ----
+    make_resident(c, build_runs(c, sel, restricted));
+    if (c->stats.ms_h2d == 0) c->stats.ms_h2d = ms_h2d_prev;
+    const WorkList& w = c->wl;
+    const uint32_t nb = (uint32_t)w.n_blocks();
+    EventTimer t_all, t1, t1m, t2, t3;
+    t_all.start(s);
 
-        // ---- K2 ----
-        const int32_t n_ref = (int32_t)c->hdr.refs.size();
-        const uint32_t S = c->combined ? 1u : (uint32_t)c->hdr.sample_names.size();
-        const uint32_t T = std::max<uint32_t>(16, floor_pow2(std::max<uint32_t>(1, 1024u / std::max<uint32_t>(1, S))));
-        std::vector<int32_t> ref_len((size_t)n_ref);
-        std::vector<uint32_t> tile_base((size_t)n_ref + 1);
-        uint64_t nt = 0;
-        for (int32_t r = 0; r < n_ref; ++r) {
-            ref_len[(size_t)r] = c->hdr.refs[(size_t)r].length;
-            tile_base[(size_t)r] = (uint32_t)nt;
-            // one spare tile per contig for alignments hanging over the contig end
-            nt += ((uint64_t)std::max(0, c->hdr.refs[(size_t)r].length) + T - 1) / T + 1;
-            if (nt > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "too many position tiles");
-        }
-        tile_base[(size_t)n_ref] = (uint32_t)nt;
-        c->d_ref_len.ensure((size_t)n_ref + 1);
-        c->d_tile_base.ensure((size_t)n_ref + 1);
-        if (n_ref) SBX_HIP(hipMemcpyAsync(c->d_ref_len.p, ref_len.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice, s));
-        SBX_HIP(hipMemcpyAsync(c->d_tile_base.p, tile_base.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
-        // -L: merged, start-sorted regions per contig for the read selection in `describe`
-        DevBuf<SortedRegion> d_sel;
-        DevBuf<uint32_t> d_sel_first;
-        if (restricted) {
-            std::vector<sbx_region> regs = sel;
-            std::sort(regs.begin(), regs.end(), [](const sbx_region& x, const sbx_region& y) {
-                if (x.ref_id != y.ref_id) return x.ref_id < y.ref_id;
-                if (x.start != y.start) return x.start < y.start;
-                return x.end < y.end;
-            });
-            std::vector<SortedRegion> merged;
-            std::vector<uint32_t> first((size_t)n_ref + 1, 0);
-            size_t j = 0;
-            for (int32_t r = 0; r < n_ref; ++r) {
-                first[(size_t)r] = (uint32_t)merged.size();
-                bool open = false;
-                while (j < regs.size() && regs[j].ref_id == (uint32_t)r) {
-                    if (open && merged.back().end >= regs[j].start) merged.back().end = std::max(merged.back().end, regs[j].end);
-                    else { merged.push_back({regs[j].start, regs[j].end, 0}); open = true; }
-                    ++j;
-                }
-            }
-            first[(size_t)n_ref] = (uint32_t)merged.size();
-            d_sel.alloc(merged.size() + 1);
-            d_sel_first.alloc((size_t)n_ref + 2);
-            if (!merged.empty()) SBX_HIP(hipMemcpyAsync(d_sel.p, merged.data(), merged.size() * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
-            SBX_HIP(hipMemcpyAsync(d_sel_first.p, first.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
-            SBX_HIP(hipStreamSynchronize(s));
-        }
-        RefTable refs{c->d_ref_len.p, c->d_tile_base.p, n_ref, restricted ? d_sel.p : nullptr, restricted ? d_sel_first.p : nullptr};
+    // ---- K1 ----
+    t1.start(s);
+    inflate_worklist(c, t1m.b);
+    t1.stop(s);
 
-        c->d_entry.ensure(nb + 1);
-        c->d_exit.ensure(nb + 1);
-        c->d_ckpt.ensure(3 * (size_t)nb + 3);
-        c->d_count.ensure(nb + 1);
-        c->d_base.ensure(nb + 2);
-        c->d_flag.ensure(4);
-        const bool dbg = getenv("SBX_DEBUG") != nullptr;
-        auto lap = [&](const char* what) {
-            if (!dbg) return;
-            static thread_local double t_prev = 0;
-            SBX_HIP(hipStreamSynchronize(s));
-            struct timespec ts2; clock_gettime(CLOCK_MONOTONIC, &ts2);
-            double now = ts2.tv_sec * 1e3 + ts2.tv_nsec * 1e-6;
-            fprintf(stderr, "[sbx]   %-14s +%.3f ms\n", what, t_prev ? now - t_prev : 0.0);
-            t_prev = now;
-        };
-        lap("start-index");
-        t2.start(s);
-        launch_block_walk(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, refs, c->d_entry.p,
-                          c->d_exit.p, c->d_count.p, c->d_ckpt.p, s);
-        lap("block_walk");
-        uint32_t verify_iters = 0;   // number of blocks whose guessed entry had to be re-walked
-        {
-            // check -> repair the first inconsistent stretch -> re-check ...; wrong guesses are rare and
-            // isolated, so this converges in a handful of rounds; a file full of them (e.g. records much
-            // longer than a BGZF block) falls back to one serial pass over the rest of the chain
-            SBX_HIP(hipMemsetAsync(c->d_flag.p + 1, 0, 4, s));
-            const char* force = getenv("SBX_FORCE_REPAIR");   // debug hook (tests/test_gpu_repair.py)
-            for (int round = 0;; ++round) {
-                uint32_t first_bad = 0xFFFFFFFFu;
-                SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 4, s));
-                launch_chain_check(c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, c->d_entry.p, c->d_exit.p, c->d_flag.p, s);
-                SBX_HIP(hipMemcpyAsync(&first_bad, c->d_flag.p, 4, hipMemcpyDeviceToHost, s));
-                SBX_HIP(hipStreamSynchronize(s));
-                bool forced = false;
-                if (force && round == 0) { uint32_t f = (uint32_t)atoi(force); if (f < first_bad && f < nb) { first_bad = f; forced = true; } }
-                if (first_bad == 0xFFFFFFFFu || first_bad >= nb) break;
-                const bool to_the_end = forced || round >= 16;
-                launch_chain_repair(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, first_off, first_bad,
-                                    !to_the_end, c->d_entry.p, c->d_exit.p, c->d_count.p, c->d_ckpt.p, c->d_flag.p + 1, s);
-                if (round > 64) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
-            }
-            SBX_HIP(hipMemcpyAsync(&verify_iters, c->d_flag.p + 1, 4, hipMemcpyDeviceToHost, s));
-            SBX_HIP(hipStreamSynchronize(s));
+    // ---- K2 ----
+    const int32_t n_ref = (int32_t)c->hdr.refs.size();
+    const uint32_t S = c->combined ? 1u : (uint32_t)c->hdr.sample_names.size();
+    const uint32_t T = std::max<uint32_t>(16, floor_pow2(std::max<uint32_t>(1, 1024u / std::max<uint32_t>(1, S))));
+    if ((size_t)448 * S + 64 > 160u * 1024)
+        throw Error(SBX_EUNSUPPORTED, "too many samples for the device path (" + std::to_string(S) + "): the counters of a position tile no longer fit "
+                                      "the LDS of a compute unit; use --combined");
+    uint64_t nt = 0;
+    RefTable refs{};
+    RgTable rg{};
+    upload_static(c, sel, restricted, T, &nt, &refs, &rg);
+
+    c->d_entry.ensure(nb + 1);
+    c->d_exit.ensure(nb + 1);
+    c->d_state.ensure(nb + 1);
+    c->d_count.ensure(nb + 1);
+    c->d_flag.ensure(8);
+    c->d_tile_lo.ensure((size_t)nt + 1);
+    c->d_tile_hi.ensure((size_t)nt + 1);
+    c->d_active.ensure((size_t)nt + 1);
+    c->d_slot_of.ensure((size_t)nt + 1);
+    c->d_n_active.ensure(4);
+    c->d_stats.ensure(1);
+    // descriptor capacity: sized for records of >= 160 bytes on average; K2 reports an overflow and the pass is repeated
+    // with the exact number (short-read fixtures, amplicon data with tiny records)
+    uint64_t want_cap = std::max<uint64_t>(c->desc_cap, w.u_bytes / 160 + 4096);
+    const bool dbg = getenv("SBX_DEBUG") != nullptr;
+    const char* force = getenv("SBX_FORCE_REPAIR");   // debug hook (tests/test_gpu_repair.py)
+    uint32_t n_rewalked = 0;
+    uint64_t n_records = 0;
+    bool entries_given = false;
+    t2.start(s);
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 4) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
+        if (want_cap > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "more than 2^32 records in one batch");
+        if (want_cap > c->desc_cap) {
+            c->d_desc.release(); c->d_rec_ref.release();
+            c->d_desc.alloc((size_t)want_cap + 64);
+            c->d_rec_ref.alloc((size_t)want_cap + 64);
+            if (c->d_name_hash.n) { c->d_name_hash.release(); }
+            c->desc_cap = want_cap;
         }
-        lap("chain_verify");
-        if (dbg && nb) {
-            std::vector<uint64_t> he(nb), hx(nb);
-            std::vector<uint32_t> hc(nb);
-            SBX_HIP(hipMemcpy(he.data(), c->d_entry.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
-            SBX_HIP(hipMemcpy(hx.data(), c->d_exit.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
-            SBX_HIP(hipMemcpy(hc.data(), c->d_count.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
-            uint64_t bad = 0, first = ~0ull, passthru = 0, sum = 0;
-            for (uint32_t b = 0; b < nb; ++b) {
-                uint64_t end = c->blocks.out_off[blk0 + b] + c->blocks.isize[blk0 + b];
-                uint64_t want = b ? hx[b - 1] : first_off;
-                sum += hc[b];
-                if (end <= first_off) continue;
-                if (he[b] >= end) ++passthru;
-                if (he[b] != want) { ++bad; if (first == ~0ull) first = b; }
-            }
-            fprintf(stderr, "[sbx]   chain: inconsistent=%llu first=%lld passthrough=%llu sum_count=%llu\n", (unsigned long long)bad,
-                    (long long)first, (unsigned long long)passthru, (unsigned long long)sum);
-            if (first != ~0ull)
-                fprintf(stderr, "[sbx]   block %llu: entry=%llu want=%llu exit=%llu count=%u beg=%llu\n", (unsigned long long)first,
-                        (unsigned long long)he[first], (unsigned long long)(first ? hx[first - 1] : 0), (unsigned long long)hx[first],
-                        hc[first], (unsigned long long)c->blocks.out_off[blk0 + first]);
-        }
-        if (nb) {
-            // the chain must end exactly at the end of the stream
-            uint64_t last_exit = 0;
-            SBX_HIP(hipMemcpy(&last_exit, c->d_exit.p + (nb - 1), 8, hipMemcpyDeviceToHost));
-            if (last_exit != total) throw Error(SBX_EFORMAT, "BAM record chain is broken (truncated or corrupt record)");
-        }
-        launch_count_scan(c->d_count.p, nb, c->d_base.p, nullptr, 0, s);
-        uint64_t n_records = 0;
-        SBX_HIP(hipMemcpyAsync(&n_records, c->d_base.p + nb, 8, hipMemcpyDeviceToHost, s));
-        SBX_HIP(hipStreamSynchronize(s));
-        if (n_records > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "more than 2^32 records in one batch");
-        c->d_desc.ensure((size_t)n_records + 64);
-        c->d_rec_ref.ensure((size_t)n_records + 64);
-        if (c->fix_mate) c->d_name_hash.ensure((size_t)n_records + 64);
-        c->d_tile_lo.ensure((size_t)nt + 1);
-        c->d_tile_hi.ensure((size_t)nt + 1);
-        c->d_active.ensure((size_t)nt + 1);
-        c->d_slot_of.ensure((size_t)nt + 1);
-        c->d_n_active.ensure(4);
+        if (c->fix_mate) c->d_name_hash.ensure((size_t)c->desc_cap + 64);
         SBX_HIP(hipMemsetAsync(c->d_tile_lo.p, 0xFF, (size_t)nt * 4, s));
         SBX_HIP(hipMemsetAsync(c->d_tile_hi.p, 0, (size_t)nt * 4, s));
-        // filter + read groups
-        c->d_filter.ensure(1);
-        DeviceFilter df;
-        memset(&df, 0, sizeof df);
-        df.n_ops = c->filter.n_ops;
-        memcpy(df.ops, c->filter.ops, sizeof(sbx_filter_op) * (size_t)c->filter.n_ops);
-        memcpy(df.strings, c->filter.strings, sizeof df.strings);
-        memcpy(df.regex, c->filter.regex, sizeof df.regex);
-        df.n_ref = n_ref;
-        std::vector<uint8_t> ref_sets;
-        for (int i = 0; i < df.n_ops; ++i) {
-            // ref_name / mate_ref_name == 'x' becomes a comparison of the reference id ("*" is the name of id -1)
-            sbx_filter_op& o = df.ops[i];
-            if (o.kind == 15 && o.field >= 4) {
-                // ref_name =~ /re/: one byte per reference id + 1 ("*", the name of id -1, first)
-                const sbx_regex& re = df.regex[o.value & 1];
-                const size_t at0 = ref_sets.size();
-                auto hit = [&](const std::string& nm) { return re_search(re, (uint32_t)nm.size(), [&](uint32_t k) { return (uint8_t)nm[k]; }) ? 1 : 0; };
-                ref_sets.push_back((uint8_t)hit("*"));
-                for (auto& r : c->hdr.refs) ref_sets.push_back((uint8_t)hit(r.name));
-                o.kind = 16;
-                o.field = (uint8_t)(o.field - 4);
-                o.value = (int64_t)at0;
-                continue;
-            }
-            if (o.kind != 11) continue;
-            const size_t off = (size_t)(o.value & 0xFFFFFFFF), len = (size_t)(o.value >> 32);
-            const std::string name(df.strings + std::min(off, sizeof df.strings), std::min(len, sizeof df.strings - std::min(off, sizeof df.strings)));
-            const int id = name == "*" ? -1 : c->hdr.find_ref(name);
-            if (id < 0 && name != "*") { o.kind = (o.cmp == 4) ? 12 : 6; continue; }     // unknown name: never equal
-            o.kind = 2;
-            o.field = o.field ? 4 : 0;
-            o.value = id;
-        }
-        c->d_ref_sets.ensure(ref_sets.size() + 1);
-        if (!ref_sets.empty()) SBX_HIP(hipMemcpyAsync(c->d_ref_sets.p, ref_sets.data(), ref_sets.size(), hipMemcpyHostToDevice, s));
-        df.ref_sets = c->d_ref_sets.p;
-        SBX_HIP(hipMemcpyAsync(c->d_filter.p, &df, sizeof df, hipMemcpyHostToDevice, s));
-        SBX_HIP(hipStreamSynchronize(s));      // df / ref_sets are locals
-        RgTable rg{nullptr, nullptr, nullptr, 0, 0};
-        std::string ids;
-        std::vector<uint32_t> id_off;
-        if (!c->hdr.read_groups.empty()) {
-            for (auto& g : c->hdr.read_groups) { id_off.push_back((uint32_t)ids.size()); ids += g.id; ids.push_back('\0'); }
-            c->d_rg_ids.ensure(ids.size());
-            c->d_rg_off.ensure(id_off.size());
-            c->d_rg_sample.ensure(id_off.size());
-            SBX_HIP(hipMemcpyAsync(c->d_rg_ids.p, ids.data(), ids.size(), hipMemcpyHostToDevice, s));
-            SBX_HIP(hipMemcpyAsync(c->d_rg_off.p, id_off.data(), id_off.size() * 4, hipMemcpyHostToDevice, s));
-            SBX_HIP(hipMemcpyAsync(c->d_rg_sample.p, c->hdr.rg_sample.data(), id_off.size() * 2, hipMemcpyHostToDevice, s));
-            rg = RgTable{c->d_rg_ids.p, c->d_rg_off.p, c->d_rg_sample.p, (int32_t)id_off.size(), 1};
-        }
-        c->d_stats.ensure(1);
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
-        lap("scan+setup");
-        launch_describe(c->U(), total, c->d_out_off.p + blk0, c->d_isize.p + blk0, nb, c->d_entry.p, c->d_ckpt.p, c->d_base.p, refs, c->d_filter.p, rg,
-                        T, c->d_desc.p, c->d_rec_ref.p, c->fix_mate ? c->d_name_hash.p : nullptr, c->d_tile_lo.p, c->d_tile_hi.p,
-                        c->d_stats.p, s);
-        lap("describe");
+        SBX_HIP(hipMemsetAsync(c->d_state.p, 0, ((size_t)nb + 1) * 8, s));
+        SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 8, s));           // [0] first inconsistent block, [1] first failed inflate
+        SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 24, s));         // [2] overflow, [3] ticket, [4] rewalked, [5] max partners
+        IndexArgs a{};
+        a.U = c->d_U.p;
+        a.u_alloc = (w.u_bytes + 15) & ~15ull;
+        a.out_off = c->d_out_off.p; a.isize = c->d_isize.p; a.run_of = c->d_run_of.p; a.runs = c->d_runs.p;
+        a.n_blocks = nb;
+        a.inflate_status = c->d_status.p;
+        a.entry_in = entries_given ? c->d_entry.p : nullptr;
+        a.entry = c->d_entry.p; a.exit_ = c->d_exit.p; a.count = c->d_count.p;
+        a.state = c->d_state.p; a.ticket = c->d_flag.p + 3;
+        a.refs = refs; a.filt = c->d_filter.p; a.rg = rg; a.tile_pos = T;
+        a.desc = c->d_desc.p; a.rec_ref = c->d_rec_ref.p; a.name_hash = c->fix_mate ? c->d_name_hash.p : nullptr;
+        a.desc_cap = c->desc_cap;
+        a.tile_lo = c->d_tile_lo.p; a.tile_hi = c->d_tile_hi.p; a.stats = c->d_stats.p; a.flags = c->d_flag.p;
+        launch_index_blocks(a, s);
         launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
-        lap("tile_compact");
-        t2.stop(s);
-        uint32_t n_active = 0;
-        IndexStats ist{};
-        SBX_HIP(hipMemcpyAsync(&n_active, c->d_n_active.p, 4, hipMemcpyDeviceToHost, s));
-        SBX_HIP(hipMemcpyAsync(&ist, c->d_stats.p, sizeof ist, hipMemcpyDeviceToHost, s));
-        SBX_HIP(hipStreamSynchronize(s));
-        if (ist.n_records != n_records)
-            throw Error(SBX_EFORMAT, "internal error: record chain (" + std::to_string(n_records) + ") and describe pass (" +
-                                         std::to_string(ist.n_records) + ") disagree on the number of records");
-        if (ist.n_unknown_rg)
-            throw Error(SBX_ERG, "error in read: read group is not present in the header (" + std::to_string(ist.n_unknown_rg) + " reads)");
-
-        // ---- K3 ----
-        const bool want_span = c->min_bq > 0 || (c->fix_mate && c->mode != SBX_MODE_BASE);
-        size_t per_tile = (size_t)T * S * SBX_NCOUNTERS;
-        c->d_counters.ensure((size_t)n_active * per_tile + 4);
-        if (want_span) c->d_span.ensure((size_t)n_active * T + 4);
-        if (c->fix_mate) {
-            c->d_mate.ensure((size_t)n_records + 64);
-            c->d_n_partners.ensure((size_t)n_records + 64);
-            SBX_HIP(hipMemsetAsync(c->d_mate.p, 0xFF, (size_t)n_records * 4, s));
-            SBX_HIP(hipMemsetAsync(c->d_n_partners.p, 0, (size_t)n_records * 4, s));
-            SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 4, s));
+        if (attempt == 0) t2.stop(s);
+        R.last_state = 0;
+        SBX_HIP(hipMemcpyAsync(R.flags, c->d_flag.p, 16, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(&R.n_active, c->d_n_active.p, 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(&R.st, c->d_stats.p, sizeof(IndexStats), hipMemcpyDeviceToHost, s));
+        if (nb) SBX_HIP(hipMemcpyAsync(&R.last_state, c->d_state.p + (nb - 1), 8, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));                            // ---- host synchronisation 1 of 2 ----
+        if (R.flags[1] != 0xFFFFFFFFu) {
+            uint32_t st = 0;
+            SBX_HIP(hipMemcpy(&st, c->d_status.p + R.flags[1], 4, hipMemcpyDeviceToHost));
+            throw Error(SBX_EFORMAT, "Error inflating BGZF block starting from offset " +
+                                         std::to_string(c->blocks.coffset[w.file_blk[R.flags[1]]]) + ": " + inflate_status_string(st));
         }
-        t3.start(s);
-        if (c->fix_mate) {
-            launch_find_mates(c->d_desc.p, c->d_name_hash.p, c->d_rec_ref.p, n_records, c->d_mate.p, c->d_n_partners.p, s);
-            launch_max_u32(c->d_n_partners.p, n_records, c->d_flag.p + 2, s);
-            uint32_t max_partners = 0;
-            SBX_HIP(hipMemcpyAsync(&max_partners, c->d_flag.p + 2, 4, hipMemcpyDeviceToHost, s));
+        n_records = R.last_state & ((1ull << 62) - 1);
+        uint32_t first_bad = R.flags[0];
+        bool forced = false;
+        if (force && attempt == 0 && !entries_given) { const uint32_t f = (uint32_t)atoi(force); if (f < first_bad && f < nb) { first_bad = f; forced = true; } }
+        if (dbg) fprintf(stderr, "[sbx]   index attempt %d: records=%llu first_bad=%u overflow=%u cap=%llu\n", attempt,
+                         (unsigned long long)n_records, first_bad, R.flags[2], (unsigned long long)c->desc_cap);
+        if (first_bad != 0xFFFFFFFFu && first_bad < nb) {
+            // a guessed entry was wrong (or a block holds no record start): follow the chain serially from there and
+            // launch again with the entries given; a chain that is still inconsistent then is a corrupt file
+            if (entries_given && !forced) throw Error(SBX_EFORMAT, "BAM record chain is broken (truncated or corrupt record)");
+            launch_chain_repair(c->d_U.p, c->d_out_off.p, c->d_isize.p, c->d_run_of.p, c->d_runs.p, nb, first_bad, c->d_entry.p, c->d_exit.p,
+                                c->d_count.p, c->d_flag.p + 4, s);
+            SBX_HIP(hipMemcpyAsync(&R.n_rewalked, c->d_flag.p + 4, 4, hipMemcpyDeviceToHost, s));
             SBX_HIP(hipStreamSynchronize(s));
-            if (max_partners > 1)
-                throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps: a read overlaps two or more records with the same name; the reference's "
-                                              "result then depends on per-column status history (depth.d:343-377) and is not on the device path");
-            if (c->mode == SBX_MODE_BASE) {
-                launch_accumulate_mates(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
-                                        c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
-            } else {
-                // region / window: the statistics come from per-column quantities, not from the base counters
-                c->d_covm.ensure((size_t)n_active * T * S + 1);
-                c->d_addm.ensure((size_t)n_active * T * S + 1);
-                if (n_active) SBX_HIP(hipMemsetAsync(c->d_counters.p, 0, (size_t)n_active * per_tile * 4, s));
-                launch_mates_columns(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
-                                     c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_covm.p, c->d_addm.p, c->d_span.p, s);
-            }
-        } else
+            n_rewalked += R.n_rewalked;
+            entries_given = true;
+            continue;
+        }
+        if (R.flags[2]) { want_cap = n_records + 1024; continue; }
+        break;
+    }
+    const IndexStats ist = R.st;
+    const uint32_t n_active = R.n_active;
+    if (ist.n_records != n_records)
+        throw Error(SBX_EFORMAT, "internal error: record chain (" + std::to_string(n_records) + ") and describe pass (" +
+                                     std::to_string(ist.n_records) + ") disagree on the number of records");
+    if (ist.n_unknown_rg)
+        throw Error(SBX_ERG, "error in read: read group is not present in the header (" + std::to_string(ist.n_unknown_rg) + " reads)");
+    if (ist.n_bad)
+        throw Error(SBX_EFORMAT, "malformed BAM record (" + std::to_string(ist.n_bad) + " records whose lengths are inconsistent with block_size, "
+                                 "whose reference id is out of range, or which start beyond the end of their contig)");
+
+    // ---- K3 ----
+    const bool want_span = c->min_bq > 0 || (c->fix_mate && c->mode != SBX_MODE_BASE);
+    size_t per_tile = (size_t)T * S * SBX_NCOUNTERS;
+    c->d_counters.ensure((size_t)n_active * per_tile + 4);
+    if (want_span) c->d_span.ensure((size_t)n_active * T + 4);
+    if (c->fix_mate) {
+        c->d_mate.ensure((size_t)n_records + 64);
+        c->d_n_partners.ensure((size_t)n_records + 64);
+        SBX_HIP(hipMemsetAsync(c->d_mate.p, 0xFF, (size_t)n_records * 4, s));
+        SBX_HIP(hipMemsetAsync(c->d_n_partners.p, 0, (size_t)n_records * 4, s));
+    }
+    t3.start(s);
+    if (c->fix_mate) {
+        launch_find_mates(c->U(), c->d_desc.p, c->d_name_hash.p, c->d_rec_ref.p, n_records, c->d_mate.p, c->d_n_partners.p, s);
+        launch_max_u32(c->d_n_partners.p, n_records, c->d_flag.p + 5, s);
+        SBX_HIP(hipMemcpyAsync(&R.max_partners, c->d_flag.p + 5, 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+        if (R.max_partners > 1)
+            throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps: a read overlaps two or more records with the same name; the reference's "
+                                          "result then depends on per-column status history (depth.d:343-377) and is not on the device path");
+        if (c->mode == SBX_MODE_BASE) {
+            launch_accumulate_mates(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
+                                    c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+        } else {
+            // region / window: the statistics come from per-column quantities, not from the base counters
+            c->d_covm.ensure((size_t)n_active * T * S + 1);
+            c->d_addm.ensure((size_t)n_active * T * S + 1);
+            if (n_active) SBX_HIP(hipMemsetAsync(c->d_counters.p, 0, (size_t)n_active * per_tile * 4, s));
+            launch_mates_columns(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
+                                 c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_covm.p, c->d_addm.p, c->d_span.p, s);
+        }
+    } else
         launch_accumulate(c->U(), c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, c->d_tile_base.p,
                           n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
-        t3.stop(s);
-        t_all.stop(s);
-        c->h_slot_of.resize((size_t)nt);
-        if (nt) SBX_HIP(hipMemcpyAsync(c->h_slot_of.data(), c->d_slot_of.p, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
-        SBX_HIP(hipStreamSynchronize(s));
+    t3.stop(s);
+    t_all.stop(s);
+    c->h_slot_of.resize((size_t)nt);
+    if (nt) SBX_HIP(hipMemcpyAsync(c->h_slot_of.data(), c->d_slot_of.p, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
+    SBX_HIP(hipStreamSynchronize(s));                                // ---- host synchronisation 2 of 2 ----
 
-        c->h_tile_base = tile_base;
-        c->tile_pos = T;
-        c->n_samples_eff = S;
-        c->n_tiles = (uint32_t)nt;
-        c->n_active = n_active;
-        c->span_valid = want_span;
-        c->stats.ms_inflate = t1.ms();
-        {
-            float f = 0;
-            SBX_HIP(hipEventElapsedTime(&f, t1.a, t1m.b));
-            c->stats.ms_huffman = f;
-            c->stats.ms_lz77 = c->stats.ms_inflate - f;
-        }
-        c->stats.ms_index = t2.ms();
-        c->stats.ms_accumulate = t3.ms();
-        c->stats.ms_total = t_all.ms();
-        c->stats.n_records = ist.n_records;
-        c->stats.n_admitted = ist.n_admitted;
-        c->stats.n_bgzf_blocks = nb;
-        c->stats.compressed_bytes = nb == nb_file ? c->file.size : (nb ? c->blocks.coffset[blk1 - 1] - c->blocks.coffset[blk0] + c->blocks.comp_len[blk1 - 1] + 26 : 0);
-        c->stats.uncompressed_bytes = nb ? c->blocks.out_off[blk1] - c->blocks.out_off[blk0] : 0;
-        c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4;
-        c->stats.covered_positions = (uint64_t)n_active * T;
-        c->stats.launches_inflate = 1;
-        c->stats.launches_index = 5 + (verify_iters ? 1 : 0);
-        if (getenv("SBX_DEBUG"))
-            fprintf(stderr, "[sbx] blocks=%u records=%llu rewalked_blocks=%u tiles=%llu active=%u T=%u\n", nb,
-                    (unsigned long long)n_records, verify_iters, (unsigned long long)nt, n_active, T);
-        c->stats.launches_accumulate = 1;
-        c->have_run = true;
+    c->h_tile_base = c->h_tile_base_up;
+    c->tile_pos = T;
+    c->n_samples_eff = S;
+    c->n_tiles = (uint32_t)nt;
+    c->n_active = n_active;
+    c->span_valid = want_span;
+    c->stats.ms_inflate = t1.ms();
+    {
+        float f = 0;
+        SBX_HIP(hipEventElapsedTime(&f, t1.a, t1m.b));
+        c->stats.ms_huffman = f;
+        c->stats.ms_lz77 = c->stats.ms_inflate - f;
     }
+    c->stats.ms_index = t2.ms();
+    c->stats.ms_accumulate = t3.ms();
+    c->stats.ms_total = t_all.ms();
+    c->stats.n_records = ist.n_records;
+    c->stats.n_admitted = ist.n_admitted;
+    c->stats.n_malformed = ist.n_bad;
+    c->stats.n_bgzf_blocks = nb;
+    c->stats.n_runs = w.runs.size();
+    c->stats.uploaded_bytes = w.comp_bytes;
+    {
+        uint64_t cb = 0;
+        for (auto& r : w.runs) cb += c->blocks.comp_off[r.blk1 - 1] + c->blocks.comp_len[r.blk1 - 1] + 8 - c->blocks.coffset[r.blk0];
+        c->stats.compressed_bytes = cb;
+    }
+    c->stats.uncompressed_bytes = w.u_bytes;
+    c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4;
+    c->stats.covered_positions = (uint64_t)n_active * T;
+    c->stats.launches_inflate = 1;
+    c->stats.launches_index = 2 + (n_rewalked ? 2 : 0);
+    if (dbg)
+        fprintf(stderr, "[sbx] blocks=%u runs=%zu records=%llu rewalked_blocks=%u tiles=%llu active=%u T=%u\n", nb, w.runs.size(),
+                (unsigned long long)n_records, n_rewalked, (unsigned long long)nt, n_active, T);
+    c->stats.launches_accumulate = 1;
+    c->have_run = true;
 }
 
 // Several BAMs: every file has been through the pipeline on its own; the per-position results are sums over the
@@ -874,12 +1122,13 @@ static void contig_blocks(sbx_ctx* c, uint32_t r, uint32_t* b0, uint32_t* b1) {
 }
 
 // estimated device bytes of a run over BGZF blocks [b0, b1) covering `positions` reference positions:
-// inflated stream + literal and entry token streams (~2.4x) + descriptors + counter tiles
+// compressed payload + inflated stream + literal and entry token streams (~2.4x) + descriptors + counter tiles
 static uint64_t footprint(sbx_ctx* c, uint32_t b0, uint32_t b1, uint64_t positions) {
     if (b1 <= b0) return 0;
     const uint64_t u = c->blocks.out_off[b1] - c->blocks.out_off[b0];
+    const uint64_t comp = c->preloaded ? 0 : c->blocks.coffset[b1 - 1] - c->blocks.coffset[b0] + 65536;
     const uint32_t S = c->combined ? 1u : (uint32_t)std::max<size_t>(1, c->hdr.sample_names.size());
-    return u + (u + 48ull * (b1 - b0)) + 4 * (u / 3 + u / 255 + 12ull * (b1 - b0)) + u / 8 + positions * (28ull * S + 4);
+    return comp + u + (u + 48ull * (b1 - b0)) + 4 * (u / 3 + u / 255 + 12ull * (b1 - b0)) + u / 4 + positions * (28ull * S + 4);
 }
 
 int sbx_plan_batches(sbx_ctx* c, uint64_t budget_bytes, sbx_batch* out, size_t cap, size_t* n_out) {
@@ -891,8 +1140,8 @@ int sbx_plan_batches(sbx_ctx* c, uint64_t budget_bytes, sbx_batch* out, size_t c
             size_t free_b = 0, total_b = 0;
             SBX_HIP(hipMemGetInfo(&free_b, &total_b));
             // what this context already holds (the compressed file, buffers of an earlier run) is reused
-            budget_bytes = (uint64_t)((double)free_b * 0.7) + c->d_U.bytes() + c->d_lit.bytes() + c->d_ent.bytes() + c->d_counters.bytes();
-            if (!c->comp_resident) budget_bytes -= std::min<uint64_t>(budget_bytes, c->file.size);   // the file itself goes to HBM first
+            budget_bytes = (uint64_t)((double)free_b * 0.7) + c->d_U.bytes() + c->d_lit.bytes() + c->d_ent.bytes() + c->d_counters.bytes() +
+                           c->d_desc.bytes() + c->d_rec_ref.bytes() + (c->preloaded ? 0 : c->d_comp.bytes());
         }
         const uint32_t n_ref = (uint32_t)c->hdr.refs.size();
         std::vector<sbx_batch> plan;
@@ -929,6 +1178,20 @@ int sbx_run_batch(sbx_ctx* c, uint32_t first_ref, uint32_t n_refs) {
             for (auto& g : c->regions)
                 if (g.ref_id >= first_ref && g.ref_id < first_ref + n_refs) sel.push_back(g);
         }
+        run_files(c, sel, true);
+    });
+}
+
+int sbx_run_interval(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        if (ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
+        if (!(beg < end)) throw Error(SBX_EINVAL, "empty interval");
+        std::vector<sbx_region> sel;
+        if (c->regions.empty()) sel.push_back({ref_id, beg, end});
+        else
+            for (auto& g : c->regions)
+                if (g.ref_id == ref_id && g.start < end && g.end > beg) sel.push_back({ref_id, std::max(g.start, beg), std::min(g.end, end)});
         run_files(c, sel, true);
     });
 }

@@ -1,26 +1,36 @@
 // index.hip -- K2 `record_index`: find every BAM record in the inflated stream and describe it.
 //
-// Replaces, for the whole file at once, the serial loop of BamReadRange.readNext
+// Replaces, for the whole work list at once, the serial loop of BamReadRange.readNext
 // (BioD/bio/std/hts/bam/readrange.d:118-173: read int32 block_size, slice block_size bytes),
 // the BamRead field accessors (read.d:907-1003), BamRead.basesCovered (read.d:255-262), the
 // -F filter objects (sambamba/utils/common/filtering.d:86-214), the RG -> sample lookup of
 // CustomBamRead (depth.d:240-250; read.d:1070-1087,1219-1230) and pileupColumns' zero-span
 // filter (pileup.d:510).
 //
-// The record chain is inherently serial (each block_size tells where the next record starts),
-// so it is cut at BGZF block granularity: one lane per BGZF block
-//   1. guesses the first record start inside its block with a structural plausibility test
-//      (ids/positions in range, lengths consistent with block_size, NUL-terminated name,
-//      two further records chain correctly and are coordinate-sorted),
-//   2. walks the chain to the end of its block -> (count, exit offset);
-// then `chain_check` tests exit[b-1] == entry[b] for every block in parallel; if any block is
-// inconsistent (rare: a decoy inside a record that looks like a record chain, or a block without any
-// record start), `chain_repair` follows the chain serially from the first such block, keeping the
-// pre-computed walk of every block whose guess turns out right.  By induction from the exactly
-// known offset of the first record, a consistent chain IS the true chain -- the guess only buys
-// parallelism, it can never change the result.  A scan of the counts gives every block its slot range in the
-// descriptor array and `describe` walks once more, now writing one 32-byte RecDesc per record
-// and the [lo,hi) record range of every position tile the record overlaps.
+// One launch, one 256-thread workgroup per BGZF block (`k_index_blocks`):
+//   1. the block's inflated bytes (+ 4 KiB of what follows) are copied into LDS with coalesced 16-byte
+//      loads -- the only time K2 touches the stream, every line exactly once;
+//   2. the record chain (each block_size tells where the next record starts) is serial, so it is cut
+//      twice: at BGZF block granularity across workgroups and at quarter-block granularity across the
+//      four waves of a workgroup.  A run of the work list starts at an exactly known record boundary
+//      (first record of the file / a BAI chunk start); everywhere else a wave GUESSES the first record
+//      start in its stretch with a structural plausibility test (ids / positions in range, lengths
+//      consistent with block_size, NUL-terminated name, two further records chain and are
+//      coordinate-sorted), 64 candidate offsets at a time, and walks the chain through LDS to the end of
+//      its stretch;
+//   3. the guesses are VERIFIED, never trusted: inside the block, quarter q must be entered exactly where
+//      quarter q-1 was left (otherwise one wave re-walks the whole block serially); across blocks the
+//      entry of block b must equal the exit of block b-1, which the workgroup reads while it looks back
+//      for its slot range (below).  By induction from the exactly known start of the run a consistent
+//      chain IS the true chain; an inconsistency is reported to the host, which repairs the chain
+//      serially (`k_chain_repair`, rare) and launches again with the entries given;
+//   4. the slot range of the block's records in the descriptor array is the exclusive prefix sum of the
+//      per-block record counts, obtained inside the same launch by decoupled look-back over a per-block
+//      status word (aggregate / inclusive prefix), blocks taking tickets in dispatch order;
+//   5. one lane per record decodes the fields out of LDS: fixed part, CIGAR span and shape, the -F
+//      program, RG -> sample, name hash; writes the 32-byte RecDesc and marks the [lo,hi) record range of
+//      every position tile the record overlaps (one atomic per tile change inside a wave).
+// Bound: HBM -- the inflated stream read once + 32 B per record written.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "regex_nfa.hpp"
@@ -31,7 +41,14 @@ namespace sbx {
 
 namespace {
 
-constexpr int kWalkThreads = 64;
+constexpr int kIdxThreads = 256;
+constexpr uint32_t kWinExtra = 4096;                       // bytes after the block that are visible in LDS
+constexpr uint32_t kWinBytes = 65536 + kWinExtra + 16;     // (+16: the window starts at a 16-byte boundary)
+constexpr uint32_t kQuarterRecs = 456;                     // records starting in 16 KiB: <= 16384 / 36 + 1
+constexpr uint32_t kRecSlots = 4 * kQuarterRecs;           // also enough for a whole block walked serially (65536 / 36 + 1)
+constexpr uint64_t kStateMask = (1ull << 62) - 1;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) {
     uint32_t v;
@@ -48,12 +65,25 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t* p) {
 constexpr uint32_t kCigarType = 0x3C1A7u;
 __device__ __forceinline__ uint32_t cig_type(uint32_t raw) { return (kCigarType >> ((raw & 15u) * 2u)) & 3u; }
 
-// Structural plausibility of a BAM record starting at offset o of the stream (fixed part only).
-__device__ bool plausible_record(const uint8_t* U, uint64_t total, uint64_t o, const RefTable& refs, uint64_t* next,
+// View of the stream around one BGZF block: offsets in [w0, w1) are served from the LDS copy, anything
+// else from global memory (records far longer than a block).  Pointers are generic (flat loads).
+struct Win {
+    const uint8_t* lds;     // lds[0] holds stream offset w0
+    const uint8_t* U;
+    uint64_t w0, w1;
+    __device__ __forceinline__ const uint8_t* ptr(uint64_t o, uint64_t n) const {
+        return (o >= w0 && o + n <= w1) ? lds + (o - w0) : U + o;
+    }
+};
+
+// Structural plausibility of a BAM record starting at offset o of the stream (fixed part only);
+// `limit` = end of the run: no record may extend beyond it.
+__device__ bool plausible_record(const Win& W, uint64_t limit, uint64_t o, const RefTable& refs, uint64_t* next,
                                  uint32_t* sort_key_ref, int32_t* sort_key_pos) {
-    if (o + 36 > total) return false;
-    const uint8_t* p = U + o;
+    if (o + 36 > limit) return false;
+    const uint8_t* p = W.ptr(o, 36 + 256 + 4);
     int64_t bs = (int32_t)ld32(p);
+    if (bs < 32 || bs > (int64_t)(1 << 29)) return false;
     int32_t ref = (int32_t)ld32(p + 4);
     if (ref < -1 || ref >= refs.n_ref) return false;
     int32_t pos = (int32_t)ld32(p + 8);
@@ -71,8 +101,8 @@ __device__ bool plausible_record(const uint8_t* U, uint64_t total, uint64_t o, c
     int32_t npos = (int32_t)ld32(p + 28);
     if (npos < -1) return false;
     int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 + (int64_t)l_seq;
-    if (bs < fixed || bs > (int64_t)(1 << 29)) return false;
-    if (o + 4 + (uint64_t)bs > total) return false;
+    if (bs < fixed) return false;
+    if (o + 4 + (uint64_t)bs > limit) return false;
     // read name: printable, NUL only at the end
     const uint8_t* name = p + 36;
     if (name[l_name - 1] != 0) return false;
@@ -87,88 +117,35 @@ __device__ bool plausible_record(const uint8_t* U, uint64_t total, uint64_t o, c
     return true;
 }
 
-// first record start in [from, limit) that passes the plausibility test 3 records deep
-__device__ uint64_t guess_entry(const uint8_t* U, uint64_t total, uint64_t from, uint64_t limit, const RefTable& refs) {
-    for (uint64_t o = from; o < limit; ++o) {
-        uint64_t n1, n2, n3;
-        uint32_t r1, r2, r3;
-        int32_t p1, p2, p3;
-        if (!plausible_record(U, total, o, refs, &n1, &r1, &p1)) continue;
-        if (n1 == total) return o;
-        if (!plausible_record(U, total, n1, refs, &n2, &r2, &p2)) continue;
-        if (r2 < r1 || (r2 == r1 && p2 < p1)) continue;     // coordinate order (unmapped = 0xFFFFFFFF last)
-        if (n2 == total) return o;
-        if (!plausible_record(U, total, n2, refs, &n3, &r3, &p3)) continue;
-        if (r3 < r2 || (r3 == r2 && p3 < p2)) continue;
-        return o;
-    }
-    return kOffUnknown;
+// is `o` the start of a chain of three plausible, coordinate-sorted records (or of the last records of the run)?
+__device__ bool plausible_chain(const Win& W, uint64_t limit, uint64_t o, const RefTable& refs) {
+    uint64_t n1, n2, n3;
+    uint32_t r1, r2, r3;
+    int32_t p1, p2, p3;
+    if (!plausible_record(W, limit, o, refs, &n1, &r1, &p1)) return false;
+    if (n1 == limit) return true;
+    if (!plausible_record(W, limit, n1, refs, &n2, &r2, &p2)) return false;
+    if (r2 < r1 || (r2 == r1 && p2 < p1)) return false;     // coordinate order (unmapped = 0xFFFFFFFF last)
+    if (n2 == limit) return true;
+    if (!plausible_record(W, limit, n2, refs, &n3, &r3, &p3)) return false;
+    if (r3 < r2 || (r3 == r2 && p3 < p2)) return false;
+    return true;
 }
 
-// walk the chain from `entry` until it leaves [.., block_end); returns exit offset or kOffInvalid
-// ck (optional): offsets of the block's records number 64, 128 and 192 -- `describe` starts a lane at each of them, so
-// that a block's ~230 records are described by four lanes with chains of 64 instead of one lane with a chain of 230
-__device__ uint64_t walk_block(const uint8_t* U, uint64_t total, uint64_t entry, uint64_t block_end, uint32_t* count,
-                               uint64_t* ck = nullptr) {
+// walk the chain from `entry` through global memory until it leaves [.., block_end); returns the exit offset or
+// kOffInvalid (repair path only)
+__device__ uint64_t walk_block(const uint8_t* U, uint64_t limit, uint64_t entry, uint64_t block_end, uint32_t* count) {
     uint64_t o = entry;
     uint32_t n = 0;
-    if (ck) { ck[0] = kOffInvalid; ck[1] = kOffInvalid; ck[2] = kOffInvalid; }
     while (o < block_end) {
-        if (ck && n && (n & 63u) == 0 && n <= 192u) ck[(n >> 6) - 1] = o;
-        if (o + 4 > total) { *count = n; return kOffInvalid; }
+        if (o + 36 > limit) { *count = n; return kOffInvalid; }
         int64_t bs = (int32_t)ld32(U + o);
-        if (bs < 32 || o + 4 + (uint64_t)bs > total) { *count = n; return kOffInvalid; }
+        if (bs < 32 || o + 4 + (uint64_t)bs > limit) { *count = n; return kOffInvalid; }
         ++n;
         o += 4 + (uint64_t)bs;
     }
     *count = n;
     return o;
-}
-
-__global__ __launch_bounds__(kWalkThreads) void k_block_walk(const uint8_t* __restrict__ U, uint64_t total,
-                                                              const uint64_t* __restrict__ out_off,
-                                                              const uint32_t* __restrict__ isize, uint32_t n_blocks,
-                                                              uint64_t first_record_off, RefTable refs,
-                                                              uint64_t* __restrict__ entry, uint64_t* __restrict__ exit_,
-                                                              uint32_t* __restrict__ count, uint64_t* __restrict__ ckpt) {
-    uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
-    if (b >= n_blocks) return;
-    uint64_t beg = out_off[b], end = beg + isize[b];
-    if (end > total) end = total;     // the sub-stream of a -L run stops at a record boundary inside its last block
-    uint64_t e;
-    if (end <= first_record_off) {
-        // block lies entirely inside the BAM header: the chain enters the next block at first_record_off
-        entry[b] = first_record_off;
-        exit_[b] = first_record_off;
-        count[b] = 0;
-        ckpt[3 * (size_t)b] = kOffInvalid; ckpt[3 * (size_t)b + 1] = kOffInvalid; ckpt[3 * (size_t)b + 2] = kOffInvalid;
-        return;
-    }
-    if (beg <= first_record_off) e = first_record_off;       // exactly known
-    else e = guess_entry(U, total, beg, end, refs);
-    uint32_t n = 0;
-    uint64_t x = kOffUnknown;
-    if (e != kOffUnknown) x = walk_block(U, total, e, end, &n, ckpt + 3 * (size_t)b);
-    else { ckpt[3 * (size_t)b] = kOffInvalid; ckpt[3 * (size_t)b + 1] = kOffInvalid; ckpt[3 * (size_t)b + 2] = kOffInvalid; }
-    entry[b] = e;
-    exit_[b] = x;
-    count[b] = n;
-}
-
-// Parallel check of the guessed chain: entry[b] must equal exit[b-1] (exit of a block that contains
-// no record start is its entry, see walk_block).  The lowest inconsistent block goes to *first_bad.
-__global__ __launch_bounds__(kWalkThreads) void k_chain_check(const uint64_t* __restrict__ out_off,
-                                                               const uint32_t* __restrict__ isize, uint32_t n_blocks,
-                                                               uint64_t first_record_off, const uint64_t* __restrict__ entry,
-                                                               const uint64_t* __restrict__ exit_, uint32_t* first_bad) {
-    uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
-    if (b >= n_blocks) return;
-    uint64_t end = out_off[b] + isize[b];
-    if (end <= first_record_off) return;             // header-only block: exact by construction
-    uint64_t want = (b == 0) ? first_record_off : exit_[b - 1];
-    bool ok = want != kOffUnknown && want != kOffInvalid && entry[b] == want && exit_[b] != kOffUnknown && exit_[b] != kOffInvalid &&
-              exit_[b] >= entry[b];
-    if (!ok) atomicMin(first_bad, b);
 }
 
 // wave-uniform copy of lane i's 64-bit value (readlane works on 32-bit ints: cast each half to
@@ -180,45 +157,52 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t i) {
 }
 
 // Serial repair from the first inconsistent block on (one wavefront; rare).  Everything before
-// `from` is consistent with the exactly known first record offset, hence true; from there the chain
-// is followed block by block: a block whose guessed entry equals the running offset keeps its
-// pre-computed walk (O(1)), any other block is re-walked from the true entry.
-__global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__ U, uint64_t total,
-                                                      const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize,
-                                                      uint32_t n_blocks, uint64_t first_record_off, uint32_t from,
-                                                      uint32_t stop_at_trusted, uint64_t* entry, uint64_t* exit_, uint32_t* count,
-                                                      uint64_t* ckpt, uint32_t* n_rewalked) {
+// `from` is consistent with the exactly known start of its run, hence true; from there the chain
+// is followed block by block: a block whose recorded entry equals the running offset keeps its
+// recorded walk (O(1)), any other block is re-walked from the true entry.  Every run starts over at
+// its known first record.
+__global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__ U, const uint64_t* __restrict__ out_off,
+                                                      const uint32_t* __restrict__ isize, const uint32_t* __restrict__ run_of,
+                                                      const ChainRun* __restrict__ runs, uint32_t n_blocks, uint32_t from,
+                                                      uint64_t* entry, uint64_t* exit_, uint32_t* count, uint32_t* n_rewalked) {
     const uint32_t lane = threadIdx.x;
-    uint64_t cur = (from == 0) ? first_record_off : exit_[from - 1];
+    uint64_t cur = kOffInvalid;
+    {
+        const ChainRun r0 = runs[run_of[from]];
+        cur = (from == r0.blk_first) ? r0.u_beg : exit_[from - 1];
+    }
     uint32_t rewalked = 0;
-    bool done = false;
-    for (uint32_t b0 = from; b0 < n_blocks && !done; b0 += 64) {
+    for (uint32_t b0 = from; b0 < n_blocks; b0 += 64) {
         const uint32_t b = b0 + lane;
-        uint64_t e = kOffUnknown, x = kOffUnknown, end = 0;
-        uint32_t n = 0;
-        if (b < n_blocks) { e = entry[b]; x = exit_[b]; n = count[b]; end = out_off[b] + isize[b]; if (end > total) end = total; }
+        uint64_t e = kOffUnknown, x = kOffUnknown, end = 0, rbeg = 0, rend = 0;
+        uint32_t n = 0, first = 0;
+        if (b < n_blocks) {
+            e = entry[b]; x = exit_[b]; n = count[b];
+            const ChainRun r = runs[run_of[b]];
+            end = out_off[b] + isize[b];
+            if (end > r.u_end) end = r.u_end;
+            rbeg = r.u_beg; rend = r.u_end;
+            first = r.blk_first == b ? 1u : 0u;
+        }
         const uint32_t lim = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
         bool dirty = false;
         for (uint32_t i = 0; i < lim; ++i) {
-            const uint64_t e_i = bcast64(e, i), x_i = bcast64(x, i), end_i = bcast64(end, i);
+            const uint64_t e_i = bcast64(e, i), x_i = bcast64(x, i), end_i = bcast64(end, i), rend_i = bcast64(rend, i);
+            if (__builtin_amdgcn_readlane((int)first, i)) cur = bcast64(rbeg, i);
             uint64_t ne, nx;
             uint32_t nn;
-            if (cur == kOffInvalid) { ne = kOffInvalid; nx = kOffInvalid; nn = 0; }
-            else if (end_i <= first_record_off) { ne = e_i; nx = x_i; nn = 0; }   // header-only block
-            else if (e_i == cur && x_i != kOffUnknown) {
-                // guess confirmed: everything from here to the next inconsistent block is already right
-                if (stop_at_trusted && rewalked) { done = true; break; }
-                ne = e_i; nx = x_i; nn = (uint32_t)__builtin_amdgcn_readlane((int)n, i);
-            }
-            else {
+            if (cur == kOffInvalid || cur == kOffUnknown) { ne = kOffInvalid; nx = kOffInvalid; nn = 0; }
+            else if (e_i == cur && x_i != kOffUnknown && x_i != kOffInvalid) {
+                ne = e_i; nx = x_i; nn = (uint32_t)__builtin_amdgcn_readlane((int)n, i);     // recorded walk confirmed
+            } else {
                 uint32_t c = 0;
-                nx = walk_block(U, total, cur, end_i, &c, ckpt + 3 * (size_t)(b0 + i));     // wave-uniform re-walk (every lane writes the same checkpoints)
+                nx = walk_block(U, rend_i, cur, end_i, &c);     // wave-uniform re-walk
                 ne = cur;
                 nn = c;
                 ++rewalked;
             }
             if (lane == i && (ne != e || nx != x || nn != n)) { e = ne; x = nx; n = nn; dirty = true; }
-            if (!(end_i <= first_record_off)) cur = nx;
+            cur = nx;
         }
         if (dirty && b < n_blocks) { entry[b] = e; exit_[b] = x; count[b] = n; }
     }
@@ -252,7 +236,7 @@ __global__ __launch_bounds__(kScanThreads) void k_count_scan(const uint32_t* __r
     if (t == kScanThreads - 1) base[n] = part[kScanThreads - 1];
 }
 
-// ---- describe ---------------------------------------------------------------------------------
+// ---- aux fields, the -F program, RG lookup -------------------------------------------------------
 // first aux field with the given key (BamRead.opIndex, read.d:1070-1087; skipValue read.d:1219-1230):
 // returns its type character and value pointer, 0 when absent or when the tag area is malformed before it
 __device__ uint32_t find_tag(const uint8_t* t, const uint8_t* e, uint32_t key, const uint8_t** val) {
@@ -518,163 +502,344 @@ __device__ uint32_t lookup_sample(const uint8_t* t, const uint8_t* e, const RgTa
     return 0;
 }
 
-__global__ __launch_bounds__(kWalkThreads) void k_describe(const uint8_t* __restrict__ U, uint64_t total,
-                                                            const uint64_t* __restrict__ out_off,
-                                                            const uint32_t* __restrict__ isize, uint32_t n_blocks,
-                                                            const uint64_t* __restrict__ entry,
-                                                            const uint64_t* __restrict__ ckpt,
-                                                            const uint64_t* __restrict__ base, RefTable refs,
-                                                            const DeviceFilter* __restrict__ filt, RgTable rg,
-                                                            uint32_t tile_pos, RecDesc* __restrict__ desc,
-                                                            int32_t* __restrict__ rec_ref, uint64_t* __restrict__ name_hash,
-                                                            uint32_t* tile_lo, uint32_t* tile_hi, IndexStats* stats) {
-    // four lanes per BGZF block: lane `seg` describes records 64*seg .. 64*seg+63 of the block (the last one: the rest),
-    // starting at the checkpoint the walk left for it
-    const uint32_t gl = blockIdx.x * kWalkThreads + threadIdx.x;
-    const uint32_t b = gl >> 2, seg = gl & 3u;
-    if (b >= n_blocks) return;
-    uint64_t end = out_off[b] + isize[b];
-    if (end > total) end = total;
-    uint64_t o = seg == 0 ? entry[b] : ckpt[3 * (size_t)b + seg - 1];
-    uint64_t idx = base[b] + 64u * seg;
-    uint32_t left = seg < 3 ? 64u : 0xFFFFFFFFu;
-    unsigned long long n_rec = 0, n_adm = 0, n_bad = 0, n_urg = 0;
-    // tile-range bookkeeping aggregated per lane: flush on tile change
-    uint32_t cur_t0 = 0xFFFFFFFFu, cur_t1 = 0, cur_lo = 0, cur_hi = 0;
-    auto flush = [&]() {
-        if (cur_t0 == 0xFFFFFFFFu) return;
-        for (uint32_t t = cur_t0; t <= cur_t1; ++t) {
-            atomicMin(&tile_lo[t], cur_lo);
-            atomicMax(&tile_hi[t], cur_hi);
+
+// ---- one record ---------------------------------------------------------------------------------
+struct Described {
+    RecDesc d;
+    int32_t ref;
+    uint64_t hash;
+    uint32_t t0, t1;        // first / last position tile the alignment touches (admitted records only)
+    bool admit, bad, urg;
+};
+
+// p: the record's block_size field (LDS copy, or global memory for a record that does not fit the window)
+__device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexArgs& a) {
+    Described R;
+    const int64_t bs = (int32_t)ld32(p);
+    const uint8_t* r = p + 4;
+    const int32_t ref = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+    const uint32_t bmn = ld32(r + 8), fnc = ld32(r + 12);
+    const uint32_t l_name = bmn & 0xFF, mapq = (bmn >> 8) & 0xFF;
+    const uint32_t n_cigar = fnc & 0xFFFF, flag = fnc >> 16;
+    const int32_t l_seq = (int32_t)ld32(r + 16);
+    RecDesc& d = R.d;
+    d.rec_off = o;
+    d.pos = pos;
+    d.end = pos;
+    d.l_seq = (uint32_t)l_seq;
+    d.n_cigar = (uint16_t)n_cigar;
+    d.l_name = (uint8_t)l_name;
+    d.mapq = (uint8_t)mapq;
+    d.flag = (uint16_t)flag;
+    d.sample = 0;
+    d.q_start = 0;
+    d.kind = 0;
+    d.pad = 0;
+    R.ref = ref;
+    R.hash = 0;
+    R.t0 = R.t1 = 0;
+    R.urg = false;
+    const int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
+    const bool sane = l_seq >= 0 && bs >= fixed && ref >= -1 && ref < a.refs.n_ref;
+    R.bad = !sane;
+    bool admit = sane && !(flag & 0x4) && ref >= 0;                       // read.d:256, unmapped reads cover nothing
+    if (admit) admit = eval_filter(a.filt, r, ref, pos, bmn, fnc, l_seq, r + fixed, r + bs);      // filtering.d:36-38
+    if (admit) {
+        // basesCovered + shape of the CIGAR
+        const uint8_t* cg = r + 32 + l_name;
+        int64_t span = 0;
+        uint32_t q_lead = 0;         // query bases before the first reference-consuming op
+        uint32_t runs = 0;           // number of maximal runs of M/=/X
+        bool in_run = false, other_ref = false, seen_ref = false, zero_ref = false;
+        for (uint32_t i = 0; i < n_cigar; ++i) {
+            const uint32_t op = ld32(cg + 4 * i);
+            const uint32_t ty = cig_type(op), len = op >> 4;
+            // a zero-length reference-consuming op still occupies one pileup column in the reference
+            // (PileupRead.incrementPosition tests offset >= length only after stepping, pileup.d:195-205):
+            // such reads take the general path, which emulates it
+            if (len == 0 && (ty & 2)) zero_ref = true;
+            if (ty == 3) {
+                if (!in_run) { ++runs; in_run = true; }
+                span += len;
+                seen_ref = true;
+            } else {
+                if (ty & 2) { other_ref = true; span += len; seen_ref = true; in_run = false; }
+                else if (ty & 1) {
+                    if (!seen_ref) q_lead += len;
+                    else in_run = false;       // I or trailing S: ends the run (a trailing clip is harmless for the fast path)
+                }
+                // H / P (ty == 0) neither end a run nor consume anything
+            }
         }
-        cur_t0 = 0xFFFFFFFFu;
-    };
-    // The walk is a pointer chase (the next record's offset is in this record's first word), so the
-    // next record's fixed fields are requested as soon as that word is known and travel while this
-    // record's CIGAR / tags are being read: one memory round trip per record instead of two or three.
-    struct Fixed { uint32_t w[6]; };     // block_size, refID, pos, bin_mq_nl, flag_nc, l_seq
-    auto load_fixed = [&](uint64_t at) {
-        Fixed f;
+        if (span <= 0 || span > 0x7FFFFFFF - (int64_t)pos) admit = false;   // pileup.d:510
+        else {
+            d.end = pos + (int32_t)span;
+            if (runs == 1 && !other_ref && !zero_ref && q_lead <= 0xFFFF) { d.kind = 1; d.q_start = (uint16_t)q_lead; }
+            else d.kind = 2;
+        }
+    }
+    if (admit && a.refs.sel) {
+        // the read must overlap one of the requested regions: pos < region.end && pos + span > region.start
+        uint32_t lo = a.refs.sel_first[ref], hi = a.refs.sel_first[ref + 1];
+        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((int64_t)a.refs.sel[m].end > (int64_t)pos) hi = m; else lo = m + 1; }
+        if (lo >= a.refs.sel_first[ref + 1] || (int64_t)a.refs.sel[lo].start >= (int64_t)d.end) { admit = false; d.kind = 0; d.end = d.pos; }
+    }
+    // RG -> sample.  The reference builds a CustomBamRead -- and throws on a read group that is not in the header -- for
+    // every read it iterates over, filtered or not (depth.d:240-250,1211-1214); with -L those are the reads the index
+    // fetch returns, which the admitted ones stand for here.
+    if (a.rg.lookup && sane && (admit || !a.refs.sel)) {
+        const uint32_t s = lookup_sample(r + fixed, r + bs, a.rg);
+        if (s == 0xFFFFu) R.urg = true;
+        else d.sample = (uint16_t)s;
+    }
+    if (admit) {
+        const uint32_t tb = a.refs.tile_base[ref];
+        uint32_t t0 = tb + (uint32_t)pos / a.tile_pos;
+        uint32_t t1 = tb + (uint32_t)(d.end - 1) / a.tile_pos;
+        const uint32_t last_tile = a.refs.tile_base[ref + 1] - 1;      // clip alignments hanging over the contig end
+        if (t1 > last_tile) t1 = last_tile;
+        if (t0 > last_tile) { admit = false; d.kind = 0; d.end = d.pos; R.bad = true; }      // starts beyond the contig's spare tile
+        R.t0 = t0; R.t1 = t1;
+    }
+    if (a.name_hash) {   // FNV-1a over the read name without its NUL (CustomBamRead, depth.d:252-258)
+        uint64_t h = 14695981039346656037ULL;
+        const uint8_t* nm = r + 32;
+        for (uint32_t k = 0; k + 1 < l_name; ++k) { h ^= nm[k]; h *= 1099511628211ULL; }
+        R.hash = h;
+    }
+    R.admit = admit;
+    return R;
+}
+
+// ---- decoupled look-back ------------------------------------------------------------------------
+// state[b] = flag << 62 | value: flag 0 nothing yet, 1 value = records of block b, 2 value = records of blocks 0..b.
+__device__ __forceinline__ uint64_t ld_state(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) f.w[k] = ld32(U + at + 4 * k);
-        return f;
+    for (int d = 32; d >= 1; d >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, d, 64);
+    return v;
+}
+// records in blocks 0 .. b-1 (one wave; predecessors hold lower tickets, so they are running or done)
+__device__ uint64_t look_back(const uint64_t* state, uint32_t b, uint32_t lane) {
+    uint64_t excl = 0;
+    for (int64_t idx = (int64_t)b - 1; idx >= 0; idx -= 64) {
+        const int64_t j = idx - (int64_t)lane;
+        uint64_t v;
+        do { v = j >= 0 ? ld_state(state + j) : (2ull << 62); } while (__any((v >> 62) == 0));
+        const uint64_t m2 = __ballot((v >> 62) == 2);
+        const uint32_t stop = m2 ? (uint32_t)__builtin_ctzll(m2) : 64u;
+        excl += wave_sum64(lane <= stop ? (v & kStateMask) : 0ull);
+        if (m2) break;
+    }
+    return excl;
+}
+
+struct IdxShared {
+    uint64_t g[4], x[4];
+    uint32_t n[4];
+    uint64_t base;
+    uint32_t b, n_adm, n_bad, n_urg;
+};
+
+__global__ __launch_bounds__(kIdxThreads) void k_index_blocks(IndexArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* win = smem;
+    uint16_t* rec = (uint16_t*)(smem + kWinBytes);
+    IdxShared* sh = (IdxShared*)(smem + kWinBytes + 2 * kRecSlots);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) {
+        sh->b = atomicAdd(a.ticket, 1u);
+        sh->n_adm = sh->n_bad = sh->n_urg = 0;
+    }
+    __syncthreads();
+    const uint32_t b = sh->b;
+    const uint64_t beg = a.out_off[b], blk_end = beg + a.isize[b];
+    const ChainRun run = a.runs[a.run_of[b]];
+    const uint64_t lo = beg > run.u_beg ? beg : run.u_beg, hi0 = blk_end < run.u_end ? blk_end : run.u_end;
+    const uint64_t hi = hi0 > lo ? hi0 : lo;
+    const bool first_of_run = b == run.blk_first, last_of_run = b == run.blk_last;
+    // ---- 1. the block (and 4 KiB of what follows) into LDS ------------------------------------------
+    Win W;
+    W.lds = win;
+    W.U = a.U;
+    W.w0 = beg & ~15ull;
+    W.w1 = W.w0 + kWinBytes < a.u_alloc ? W.w0 + kWinBytes : a.u_alloc;      // (u_alloc: multiple of 16, >= stream end + 16)
+    {
+        const uint32_t nbytes = (uint32_t)(W.w1 - W.w0);
+        const uint8_t* src = a.U + W.w0;
+        for (uint32_t off = tid * 16u; off < nbytes; off += kIdxThreads * 16u)
+            *(u32x4*)(win + off) = *(const u32x4*)(src + off);
+    }
+    __syncthreads();
+    // ---- 2. entries of the four quarters and their walks ------------------------------------------------
+    const bool given = a.entry_in != nullptr;
+    uint64_t E = first_of_run ? run.u_beg : given ? a.entry_in[b] : kOffUnknown;
+    const bool known = first_of_run || given;
+    const uint64_t qlen = (hi - lo + 3) / 4;
+    const uint64_t s_q = lo + wv * qlen < hi ? lo + wv * qlen : hi, e_q = s_q + qlen < hi ? s_q + qlen : hi;
+    {
+        uint64_t g = kOffUnknown;
+        if (wv == 0 && known) g = E;
+        else {
+            for (uint64_t o0 = s_q; o0 < e_q && g == kOffUnknown; o0 += 64) {
+                const uint64_t o = o0 + lane;
+                const bool ok = o < e_q && plausible_chain(W, run.u_end, o, a.refs);
+                const uint64_t m = __ballot(ok);
+                if (m) g = o0 + (uint64_t)__builtin_ctzll(m);
+            }
+        }
+        // walk (wave-uniform): records starting in [g, e_q)
+        uint32_t n = 0;
+        uint64_t x = g;
+        if (g != kOffUnknown && g != kOffInvalid && g >= s_q && g < e_q) {
+            uint64_t o = g;
+            bool okc = true;
+            while (o < e_q) {
+                if (o + 36 > run.u_end) { okc = false; break; }
+                const int64_t bs = (int32_t)ld32(win + (o - W.w0));
+                if (bs < 32 || o + 4 + (uint64_t)bs > run.u_end) { okc = false; break; }
+                if (lane == 0) rec[wv * kQuarterRecs + n] = (uint16_t)(o - beg);
+                ++n;
+                o += 4 + (uint64_t)bs;
+            }
+            x = okc ? o : kOffInvalid;
+        }
+        if (lane == 0) { sh->g[wv] = g; sh->x[wv] = x; sh->n[wv] = n; }
+    }
+    __syncthreads();
+    // ---- 3. stitch the quarters (every thread, same result) ------------------------------------------------
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    uint64_t X = kOffUnknown;
+    bool serial = false;
+    {
+        if (!known) {
+#pragma unroll
+            for (int q = 3; q >= 0; --q) if (sh->g[q] != kOffUnknown) E = sh->g[q];
+        }
+        uint64_t cur = E;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t sq = lo + q * qlen < hi ? lo + q * qlen : hi, eq = sq + qlen < hi ? sq + qlen : hi;
+            if (serial || cur == kOffUnknown || cur == kOffInvalid) continue;
+            if (cur >= eq) continue;                       // no record starts in this quarter
+            if (sh->g[q] != cur) { serial = true; continue; }
+            cnt[q] = sh->n[q];
+            cur = sh->x[q];
+        }
+        X = cur;
+    }
+    if (serial) {
+        // a quarter was not entered where its wave had guessed (a decoy, or a record longer than a quarter):
+        // one wave walks the whole block from its entry
+        __syncthreads();
+        if (wv == 0) {
+            uint32_t n = 0;
+            uint64_t o = E;
+            bool okc = true;
+            while (o < hi) {
+                if (o + 36 > run.u_end) { okc = false; break; }
+                const int64_t bs = (int32_t)ld32(win + (o - W.w0));
+                if (bs < 32 || o + 4 + (uint64_t)bs > run.u_end) { okc = false; break; }
+                if (lane == 0 && n < kRecSlots) rec[n] = (uint16_t)(o - beg);
+                ++n;
+                o += 4 + (uint64_t)bs;
+            }
+            if (lane == 0) { sh->n[0] = n; sh->x[0] = okc ? o : kOffInvalid; }
+        }
+        __syncthreads();
+        cnt[0] = sh->n[0]; cnt[1] = cnt[2] = cnt[3] = 0;
+        X = sh->x[0];
+    }
+    const uint32_t count = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const bool bad_block = E == kOffUnknown || E == kOffInvalid || X == kOffUnknown || X == kOffInvalid || X < E ||
+                           (last_of_run && X != run.u_end);
+    // ---- 4. publish, describe the first 256 records while the predecessors publish, look back --------------
+    if (tid == 0) {
+        a.entry[b] = E;
+        a.count[b] = count;
+        __hip_atomic_store(a.exit_ + b, X, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.state + b, ((b == 0 ? 2ull : 1ull) << 62) | (uint64_t)count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (bad_block) atomicMin(a.flags + 0, b);
+        if (a.inflate_status[b] != 0) atomicMin(a.flags + 1, b);
+    }
+    auto rec_at = [&](uint32_t i) -> uint64_t {          // stream offset of the block's record number i
+        uint32_t q = 0, j = i;
+        if (!serial) {
+            if (j >= cnt[0]) { j -= cnt[0]; q = 1; if (j >= cnt[1]) { j -= cnt[1]; q = 2; if (j >= cnt[2]) { j -= cnt[2]; q = 3; } } }
+        }
+        return beg + rec[serial ? i : q * kQuarterRecs + j];
     };
-    bool have = o < end && o != kOffUnknown && o != kOffInvalid;
-    Fixed fx = {{0, 0, 0, 0, 0, 0}};
-    if (have) fx = load_fixed(o);
-    while (have) {
-        const uint8_t* p = U + o;
-        int64_t bs = (int32_t)fx.w[0];
-        const uint8_t* r = p + 4;
-        int32_t ref = (int32_t)fx.w[1], pos = (int32_t)fx.w[2];
-        uint32_t bmn = fx.w[3], fnc = fx.w[4];
-        uint32_t l_name = bmn & 0xFF, mapq = (bmn >> 8) & 0xFF;
-        uint32_t n_cigar = fnc & 0xFFFF, flag = fnc >> 16;
-        int32_t l_seq = (int32_t)fx.w[5];
-        const uint64_t o_next = o + 4 + (uint64_t)bs;
-        --left;
-        const bool have_next = bs >= 32 && o_next < end && left != 0;
-        Fixed fn = {{0, 0, 0, 0, 0, 0}};
-        if (have_next) fn = load_fixed(o_next);
-        RecDesc d;
-        d.rec_off = o;
-        d.pos = pos;
-        d.end = pos;
-        d.l_seq = (uint32_t)l_seq;
-        d.n_cigar = (uint16_t)n_cigar;
-        d.l_name = (uint8_t)l_name;
-        d.mapq = (uint8_t)mapq;
-        d.flag = (uint16_t)flag;
-        d.sample = 0;
-        d.q_start = 0;
-        d.kind = 0;
-        d.pad = 0;
-        ++n_rec;
-        int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
-        bool sane = l_seq >= 0 && bs >= fixed && ref >= -1 && ref < refs.n_ref;
-        if (!sane) ++n_bad;
-        bool admit = sane && !(flag & 0x4) && ref >= 0;                       // read.d:256, unmapped reads cover nothing
-        if (admit) admit = eval_filter(filt, r, ref, pos, bmn, fnc, l_seq, r + fixed, r + bs);                              // filtering.d:36-38
-        if (admit) {
-            // basesCovered + shape of the CIGAR
-            const uint8_t* cg = r + 32 + l_name;
-            int64_t span = 0;
-            uint32_t q_lead = 0;         // query bases before the first reference-consuming op
-            uint32_t runs = 0;           // number of maximal runs of M/=/X
-            bool in_run = false, other_ref = false, q_inside = false, seen_ref = false, zero_ref = false;
-            for (uint32_t i = 0; i < n_cigar; ++i) {
-                uint32_t op = ld32(cg + 4 * i);
-                uint32_t ty = cig_type(op), len = op >> 4;
-                // a zero-length reference-consuming op still occupies one pileup column in the reference
-                // (PileupRead.incrementPosition tests offset >= length only after stepping, pileup.d:195-205):
-                // such reads take the general path, which emulates it
-                if (len == 0 && (ty & 2)) zero_ref = true;
-                if (ty == 3) {
-                    if (!in_run) { ++runs; in_run = true; }
-                    span += len;
-                    seen_ref = true;
-                } else {
-                    if (ty & 2) { other_ref = true; span += len; seen_ref = true; in_run = false; }
-                    else if (ty & 1) {
-                        if (!seen_ref) q_lead += len;
-                        else { in_run = false; q_inside = true; }   // I or trailing S: ends the run
-                    }
-                    // H / P (ty == 0) neither end a run nor consume anything
+    auto describe_at = [&](uint32_t i) -> Described {
+        const uint64_t o = rec_at(i);
+        const uint8_t* p = win + (o - W.w0);                 // the fixed part always lies inside the window
+        const int64_t bs = (int32_t)ld32(p);
+        if (o + 4 + (uint64_t)bs > W.w1) p = a.U + o;        // the whole record must be addressable through one pointer
+        return describe_record(p, o, a);
+    };
+    Described R;
+    R.admit = false;
+    if (tid < count) R = describe_at(tid);
+    if (wv == 0) {
+        uint64_t base = 0;
+        if (b != 0) {
+            base = look_back(a.state, b, lane);
+            if (lane == 0) {
+                __hip_atomic_store(a.state + b, (2ull << 62) | (base + count), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (!first_of_run) {
+                    // the predecessor's exit was stored before its status word (release / acquire)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const uint64_t px = __hip_atomic_load(a.exit_ + (b - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (px != E) atomicMin(a.flags + 0, b);
                 }
             }
-            // q_inside is also set by a trailing soft clip, which is harmless for the fast path
-            // as long as there is exactly one run and no D/N: positions map 1:1 onto the query.
-            (void)q_inside;
-            if (span <= 0 || span > 0x7FFFFFFF - (int64_t)pos) admit = false;   // pileup.d:510
-            else {
-                d.end = pos + (int32_t)span;
-                if (runs == 1 && !other_ref && !zero_ref && q_lead <= 0xFFFF) { d.kind = 1; d.q_start = (uint16_t)q_lead; }
-                else d.kind = 2;
-            }
         }
-        if (admit && refs.sel) {
-            // the read must overlap one of the requested regions: pos < region.end && pos + span > region.start
-            uint32_t lo = refs.sel_first[ref], hi = refs.sel_first[ref + 1];
-            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((int64_t)refs.sel[m].end > (int64_t)pos) hi = m; else lo = m + 1; }
-            if (lo >= refs.sel_first[ref + 1] || (int64_t)refs.sel[lo].start >= (int64_t)d.end) { admit = false; d.kind = 0; d.end = d.pos; }
-        }
-        if (admit && rg.lookup) {
-            const uint8_t* tags = r + fixed;
-            uint32_t s = lookup_sample(tags, r + bs, rg);
-            if (s == 0xFFFFu) { ++n_urg; s = 0; }
-            d.sample = (uint16_t)s;
-        }
-        if (admit) {
-            ++n_adm;
-            uint32_t t0 = refs.tile_base[ref] + (uint32_t)pos / tile_pos;
-            uint32_t t1 = refs.tile_base[ref] + (uint32_t)(d.end - 1) / tile_pos;
-            uint32_t last_tile = refs.tile_base[ref + 1] - 1;      // clip alignments hanging over the contig end
-            if (t1 > last_tile) t1 = last_tile;
-            if (t0 > last_tile) { admit = false; d.kind = 0; d.end = d.pos; --n_adm; ++n_bad; }
-            else if (t0 == cur_t0 && t1 == cur_t1) { cur_hi = (uint32_t)idx + 1; }
-            else {
-                flush();
-                cur_t0 = t0; cur_t1 = t1; cur_lo = (uint32_t)idx; cur_hi = (uint32_t)idx + 1;
-            }
-        }
-        desc[idx] = d;
-        rec_ref[idx] = ref;
-        if (name_hash) {   // FNV-1a over the read name without its NUL (CustomBamRead, depth.d:252-258)
-            uint64_t h = 14695981039346656037ULL;
-            const uint8_t* nm = r + 32;
-            for (uint32_t k = 0; k + 1 < l_name; ++k) { h ^= nm[k]; h *= 1099511628211ULL; }
-            name_hash[idx] = h;
-        }
-        ++idx;
-        o = o_next;
-        fx = fn;
-        have = have_next;
+        if (lane == 0) sh->base = base;
     }
-    flush();
-    if (n_rec) atomicAdd(&stats->n_records, n_rec);
-    if (n_adm) atomicAdd(&stats->n_admitted, n_adm);
-    if (n_bad) atomicAdd(&stats->n_bad, n_bad);
-    if (n_urg) atomicAdd(&stats->n_unknown_rg, n_urg);
+    __syncthreads();
+    const uint64_t base = sh->base;
+    if (base + count > a.desc_cap) {                   // descriptor array too small: the host enlarges it and launches again
+        if (tid == 0) atomicOr(a.flags + 2, 1u);
+        return;
+    }
+    // ---- 5. write descriptors, mark tile ranges -------------------------------------------------------------
+    uint32_t n_adm = 0, n_bad = 0, n_urg = 0;
+    for (uint32_t i0 = 0; i0 < count; i0 += kIdxThreads) {
+        const uint32_t i = i0 + tid;
+        if (i0 != 0) { R.admit = false; if (i < count) R = describe_at(i); }
+        const bool live = i < count;
+        const uint64_t idx = base + i;
+        if (live) {
+            a.desc[idx] = R.d;
+            a.rec_ref[idx] = R.ref;
+            if (a.name_hash) a.name_hash[idx] = R.hash;
+            n_adm += R.admit ? 1u : 0u;
+            n_bad += R.bad ? 1u : 0u;
+            n_urg += R.urg ? 1u : 0u;
+        }
+        // records of a wave have consecutive indices, so the lowest index of a tile is held by the first lane of a run
+        // of equal tiles and the highest by the last one
+        const bool adm = live && R.admit;
+        const uint32_t t0 = adm ? R.t0 : 0xFFFFFFFFu;
+        const uint32_t t0_prev = __shfl_up(t0, 1, 64), t0_next = __shfl_down(t0, 1, 64);
+        if (adm) {
+            if (lane == 0 || t0_prev != t0) atomicMin(&a.tile_lo[t0], (uint32_t)idx);
+            if (lane == 63 || t0_next != t0) atomicMax(&a.tile_hi[t0], (uint32_t)idx + 1);
+            for (uint32_t t = R.t0 + 1; t <= R.t1; ++t) {
+                atomicMin(&a.tile_lo[t], (uint32_t)idx);
+                atomicMax(&a.tile_hi[t], (uint32_t)idx + 1);
+            }
+        }
+    }
+    if (n_adm) atomicAdd(&sh->n_adm, n_adm);
+    if (n_bad) atomicAdd(&sh->n_bad, n_bad);
+    if (n_urg) atomicAdd(&sh->n_urg, n_urg);
+    __syncthreads();
+    if (tid == 0) {
+        if (count) atomicAdd(&a.stats->n_records, (unsigned long long)count);
+        if (sh->n_adm) atomicAdd(&a.stats->n_admitted, (unsigned long long)sh->n_adm);
+        if (sh->n_bad) atomicAdd(&a.stats->n_bad, (unsigned long long)sh->n_bad);
+        if (sh->n_urg) atomicAdd(&a.stats->n_unknown_rg, (unsigned long long)sh->n_urg);
+    }
 }
 
 // ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
@@ -714,6 +879,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* _
     if (t == 0) *n_active = run;
 }
 
+
 }  // namespace
 
 namespace {
@@ -732,30 +898,25 @@ void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream
     SBX_HIP(hipGetLastError());
 }
 
-void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                       uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry, uint64_t* d_exit,
-                       uint32_t* d_count, uint64_t* d_ckpt, hipStream_t stream) {
-    if (!n_blocks) return;
-    dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
-    hipLaunchKernelGGL(k_block_walk, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, first_record_off,
-                       refs, d_entry, d_exit, d_count, d_ckpt);
+size_t index_lds_bytes() { return (size_t)kWinBytes + 2 * kRecSlots + sizeof(IdxShared); }
+
+void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
+    if (!a.n_blocks) return;
+    const size_t lds = index_lds_bytes();
+    static bool attr_set = false;
+    if (!attr_set) {
+        SBX_HIP(hipFuncSetAttribute((const void*)k_index_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_index_blocks, dim3(a.n_blocks), dim3(kIdxThreads), lds, stream, a);
     SBX_HIP(hipGetLastError());
 }
 
-void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint32_t n_blocks, uint64_t first_record_off,
-                        const uint64_t* d_entry, const uint64_t* d_exit, uint32_t* d_first_bad, hipStream_t stream) {
-    if (!n_blocks) return;
-    dim3 grid((n_blocks + kWalkThreads - 1) / kWalkThreads), block(kWalkThreads);
-    hipLaunchKernelGGL(k_chain_check, grid, block, 0, stream, d_out_off, d_isize, n_blocks, first_record_off, d_entry, d_exit,
-                       d_first_bad);
-    SBX_HIP(hipGetLastError());
-}
-
-void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, bool stop_at_trusted, uint64_t* d_entry,
-                         uint64_t* d_exit, uint32_t* d_count, uint64_t* d_ckpt, uint32_t* d_n_rewalked, hipStream_t stream) {
-    hipLaunchKernelGGL(k_chain_repair, dim3(1), dim3(64), 0, stream, d_U, total, d_out_off, d_isize, n_blocks,
-                       first_record_off, from, stop_at_trusted ? 1u : 0u, d_entry, d_exit, d_count, d_ckpt, d_n_rewalked);
+void launch_chain_repair(const uint8_t* d_U, const uint64_t* d_out_off, const uint32_t* d_isize, const uint32_t* d_run_of,
+                         const ChainRun* d_runs, uint32_t n_blocks, uint32_t from, uint64_t* d_entry, uint64_t* d_exit,
+                         uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream) {
+    hipLaunchKernelGGL(k_chain_repair, dim3(1), dim3(64), 0, stream, d_U, d_out_off, d_isize, d_run_of, d_runs, n_blocks, from,
+                       d_entry, d_exit, d_count, d_n_rewalked);
     SBX_HIP(hipGetLastError());
 }
 
@@ -763,17 +924,6 @@ size_t count_scan_tmp_bytes(uint32_t) { return 0; }
 
 void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void*, size_t, hipStream_t stream) {
     hipLaunchKernelGGL(k_count_scan, dim3(1), dim3(kScanThreads), 0, stream, d_count, n_blocks, d_base);
-    SBX_HIP(hipGetLastError());
-}
-
-void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_ckpt, const uint64_t* d_base, RefTable refs,
-                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
-                     uint64_t* d_name_hash, uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats, hipStream_t stream) {
-    if (!n_blocks) return;
-    dim3 grid((uint32_t)(((uint64_t)n_blocks * 4 + kWalkThreads - 1) / kWalkThreads)), block(kWalkThreads);
-    hipLaunchKernelGGL(k_describe, grid, block, 0, stream, d_U, total, d_out_off, d_isize, n_blocks, d_entry, d_ckpt, d_base,
-                       refs, d_filter, rg, tile_pos, d_desc, d_rec_ref, d_name_hash, d_tile_lo, d_tile_hi, d_stats);
     SBX_HIP(hipGetLastError());
 }
 

@@ -88,32 +88,57 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
 const char* inflate_status_string(uint32_t s);
 
 // ---- K2: record index (index.hip) ---------------------------------------------------------
-// guess + walk: per BGZF block, first record start g[b] >= out_off[b], record count and exit.
-void launch_block_walk(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                       uint32_t n_blocks, uint64_t first_record_off, RefTable refs, uint64_t* d_entry,
-                       uint64_t* d_exit, uint32_t* d_count, uint64_t* d_ckpt, hipStream_t stream);
-// parallel consistency check of the guessed chain: *d_first_bad = lowest inconsistent block (or unchanged)
-void launch_chain_check(const uint64_t* d_out_off, const uint32_t* d_isize, uint32_t n_blocks, uint64_t first_record_off,
-                        const uint64_t* d_entry, const uint64_t* d_exit, uint32_t* d_first_bad, hipStream_t stream);
-// serial (one wave) repair of the chain from block `from` on; with stop_at_trusted it returns at the first
-// block after a fix whose guessed entry is confirmed (the caller re-checks); *d_n_rewalked += wrong guesses
-void launch_chain_repair(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                         uint32_t n_blocks, uint64_t first_record_off, uint32_t from, bool stop_at_trusted, uint64_t* d_entry,
-                         uint64_t* d_exit, uint32_t* d_count, uint64_t* d_ckpt, uint32_t* d_n_rewalked, hipStream_t stream);
-// exclusive scan of per-block record counts -> d_base[n_blocks+1]
-void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void* d_tmp, size_t tmp_bytes,
-                       hipStream_t stream);
-size_t count_scan_tmp_bytes(uint32_t n_blocks);
+// One run of the device work list: a stretch [u_beg, u_end) of the (compacted) inflated stream that holds a
+// whole number of BAM records -- the whole file from its first record on, or a group of merged BAI chunks
+// (chunk boundaries are record boundaries, randomaccessmanager.d:247-294).  Blocks are launch-local indices.
+struct ChainRun {
+    uint64_t u_beg, u_end;
+    uint32_t blk_first, blk_last;      // inclusive
+};
 
 struct IndexStats {         // device-side accumulators of the describe pass
     unsigned long long n_records, n_admitted, n_bad, n_unknown_rg;
 };
-// walk again, decode fixed fields + CIGAR span, apply filter, write descriptors, mark tile ranges
-void launch_describe(const uint8_t* d_U, uint64_t total, const uint64_t* d_out_off, const uint32_t* d_isize,
-                     uint32_t n_blocks, const uint64_t* d_entry, const uint64_t* d_ckpt, const uint64_t* d_base, RefTable refs,
-                     const DeviceFilter* d_filter, RgTable rg, uint32_t tile_pos, RecDesc* d_desc, int32_t* d_rec_ref,
-                     uint64_t* d_name_hash /* may be null */, uint32_t* d_tile_lo, uint32_t* d_tile_hi, IndexStats* d_stats,
-                     hipStream_t stream);
+
+struct IndexArgs {
+    const uint8_t* U;               // inflated stream of this launch (offset 0 = first byte of block 0)
+    uint64_t u_alloc;               // readable bytes of U rounded up to 16 (the allocation is >= u_alloc + 64)
+    const uint64_t* out_off;        // [n_blocks] offset of every block in U
+    const uint32_t* isize;          // [n_blocks]
+    const uint32_t* run_of;         // [n_blocks] index into runs
+    const ChainRun* runs;
+    uint32_t n_blocks;
+    const uint32_t* inflate_status; // [n_blocks] K1 status
+    const uint64_t* entry_in;       // nullptr: guess the first record start of every block; else the repaired chain
+    uint64_t* entry;                // [n_blocks] out: first record start at or after the block's first byte (may lie beyond it)
+    uint64_t* exit_;                // [n_blocks] out: where the chain leaves the block
+    uint32_t* count;                // [n_blocks] out: records starting inside the block
+    uint64_t* state;                // [n_blocks] look-back status words, zeroed before the launch
+    uint32_t* ticket;               // zeroed before the launch
+    RefTable refs;
+    const DeviceFilter* filt;
+    RgTable rg;
+    uint32_t tile_pos;
+    RecDesc* desc;
+    int32_t* rec_ref;
+    uint64_t* name_hash;            // may be null
+    uint64_t desc_cap;              // capacity of desc / rec_ref / name_hash in records
+    uint32_t* tile_lo;
+    uint32_t* tile_hi;
+    IndexStats* stats;
+    uint32_t* flags;                // [0] lowest block with an inconsistent chain (0xFFFFFFFF: none), [1] lowest block whose
+                                    // inflate failed, [2] != 0: desc_cap was too small (nothing useful was written)
+};
+size_t index_lds_bytes();
+void launch_index_blocks(const IndexArgs& a, hipStream_t stream);
+// serial (one wave) repair of the recorded chain from block `from` on; *d_n_rewalked += blocks re-walked
+void launch_chain_repair(const uint8_t* d_U, const uint64_t* d_out_off, const uint32_t* d_isize, const uint32_t* d_run_of,
+                         const ChainRun* d_runs, uint32_t n_blocks, uint32_t from, uint64_t* d_entry, uint64_t* d_exit,
+                         uint32_t* d_count, uint32_t* d_n_rewalked, hipStream_t stream);
+// exclusive scan of per-chunk counts -> d_base[n + 1] (used by K6)
+void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void* d_tmp, size_t tmp_bytes,
+                       hipStream_t stream);
+size_t count_scan_tmp_bytes(uint32_t n_blocks);
 // compact the tiles that have work: active[] = tile ids, slot_of[t] = index into active or ~0u
 void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t* d_active,
                          uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream);
@@ -127,7 +152,7 @@ void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t
 // ---- K7: --fix-mate-overlaps, base mode (mates.hip) ---------------------------------------
 // d_mate[i] = index of the single overlapping same-name record of i (0xFFFFFFFF: none),
 // d_n_partners[i] = how many were found (> 1 is outside the supported scope)
-void launch_find_mates(const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
+void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
                        uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream);
 void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,
                              const uint32_t* d_tile_hi, const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base,

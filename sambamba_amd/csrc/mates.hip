@@ -17,7 +17,7 @@
 // same-name partners (the reference's behaviour then depends on per-column status history and on the
 // order produced by an unstable sort) raises SBX_EUNSUPPORTED.  Ties are
 // resolved as in the oracle: the record later in the file wins (column order; parity unpinned).
-// Equality of names is decided by the 64-bit hash.
+// Names are compared byte for byte after the hashes match (depth.d:352-353).
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -41,9 +41,18 @@ __device__ __forceinline__ uint32_t base5_m(uint32_t nib) {
 }
 __device__ __forceinline__ uint32_t pos_dw_m(uint32_t p, uint32_t sub_dw, uint32_t s7) { return (p & 3u) * sub_dw + (p >> 2) * s7; }
 
-__global__ __launch_bounds__(kMateThreads) void k_find_mates(const RecDesc* __restrict__ desc, const uint64_t* __restrict__ hash,
-                                                              const int32_t* __restrict__ rec_ref, uint64_t n, uint32_t* mate,
-                                                              uint32_t* n_partners) {
+// equal read names (depth.d:353 compares the names after the hashes)
+__device__ bool same_name(const uint8_t* U, const RecDesc& a, const RecDesc& b) {
+    if (a.l_name != b.l_name) return false;
+    const uint8_t* x = U + a.rec_off + 36;
+    const uint8_t* y = U + b.rec_off + 36;
+    for (uint32_t k = 0; k < a.l_name; ++k) if (x[k] != y[k]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(kMateThreads) void k_find_mates(const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc,
+                                                              const uint64_t* __restrict__ hash, const int32_t* __restrict__ rec_ref,
+                                                              uint64_t n, uint32_t* mate, uint32_t* n_partners) {
     const uint64_t i = (uint64_t)blockIdx.x * kMateThreads + threadIdx.x;
     if (i >= n) return;
     const RecDesc a = desc[i];
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(kMateThreads) void k_find_mates(const RecDesc* __re
     for (uint64_t j = i + 1; j < n; ++j) {
         const RecDesc b = desc[j];
         if (rec_ref[j] != ref || b.pos >= a.end) break;          // coordinate sorted: nothing further can overlap A
-        if (b.kind != 0 && hash[j] == h && b.sample == a.sample && b.end > a.pos) {
+        if (b.kind != 0 && hash[j] == h && b.sample == a.sample && b.end > a.pos && same_name(U, a, b)) {
             mate[i] = (uint32_t)j;
             mate[j] = (uint32_t)i;
             atomicAdd(&n_partners[i], 1u);
@@ -251,11 +260,11 @@ __global__ __launch_bounds__(kMateThreads) void k_mates_columns(
 
 }  // namespace
 
-void launch_find_mates(const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
+void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
                        uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream) {
     if (!n_records) return;
     hipLaunchKernelGGL(k_find_mates, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
-                       d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
+                       d_U, d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
     SBX_HIP(hipGetLastError());
 }
 

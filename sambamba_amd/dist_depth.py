@@ -1,16 +1,27 @@
-"""`depth region|window` of ONE BAM sharded over the ranks of a torch.distributed job (BASELINE config 4).
+"""`depth base|region|window` of ONE BAM sharded over the ranks of a torch.distributed job.
 
-Every rank opens the BAM on its own GPU, takes a run of consecutive contigs (shard.plan_contig_shards, balanced
-by length), runs the device pipeline for those contigs only (sbx_run_batch -- the engine then inflates just the
-BGZF blocks the BAI lists for them) and computes the statistics of the regions / windows lying on them.  Shards
-own disjoint outputs, so the only exchange is an all-gather of the small per-region rows; per-position data
-never leaves a GPU.  Rank 0 prints exactly what `sbx-depth` prints on one GPU.
+Every rank opens the BAM on its own GPU and takes a contiguous slice of the concatenated reference
+(shard.plan_position_shards: whole contigs and, where a contig is cut, position intervals inside it -- so ONE long
+contig shards as well as a whole genome does).  For every interval of its slice it runs the device pipeline over the
+reads that overlap the interval (sbx_run_interval: only the BGZF blocks the BAI lists for it are uploaded and inflated)
+and produces its share of the output:
 
+  base    the text of the positions it owns, formatted on the device; rank 0 concatenates the ranks' text in rank order
+          (point-to-point sends; with -o every rank could equally write its own byte range)
+  window  the statistics of the windows that start in its slice (cuts are aligned to the window size, so no window is split)
+  region  the statistics of the BED regions whose first position it owns (a region is never split)
+
+Shards own disjoint outputs, so the only exchange is the gather of small stat rows (as tensors: RCCL all_gather on GPUs)
+or of finished text; per-position counters never leave a GPU.  Rank 0 prints byte for byte what `sbx-depth` prints on one
+GPU for the supported option set (tests/test_gpu_dist.py).
+
+    python -m torch.distributed.run --nproc-per-node N -m sambamba_amd.dist_depth base in.bam
     python -m torch.distributed.run --nproc-per-node N -m sambamba_amd.dist_depth region -L x.bed -T 10 in.bam
 
-Window mode here covers disjoint windows (no --overlap) of genomes whose read-less contigs, if any, are followed by a
-contig with reads; the ring quirks the single-GPU CLI reproduces for the other cases are not
-replicated in this driver.
+Not replicated here (rejected with an error instead of printing something else; the single-GPU CLI handles them):
+`window --overlap > 0` (the reference's ring bookkeeping is order dependent), `base -L` together with `-c 0` (stateful
+consumption of the raw BED), and `window` on a genome whose LAST contigs have no reads (the reference continues the
+previous contig's window coordinates there).
 """
 import argparse
 import os
@@ -18,8 +29,8 @@ import sys
 
 import numpy as np
 
-from . import Depth, SBX_MODE_REGION, SBX_MODE_WINDOW
-from .shard import gather_region_stats, plan_contig_shards
+from . import Depth, SBX_MODE_BASE, SBX_MODE_REGION, SBX_MODE_WINDOW
+from .shard import gather_rows, plan_position_shards, send_text_to_rank0
 
 
 def fmt_g(x):
@@ -44,96 +55,219 @@ def region_row(prefix, length, n_reads, n_bases, cov, thresholds, sample, combin
     return row + "\n"
 
 
-def read_bed(path, depth):
-    """(ref_id, start, end, line) of every BED line naming a contig of the BAM, in file order."""
-    out = []
-    with open(path) as fh:
-        for line in fh:
-            f = line.split()
-            if len(f) < 3 or f[0] not in depth.ref_names:
-                continue
-            out.append((depth.ref_names.index(f[0]), int(f[1]), int(f[2]), line.rstrip()))
-    return out
+class Unsupported(RuntimeError):
+    pass
 
 
-def sharded_stats(bam, mode, raw=None, window=0, thresholds=(), min_bq=0, combined=False, fix_mate=False, filt=None,
-                  dist=None, device=0):
-    """Rows (index, payload) of every region (mode 'region') or window (mode 'window'), merged over the ranks.
-
-    region payload: (n_reads[S], n_bases[S], cov[S][n_thr], seen); window payload: (ref, k, n_reads[S], n_bases[S], cov[S][n_thr])."""
-    world = dist.get_world_size() if dist is not None else 1
-    rank = dist.get_rank() if dist is not None else 0
-    rows = []
-    with Depth(bam, device=device) as d:
-        if filt is not None:
-            d.set_filter(filt)
-        d.set_params(mode=SBX_MODE_REGION if mode == "region" else SBX_MODE_WINDOW, min_bq=min_bq, fix_mate_overlaps=fix_mate,
-                     combined=combined, window=window, thresholds=thresholds)
-        first, last = plan_contig_shards(d.ref_lengths, world)[rank]
-        if mode == "region":
-            merged = merge_regions([(r, s, e) for (r, s, e, _) in raw])
-            d.set_regions(merged)
-        info = {"ref_names": d.ref_names, "ref_lengths": d.ref_lengths, "samples": d.sample_names, "first_column": None}
-        if last > first:
-            # (a shard larger than the device would loop over d.plan_batches() here; one batch per shard otherwise)
-            d.run_batch(first, last - first)
-            nt = len(thresholds)
-            if mode == "region":
-                ids = [i for i, g in enumerate(raw) if first <= g[0] < last]
-                if ids:
-                    nr, nb, cov, seen = d.region_stats([raw[i][:3] for i in ids], nt)
-                    rows = [(i, (nr[j], nb[j], cov[j], int(seen[j]))) for j, i in enumerate(ids)]
-            else:
-                base = 0
-                for r in range(len(d.ref_lengths)):
-                    n_full = d.ref_lengths[r] // window
-                    if first <= r < last:
-                        if info["first_column"] is None:
-                            info["first_column"] = first_column(d, r)
-                        if n_full:
-                            nr, nb, cov = d.window_stats(r, 0, n_full, nt)
-                            rows += [(base + k, (r, k, nr[k], nb[k], cov[k])) for k in range(n_full)]
-                    base += n_full
-    firsts = gather_region_stats([(rank, info["first_column"])], dist)
-    info["first_column"] = next((fc for _, fc in firsts if fc is not None), None)
-    return gather_region_stats(rows, dist), info
+def _all_ok(dist, ok):
+    """True iff every rank is fine -- so that one failing rank cannot leave the others waiting in a collective."""
+    if dist is None:
+        return ok
+    import torch
+    from .shard import _dev
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=_dev(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
 
 
-def merge_regions(regs):
-    out = []
-    for r, s, e in sorted(regs):
-        if out and out[-1][0] == r and out[-1][2] >= s:
-            out[-1] = (r, out[-1][1], max(out[-1][2], e))
-        else:
-            out.append((r, s, e))
-    return out
+def _min_over_ranks(dist, value):
+    if dist is None:
+        return value
+    import torch
+    from .shard import _dev
+    t = torch.tensor([value], dtype=torch.int64, device=_dev(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
 
 
-def first_column(d, ref):
-    """(ref, pos) of the first pileup column on contig `ref`, or None."""
-    L = d.ref_lengths[ref]
-    step = 1 << 20
-    for b in range(0, L, step):
-        _, cov = d.base_counters(ref, b, min(L, b + step), with_covered=True)
+def _max_flags(dist, flags):
+    if dist is None:
+        return flags
+    import torch
+    from .shard import _dev
+    t = torch.tensor(flags, dtype=torch.int64, device=_dev(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(x) for x in t.cpu()]
+
+
+def first_column_in(d, ref, beg, end):
+    """Position of the first pileup column of the resident run inside [beg, end) of contig `ref`, or None."""
+    step = 1 << 16
+    for b in range(beg, end, step):
+        _, cov = d.base_counters(ref, b, min(end, b + step), with_covered=True)
         nz = np.flatnonzero(cov)
         if len(nz):
-            return (ref, b + int(nz[0]))
+            return b + int(nz[0])
     return None
+
+
+def run_sharded(a, dist, device, out):
+    """The whole job of one rank; rank 0 writes to `out`.  Raises Unsupported for option sets this driver rejects."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    thresholds = list(a.cov_threshold)
+    nt = len(thresholds)
+    mode = a.mode
+    if mode == "window" and a.overlap:
+        raise Unsupported("window --overlap > 0 is not supported by the sharded driver (use sbx-depth on one GPU)")
+    min_cov = a.min_coverage if a.min_coverage is not None else (1.0 if mode == "base" else 0.0)
+    if mode == "base" and a.regions and min_cov <= 0:
+        raise Unsupported("base -L with --min-coverage=0 is not supported by the sharded driver (use sbx-depth on one GPU)")
+    with Depth(a.bam, device=device) as d:
+        if a.filter is not None:
+            d.set_filter(a.filter)
+        d.set_params(mode={"base": SBX_MODE_BASE, "region": SBX_MODE_REGION, "window": SBX_MODE_WINDOW}[mode], min_bq=a.min_base_quality,
+                     fix_mate_overlaps=a.fix_mate_overlaps, combined=a.combined, window=a.window_size, thresholds=thresholds)
+        samples = ["*"] if a.combined else d.sample_names
+        S = len(samples)
+        merged = raw = lines = None
+        if a.regions:
+            merged, raw, lines = d.parse_regions(a.regions)
+            if not merged:
+                raise Unsupported("Enforcement failed")
+        align = a.window_size if mode == "window" else 1024
+        plan = plan_position_shards(d.ref_lengths, world, align=align)
+        mine = plan[rank]
+        n_ref = len(d.ref_lengths)
+
+        # ---- header line (rank 0) ----
+        if rank == 0:
+            if mode == "base":
+                out.write(("REF\tPOS\tCOV\tA\tC\tG\tT\tDEL\tREFSKIP" + ("" if a.combined else "\tSAMPLE") + ("\tFLAG" if a.annotate else "") + "\n").encode())
+            else:
+                n_before = 3 if mode == "window" else len(lines[0].split()) if lines else 3
+                head = "# " + "".join(c + "\t" for c in ["chrom", "chromStart", "chromEnd"][:min(3, n_before)]) + "".join("F%d\t" % k for k in range(3, n_before))
+                head += "readCount\tmeanCoverage" + "".join("\tpercentage%d" % t for t in thresholds)
+                head += ("" if a.combined else "\tsampleName") + ("\tmeanCovWithinBounds" if a.annotate else "") + "\n"
+                out.write(head.encode())
+
+        if mode == "base":
+            # which contigs have pileup columns decides where zero rows go under -c 0 (push / close, depth.d:567-606)
+            chunks = []
+            has_cols = [0] * n_ref
+            pieces = []         # (ref, beg, end, text or None)
+            if merged is not None:
+                d.set_regions(merged)
+            for ref, beg, end in mine:
+                d.run_interval(ref, beg, end)
+                if merged is not None:
+                    for r, s, e in merged:
+                        if r == ref and s < end and e > beg:
+                            pieces.append((ref, max(s, beg), min(e, end), d.format_base_rows(ref, max(s, beg), min(e, end), min_cov, a.max_coverage, a.annotate)))
+                    continue
+                if first_column_in(d, ref, beg, end) is not None:
+                    has_cols[ref] = 1
+                pieces.append((ref, beg, end, d.format_base_rows(ref, beg, end, min_cov, a.max_coverage, a.annotate)))
+                # alignments hanging over the end of the contig have columns beyond it: the owner of the contig's last position prints them
+                if end == d.ref_lengths[ref]:
+                    over = d.format_base_rows(ref, end, end + 1024, max(min_cov, 1e-9) if min_cov <= 0 else min_cov, a.max_coverage, a.annotate)
+                    if over:
+                        if min_cov <= 0:
+                            raise Unsupported("alignments hang over the end of contig %s: not supported with --min-coverage=0 by the sharded driver" % d.ref_names[ref])
+                        pieces.append((ref, end, end + 1024, over))
+            if merged is None and min_cov <= 0:
+                # a contig WITHOUT columns is zero-filled only before the first and after the last contig that has some
+                has_cols = _max_flags(dist, has_cols)
+                with_cols = [r for r in range(n_ref) if has_cols[r]]
+                keep = lambda r: has_cols[r] or not with_cols or r < with_cols[0] or r > with_cols[-1]
+                pieces = [p for p in pieces if keep(p[0])]
+            chunks = [p[3] for p in pieces if p[3]]
+            send_text_to_rank0(chunks, dist, out.write)
+            return
+
+        if mode == "region":
+            # Every rank reports on the raw regions whose first position it owns.  Reads are selected against ALL merged
+            # regions (a mate that reaches the pileup through a neighbour's region must still pair, depth.d:717-758), but
+            # fetched only for the hull of the owned regions of a contig, widened by one linear-index window on each side.
+            d.set_regions(merged)
+            ids_all, rows = [], []
+            for ref, beg, end in mine:
+                ids = [i for i, g in enumerate(raw) if g[0] == ref and beg <= g[1] < end]
+                if not ids:
+                    continue
+                lo = max(0, min(raw[i][1] for i in ids) - 16384)
+                hi = max(raw[i][2] for i in ids) + 16384
+                d.run_interval(ref, lo, hi)
+                nr, nb, cov, seen = d.region_stats([raw[i] for i in ids], nt)
+                for j, i in enumerate(ids):
+                    v = [int(seen[j])]
+                    for s in range(S):
+                        v += [int(nr[j][s]), int(nb[j][s])] + [int(x) for x in cov[j][s][:nt]]
+                    ids_all.append(i)
+                    rows.append(v)
+            idx, vals = gather_rows(np.asarray(ids_all, dtype=np.int64), np.asarray(rows, dtype=np.int64).reshape(len(ids_all), 1 + S * (2 + nt)), dist)
+            if rank == 0 and len(idx) and bool((vals[:, 0] != 0).any()):      # rows only if some column fell inside some region
+                for i, v in zip(idx.tolist(), vals.tolist()):
+                    r, s0, e0 = raw[i]
+                    for s in range(S):
+                        o = 1 + s * (2 + nt)
+                        row = region_row(lines[i].rstrip() + "\t", e0 - s0, v[o], v[o + 1], v[o + 2:o + 2 + nt], thresholds, samples[s], a.combined,
+                                         a.annotate, min_cov, a.max_coverage)
+                        if row:
+                            out.write(row.encode())
+            return
+
+        # ---- window ----
+        w = a.window_size
+        if w <= 0:
+            raise Unsupported("positive window size must be specified")
+        first_col = 1 << 62         # (ref << 32 | pos) of the first pileup column of the run
+        has_cols = [0] * n_ref
+        ids, rows = [], []
+        win_base = np.cumsum([0] + [L // w for L in d.ref_lengths])
+        for ref, beg, end in mine:
+            d.run_interval(ref, beg, end)
+            fc = first_column_in(d, ref, beg, end)
+            if fc is not None:
+                has_cols[ref] = 1
+                first_col = min(first_col, (ref << 32) | fc)
+            k0 = beg // w
+            k1 = d.ref_lengths[ref] // w if end >= d.ref_lengths[ref] else end // w      # only full windows are printed
+            if k1 > k0:
+                nr, nb, cov = d.window_stats(ref, k0, k1 - k0, nt)
+                for k in range(k0, k1):
+                    ids.append(int(win_base[ref]) + k)
+                    v = [ref, k]
+                    for s in range(S):
+                        v += [int(nr[k - k0][s]), int(nb[k - k0][s])] + [int(x) for x in cov[k - k0][s][:nt]]
+                    rows.append(v)
+        first_col = _min_over_ranks(dist, first_col)
+        has_cols = _max_flags(dist, has_cols)
+        with_cols = [r for r in range(n_ref) if has_cols[r]]
+        if with_cols and any(d.ref_lengths[r] // w for r in range(with_cols[-1] + 1, n_ref)):
+            raise Unsupported("window mode: the contigs after %s have no reads; the reference continues the previous contig's window "
+                              "coordinates there -- use sbx-depth on one GPU" % d.ref_names[with_cols[-1]])
+        idx, vals = gather_rows(np.asarray(ids, dtype=np.int64), np.asarray(rows, dtype=np.int64).reshape(len(ids), 2 + S * (2 + nt)), dist)
+        if rank == 0 and first_col != (1 << 62):
+            f_ref, f_pos = first_col >> 32, first_col & 0xFFFFFFFF
+            for v in vals.tolist():
+                r, k = v[0], v[1]
+                if r < f_ref or (r == f_ref and (k + 1) * w <= f_pos):
+                    continue                        # windows finished before the first column of the run print nothing
+                prefix = "%s\t%d\t%d\t" % (d.ref_names[r], k * w, (k + 1) * w)
+                for s in range(S):
+                    o = 2 + s * (2 + nt)
+                    row = region_row(prefix, w, v[o], v[o + 1], v[o + 2:o + 2 + nt], thresholds, samples[s], a.combined, a.annotate, min_cov,
+                                     a.max_coverage)
+                    if row:
+                        out.write(row.encode())
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="sambamba_amd.dist_depth")
-    ap.add_argument("mode", choices=["region", "window"])
+    ap.add_argument("mode", choices=["base", "region", "window"])
     ap.add_argument("bam")
     ap.add_argument("-L", "--regions")
     ap.add_argument("-w", "--window-size", type=int, default=0)
+    ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("-T", "--cov-threshold", type=int, action="append", default=[])
     ap.add_argument("-q", "--min-base-quality", type=int, default=0)
     ap.add_argument("-F", "--filter")
     ap.add_argument("-c", "--min-coverage", type=float, default=None)
-    ap.add_argument("-C", "--max-coverage", type=float, default=float("inf"))
+    ap.add_argument("-C", "--max-coverage", type=float, default=1e50)
     ap.add_argument("-a", "--annotate", action="store_true")
     ap.add_argument("-m", "--fix-mate-overlaps", action="store_true")
+    ap.add_argument("-o", "--output-filename")
     ap.add_argument("--combined", action="store_true")
     a = ap.parse_args(argv)
     import torch
@@ -150,47 +284,28 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
     dd = dist if world > 1 else None
-    min_cov = a.min_coverage if a.min_coverage is not None else 0.0     # region/window print everything by default
-    raw = None
-    if a.mode == "region":
-        with Depth(a.bam, device=device) as d0:
-            raw = read_bed(a.regions, d0)
-    rows, info = sharded_stats(a.bam, a.mode, raw=raw, window=a.window_size, thresholds=a.cov_threshold, min_bq=a.min_base_quality,
-                               combined=a.combined, fix_mate=a.fix_mate_overlaps, filt=a.filter, dist=dd, device=device)
-    if dd is None or dist.get_rank() == 0:
-        out = sys.stdout
-        samples = ["*"] if a.combined else info["samples"]
-        hdr_cols = ["chrom", "chromStart", "chromEnd"]
-        n_before = 3 if a.mode == "window" else len(raw[0][3].split()) if raw else 3
-        head = "# " + "".join(c + "\t" for c in hdr_cols[:min(3, n_before)]) + "".join("F%d\t" % k for k in range(3, n_before))
-        head += "readCount\tmeanCoverage" + "".join("\tpercentage%d" % t for t in a.cov_threshold)
-        head += ("" if a.combined else "\tsampleName") + ("\tmeanCovWithinBounds" if a.annotate else "") + "\n"
-        out.write(head)
-        if a.mode == "region":
-            if any(p[3] for _, p in rows):          # rows only if some column fell inside some region
-                for i, (nr, nb, cov, _seen) in rows:
-                    r, s, e, line = raw[i]
-                    for si, sm in enumerate(samples):
-                        row = region_row(line + "\t", e - s, nr[si], nb[si], cov[si], a.cov_threshold, sm, a.combined, a.annotate,
-                                         min_cov, a.max_coverage)
-                        if row:
-                            out.write(row)
-        else:
-            fc = info["first_column"]
-            w = a.window_size
-            for _, (r, k, nr, nb, cov) in rows:
-                if fc is None or r < fc[0] or (r == fc[0] and (k + 1) * w <= fc[1]):
-                    continue                        # windows finished before the first column of the run print nothing
-                prefix = "%s\t%d\t%d\t" % (info["ref_names"][r], k * w, (k + 1) * w)
-                for si, sm in enumerate(samples):
-                    row = region_row(prefix, w, nr[si], nb[si], cov[si], a.cov_threshold, sm, a.combined, a.annotate, min_cov,
-                                     a.max_coverage)
-                    if row:
-                        out.write(row)
+    rank = dist.get_rank() if dd is not None else 0
+    if a.mode == "region" and not a.regions:
+        sys.stderr.write("BED file or a region must be provided in region mode\n")
+        sys.exit(1)
+    out = None
+    if rank == 0:
+        out = open(a.output_filename, "wb") if a.output_filename else sys.stdout.buffer
+    rc = 0
+    try:
+        run_sharded(a, dd, device, out)
+    except Exception as e:      # the failing rank must not leave the others waiting in a collective: tear the group down hard
+        sys.stderr.write("sambamba-depth: %s\n" % (e.msg if hasattr(e, "msg") else e))
+        sys.stderr.flush()
+        if out is not None:
+            out.flush()
+        os._exit(1)
+    if out is not None:
         out.flush()
     if dd is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

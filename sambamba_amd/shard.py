@@ -1,13 +1,20 @@
-"""Contig sharding of ONE BAM across ranks (BASELINE config 4: `depth region` contig-sharded over 8 GPUs).
+"""Sharding of ONE BAM across the ranks of a torch.distributed job.
 
-The path shards by reference position: every rank takes a run of consecutive contigs (balanced by
-length), restricts the engine to them with sbx_set_regions (the engine then inflates only the BGZF
-blocks that the BAI lists for those contigs) and computes its share of the per-region / per-window
-statistics.  Outputs of different ranks are disjoint, so the only exchange is a gather of the small
-stat arrays (torch.distributed: RCCL on GPUs, gloo in the CPU tests) -- no per-position counters ever
-cross xGMI.
+The path shards by reference position (the reference's analogue is pileupChunks,
+BioD/bio/std/hts/bam/pileup.d:1011-1015): every rank takes a contiguous slice of the concatenated reference
+-- whole contigs and, where a contig is cut, position intervals inside it --, fetches the reads overlapping
+its slice through the BAI (sbx_run_interval: the chunk arithmetic of randomaccessmanager.d:247-294 plus the
+linear-index cut of baifile.d:75-80) and clips its contributions to the slice.  A read near a cut is seen by
+both neighbours; each counts only the positions it owns, so per-position outputs need no reduction, only
+concatenation.  With --fix-mate-overlaps both mates of a pair that straddles a cut are seen by both sides
+(each overlaps the slice of every position where the pair is resolved).  Regions and windows are never split:
+cuts are aligned to the window step, and a BED region belongs to the rank that owns its first position.
+The only exchange is a gather of small stat rows / of the finished text (torch.distributed: RCCL on GPUs, gloo
+in the CPU tests) -- no per-position counters ever cross xGMI.
 """
 from typing import List, Sequence, Tuple
+
+Interval = Tuple[int, int, int]     # (ref_id, beg, end), 0-based half-open
 
 
 def plan_contig_shards(ref_lengths: Sequence[int], world: int) -> List[Tuple[int, int]]:
@@ -30,8 +37,42 @@ def plan_contig_shards(ref_lengths: Sequence[int], world: int) -> List[Tuple[int
     return [(cuts[i], max(cuts[i], cuts[i + 1])) for i in range(world)]
 
 
-def regions_of_shard(ref_lengths: Sequence[int], shard: Tuple[int, int]) -> List[Tuple[int, int, int]]:
-    """Whole-contig regions (ref_id, 0, length) of a shard, for sbx_set_regions."""
+def plan_position_shards(ref_lengths: Sequence[int], world: int, align: int = 1024) -> List[List[Interval]]:
+    """Per rank, the intervals (ref_id, beg, end) of its slice of the concatenated reference: equal shares of the total
+    length, cuts inside a contig rounded to a multiple of `align` (the tile size, or the window step) so that no tile /
+    window is split.  Every position of every contig belongs to exactly one rank; a rank's intervals are in genome order."""
+    import bisect
+    n_ref = len(ref_lengths)
+    lens = [max(0, int(x)) for x in ref_lengths]
+    total = sum(lens)
+    starts, acc = [], 0
+    for L in lens:
+        starts.append(acc)
+        acc += L
+    out: List[List[Interval]] = [[] for _ in range(world)]
+    if total == 0:
+        return out
+
+    def locate(g):      # global position 0 <= g < total -> (ref, position aligned down)
+        r = bisect.bisect_right(starts, g) - 1
+        return r, (g - starts[r]) // align * align
+
+    bounds = [(0, 0)] + [locate(total * k // world) for k in range(1, world)] + [(n_ref, 0)]
+    for k in range(1, world):       # keep the cuts monotone (tiny contigs, more ranks than tiles)
+        if bounds[k] < bounds[k - 1]:
+            bounds[k] = bounds[k - 1]
+    for k in range(world):
+        (r0, p0), (r1, p1) = bounds[k], bounds[k + 1]
+        for r in range(r0, min(r1, n_ref - 1) + 1):
+            beg = p0 if r == r0 else 0
+            end = p1 if r == r1 else lens[r]
+            if end > beg:
+                out[k].append((r, beg, end))
+    return out
+
+
+def regions_of_shard(ref_lengths: Sequence[int], shard: Tuple[int, int]) -> List[Interval]:
+    """Whole-contig regions (ref_id, 0, length) of a contig shard, for sbx_set_regions."""
     return [(r, 0, int(ref_lengths[r])) for r in range(shard[0], shard[1]) if ref_lengths[r] > 0]
 
 
@@ -42,13 +83,127 @@ def owner_of_region(shards: Sequence[Tuple[int, int]], ref_id: int) -> int:
     return -1
 
 
-def gather_region_stats(local_rows, dist=None):
-    """All-gather per-rank lists of (region_index, payload) rows and return them merged by region index.
+def owner_of_position(plan: Sequence[Sequence[Interval]], ref_id: int, pos: int) -> int:
+    """Rank whose slice holds position `pos` of contig `ref_id` (-1: beyond the contig)."""
+    for rank, ivs in enumerate(plan):
+        for r, b, e in ivs:
+            if r == ref_id and b <= pos < e:
+                return rank
+    return -1
 
-    `dist` is torch.distributed (initialised) or None for a single process."""
+
+def clip_regions_to_shards(regions: Sequence[Interval], mine: Sequence[Interval]) -> List[Interval]:
+    """The regions a rank owns: those whose first position lies in its slice (a region is never split)."""
+    out = []
+    for (r, s, e) in regions:
+        for (mr, mb, me) in mine:
+            if r == mr and mb <= s < me:
+                out.append((r, s, e))
+                break
+    return out
+
+
+def merge_regions(regs: Sequence[Interval]) -> List[Interval]:
+    """Sorted union of the regions (what sbx_set_regions takes)."""
+    out: List[Interval] = []
+    for r, s, e in sorted(regs):
+        if out and out[-1][0] == r and out[-1][2] >= s:
+            out[-1] = (r, out[-1][1], max(out[-1][2], e))
+        else:
+            out.append((r, s, e))
+    return out
+
+
+def read_bed_regions(path: str, ref_names: Sequence[str]) -> List[Interval]:
+    """(ref_id, start, end) of a BED written by this harness (bench.py): three integer columns, known contigs only.
+    User-supplied -L arguments go through Depth.parse_regions (the library's parser, identical to the CLI's)."""
+    idx = {n: i for i, n in enumerate(ref_names)}
+    out = []
+    with open(path) as fh:
+        for line in fh:
+            f = line.split()
+            if len(f) >= 3 and f[0] in idx:
+                out.append((idx[f[0]], int(f[1]), int(f[2])))
+    return out
+
+
+# ---- exchange ---------------------------------------------------------------------------------------------------
+def _dev(dist):
+    import torch
+    if dist is not None and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_rows(index, values, dist=None):
+    """All-gather per-rank stat rows as tensors and return them merged and sorted by row index.
+
+    index: int64 [n]; values: int64 [n, k] (same k on every rank).  Ranks may hold different numbers of rows: the
+    lengths are exchanged first and the payload travels as one padded tensor per rank (RCCL all_gather on GPUs)."""
+    import torch
+    index = torch.as_tensor(index, dtype=torch.int64).reshape(-1)
+    values = torch.as_tensor(values, dtype=torch.int64).reshape(index.numel(), -1)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        order = torch.argsort(index)
+        return index[order], values[order]
+    dev = _dev(dist)
+    world = dist.get_world_size()
+    k = torch.tensor([values.shape[1]], dtype=torch.int64, device=dev)
+    dist.all_reduce(k, op=dist.ReduceOp.MAX)          # a rank without rows does not know k
+    k = int(k.item())
+    n = torch.tensor([index.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(1, max(sizes))
+    buf = torch.zeros((cap, k + 1), dtype=torch.int64, device=dev)
+    if index.numel():
+        buf[:index.numel(), 0] = index.to(dev)
+        buf[:index.numel(), 1:1 + values.shape[1]] = values.to(dev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    merged = torch.cat([p[:sizes[i]] for i, p in enumerate(parts)], dim=0).cpu()
+    order = torch.argsort(merged[:, 0], stable=True)
+    merged = merged[order]
+    return merged[:, 0], merged[:, 1:]
+
+
+def gather_region_stats(local_rows, dist=None):
+    """(kept for small, irregular payloads) all-gather lists of (index, payload) rows as Python objects."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return sorted(local_rows, key=lambda r: r[0])
     gathered = [None] * dist.get_world_size()
     dist.all_gather_object(gathered, list(local_rows))
     merged = [row for part in gathered for row in part]
     return sorted(merged, key=lambda r: r[0])
+
+
+def send_text_to_rank0(chunks, dist, write):
+    """Concatenate the ranks' text in rank order on rank 0: rank r sends its byte chunks point to point (RCCL send/recv on
+    GPUs), rank 0 hands every chunk to `write` -- per-position text never visits a third rank."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        for c in chunks:
+            write(c)
+        return
+    dev = _dev(dist)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank == 0:
+        for c in chunks:
+            write(c)
+        for src in range(1, world):
+            while True:
+                n = torch.zeros(1, dtype=torch.int64, device=dev)
+                dist.recv(n, src=src)
+                n = int(n.item())
+                if n < 0:
+                    break
+                buf = torch.empty(max(1, n), dtype=torch.uint8, device=dev)
+                dist.recv(buf, src=src)
+                write(bytes(buf[:n].cpu().numpy().tobytes()))
+    else:
+        for c in chunks:
+            dist.send(torch.tensor([len(c)], dtype=torch.int64, device=dev), dst=0)
+            t = torch.frombuffer(bytearray(c if len(c) else b"\0"), dtype=torch.uint8).to(dev)
+            dist.send(t, dst=0)
+        dist.send(torch.tensor([-1], dtype=torch.int64, device=dev), dst=0)

@@ -72,3 +72,73 @@ def test_plan_edge_cases():
     assert s == [(0, 2), (2, 4)]
     s = plan_contig_shards([], 2)
     assert s == [(0, 0), (0, 0)]
+
+
+def _worker_rows(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sambamba_amd.shard import gather_rows, plan_position_shards, send_text_to_rank0
+    import numpy as np
+    plan = plan_position_shards([5_000_000], world, align=1000)      # ONE contig: shards by position only
+    mine = plan[rank]
+    # rows = windows of 1000 starting in my slice; payload = (window index * 7, rank)
+    ids = [k for (r, b, e) in mine for k in range(b // 1000, e // 1000)]
+    vals = np.array([[k * 7, rank] for k in ids], dtype=np.int64).reshape(len(ids), 2)
+    idx, merged = gather_rows(np.array(ids, dtype=np.int64), vals, dist)
+    # text in rank order
+    got = []
+    send_text_to_rank0([b"r%d:" % rank, b"x" * (rank + 1), b""], dist, got.append)
+    if rank == 0:
+        q.put((plan, idx.tolist(), merged.tolist(), b"".join(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_position_sharding_row_gather_and_text_order(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29660 + world
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    plan, idx, merged, text = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the slices partition the contig, cuts on window boundaries
+    flat = [iv for part in plan for iv in part]
+    assert flat[0][1] == 0 and flat[-1][2] == 5_000_000
+    for a, b in zip(flat[:-1], flat[1:]):
+        assert a[2] == b[1] and a[2] % 1000 == 0
+    assert idx == list(range(5000))
+    assert [m[0] for m in merged] == [k * 7 for k in range(5000)]
+    assert sorted(set(m[1] for m in merged)) == list(range(world))
+    assert text == b"".join(b"r%d:" % r + b"x" * (r + 1) for r in range(world))
+
+
+def test_position_shard_plan_properties():
+    from sambamba_amd.shard import clip_regions_to_shards, owner_of_position, plan_position_shards
+    for lens, world, align in ((GRCH38, 8, 1000), ([248956422], 8, 1024), ([100, 0, 50], 3, 16), ([1000], 4, 1024)):
+        plan = plan_position_shards(lens, world, align)
+        assert len(plan) == world
+        seen = {}
+        for part in plan:
+            for r, b, e in part:
+                assert 0 <= b < e <= lens[r]
+                seen.setdefault(r, []).append((b, e))
+        for r, L in enumerate(lens):
+            cur = 0
+            for b, e in sorted(seen.get(r, [])):
+                assert b == cur and (b % align == 0)
+                cur = e
+            assert cur == L
+        sizes = [sum(e - b for _, b, e in part) for part in plan]
+        if sum(lens) > world * align * 4:
+            assert max(sizes) - min(sizes) <= 2 * align + 2
+    plan = plan_position_shards([10000, 10000], 2, 1000)
+    assert owner_of_position(plan, 0, 9999) == 0 and owner_of_position(plan, 1, 0) == 1 and owner_of_position(plan, 1, 10000) == -1
+    regs = [(0, 9990, 10000), (1, 0, 50), (0, 100, 20000)]
+    assert clip_regions_to_shards(regs, plan[0]) == [(0, 9990, 10000), (0, 100, 20000)]
+    assert clip_regions_to_shards(regs, plan[1]) == [(1, 0, 50)]

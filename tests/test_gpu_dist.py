@@ -1,4 +1,4 @@
-"""`depth region|window` of one BAM sharded over the ranks of a torch.distributed job (sambamba_amd.dist_depth,
+"""`depth base|region|window` of one BAM sharded over the ranks of a torch.distributed job (sambamba_amd.dist_depth,
 BASELINE config 4's shape): every rank runs its contigs through the device, rank 0 prints -- byte-identical to the
 single-GPU CLI.  Ranks share the one GPU of the test box and talk through gloo; on a multi-GPU node the same
 module runs one rank per GPU over RCCL."""
@@ -24,7 +24,7 @@ def genome(tmp_path_factory):
     return bam, bed
 
 
-def run_sharded(args, world, port):
+def run_sharded(args, world, port, first=b"# "):
     env = dict(os.environ, SBX_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "sambamba_amd.dist_depth"] + args
@@ -32,8 +32,40 @@ def run_sharded(args, world, port):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     # gloo announces its connections on stdout while the process group comes up (the ranks' lines interleave);
     # rank 0 prints afterwards, starting with the "# chrom ..." header
-    at = r.stdout.find(b"# ")
+    at = r.stdout.find(first)
     return r.stdout[at:] if at >= 0 else r.stdout
+
+
+@pytest.fixture(scope="module")
+def one_contig(tmp_path_factory):
+    """ONE contig (BASELINE config 5's shape): shards only by position; most mates overlap, some straddle every cut."""
+    d = tmp_path_factory.mktemp("dist1")
+    return gen_bam(str(d / "one.bam"), "chrOne:200000", coverage=40, seed=43,
+                   extra=["--insert-mean", "250", "--insert-sd", "40", "--tie-free-overlaps"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("args", [
+    ["base"],
+    ["base", "-m", "-q", "20"],
+    ["base", "-c", "0", "-a", "-C", "45"],
+    ["base", "-L", "chrOne:30000-150000", "-m"],
+    ["window", "-w", "1000", "-m", "-T", "20"],
+])
+def test_position_sharded_single_contig_equals_single_gpu_cli(one_contig, args, world):
+    want = run_cli(args + [one_contig])
+    assert len(want) > 1000
+    port = 29500 + 10 * world + (sum(map(ord, " ".join(args))) % 10)
+    got = run_sharded([args[0], one_contig] + args[1:], world, port, first=b"REF" if args[0] == "base" else b"# ")
+    assert got == want
+
+
+def test_position_sharded_base_on_a_genome(genome):
+    bam, bed = genome
+    for args in (["base"], ["base", "-c", "0"], ["base", "-L", bed, "-q", "10"]):
+        want = run_cli(args + [bam])
+        got = run_sharded([args[0], bam] + args[1:], 3, 29590 + len(args), first=b"REF")
+        assert got == want, args
 
 
 @pytest.mark.parametrize("world", [2, 3])
