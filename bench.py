@@ -46,6 +46,16 @@ GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1593
 GRCH38_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY", "chrM"]
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress of the harness on stderr (the JSON line on stdout stays alone)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %7.1fs] %s\n" % (time.time() - _T0, msg))
+        sys.stderr.flush()
+
+
 def ensure_built():
     from sambamba_amd import build as b
     b.build()
@@ -186,7 +196,7 @@ def parity_windows(d, bam, intervals, n_windows, seed, min_bq=0, fix_mate=False)
     S = d.n_samples_eff
     for ref, a, b in picks:
         got = d.base_counters(ref, a, b)
-        want = oracle_base_counters(bam, ref, a, b, n_samples=S, min_bq=min_bq, fix_mate=fix_mate)
+        want = oracle_base_counters(bam, ref, a, b, n_samples=S, min_bq=min_bq, fix_mate=fix_mate, ref_name=d.ref_names[ref])
         if not np.array_equal(got, want):
             bad.append([ref, a, b])
     return len(picks), bad
@@ -267,7 +277,9 @@ def main():
     key = "%s_%g_%x_%d_%s_%s" % (contigs, coverage, seed, args.level, args.codec, " ".join(extra))
     path = os.path.join(tmp_dir(), "sbx_bench_%s.bam" % hashlib.sha1(key.encode()).hexdigest()[:12])
     if rank == 0:
+        log("built; generating %s" % path)
         info = generate(path, contigs, coverage, seed, args.level, args.codec, extra)
+        log("BAM ready: %d reads" % int(info["reads"]))
     if dist:
         dist.barrier()
     if rank != 0:
@@ -357,15 +369,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    log("context open, input resident; warmup")
     for _ in range(args.warmup):
         one_pass()
     sync()
+    log("timed region: %d steps" % args.steps)
     t0 = time.perf_counter()
     kstats = []
     for _ in range(args.steps):
         kstats.append(one_pass())
     sync()
     elapsed = time.perf_counter() - t0
+    log("timed region done: %.1f ms per step; parity" % (elapsed / args.steps * 1e3))
     last = kstats[-1]
     my_reads = float(sum(s["n_records"] for s in last))
     my_adm = float(sum(s["n_admitted"] for s in last))
@@ -437,9 +452,11 @@ def main():
         # the fused-path figure of SURVEY.md 8(d): compressed bytes in + counters out over the whole pass
         fused = (comp + cnt) / (sum(kern.values()) * 1e-3) / 1e9 if sum(kern.values()) > 0 else 0.0
         cpu = None
+        log("parity %s; cpu baseline" % par.get("ok"))
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(path, min(args.cpu_sample_reads, int(info["reads"])), mode_args)
         e2e = None
+        log("cpu baseline done; e2e CLI")
         if not args.no_e2e and world == 1:
             e2e = cli_e2e(path, mode_args, int(info["reads"]))
             if cpu and e2e.get("Mreads_per_s"):
@@ -469,7 +486,9 @@ def main():
                      "runs_per_pass": len(last), "chain_runs": int(sum(s["n_runs"] for s in last)),
                      "window_rows_per_pass": window_rows[0] // max(1, args.steps + args.warmup)},
         }
+        log("done")
         print(json.dumps(line))
+        sys.stdout.flush()
     d.close()
     if dist:
         dist.barrier()

@@ -1674,6 +1674,38 @@ int orc_base_counters(const char* bam_path, int ref_id, long beg, long end, int 
     return rc;
 }
 
+// The same counters with the reads fetched through the BAI, as `depth base -L name:beg+1-end` fetches them
+// (getReadsOverlapping, depth.d:1184-1212): every read covering a position of [beg,end) overlaps the region, so the
+// columns inside it are the ones of the whole-file pileup -- seconds instead of a pass over a chromosome-sized BAM
+// (bench.py samples windows of the full-size run with it; tests/test_oracle_golden.py checks the equivalence).
+int orc_base_counters_indexed(const char* bam_path, const char* ref_name, int ref_id, long beg, long end, int min_bq,
+                              int fix_mate_overlaps, int combined, const char* filter, int n_samples, unsigned int* out,
+                              char* err, size_t errlen) {
+    orc::Options o;
+    o.mode = "base";
+    o.bams.push_back(bam_path);
+    o.min_cov = 1;
+    o.min_bq = min_bq;
+    o.fix_mate_overlaps = fix_mate_overlaps != 0;
+    o.combined = combined != 0;
+    if (filter) { o.filter = filter; o.has_filter = true; }
+    o.annotate = true;
+    o.regions = std::string(ref_name) + ":" + std::to_string(beg + 1) + "-" + std::to_string(end);
+    o.has_regions = true;
+    size_t n = (size_t)(end - beg) * (size_t)n_samples * 7;
+    memset(out, 0, n * sizeof(unsigned int));
+    std::string e;
+    FILE* devnull = fopen("/dev/null", "w");
+    int rc = orc::depth_main_impl(o, devnull, &e, nullptr, [&](int r, int64_t pos, uint32_t s, const uint64_t* v) {
+        if (r != ref_id || pos < beg || pos >= end || (int)s >= n_samples) return;
+        unsigned int* p = out + ((size_t)(pos - beg) * (size_t)n_samples + s) * 7;
+        for (int k = 0; k < 7; ++k) p[k] = (unsigned int)v[k];
+    });
+    if (devnull) fclose(devnull);
+    if (err && errlen) snprintf(err, errlen, "%s", e.c_str());
+    return rc;
+}
+
 // Inflate every BGZF block of a file (used to check the device inflater). Returns total bytes
 // or -1; when out == NULL only the size is computed.
 long long orc_inflate_all(const char* path, unsigned char* out, unsigned long long cap) {

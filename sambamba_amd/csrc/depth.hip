@@ -67,9 +67,13 @@ template <bool kSpan>
 __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
     const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, const uint32_t* __restrict__ tile_base,
-    int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq, uint32_t* __restrict__ counters,
+    int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq, uint32_t deep_thr, uint32_t* __restrict__ counters,
     uint32_t* __restrict__ span_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    {   // only the tiles k_accumulate16 left alone
+        const uint32_t t = active[blockIdx.x];
+        if (tile_hi[t] - tile_lo[t] < deep_thr) return;
+    }
     const uint32_t s7 = S * 7;
     const uint32_t sub_dw = (T / 4) * s7 + 8;
     uint32_t* cnt = lds;                  // 4 * sub_dw dwords
@@ -277,22 +281,310 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     }
 }
 
+
+// ---- K3, 16-bit LDS counters ----------------------------------------------------------------------------
+// The tile kernel above keeps 32-bit counters in LDS (28.7 KB per tile => 5 workgroups per CU) and is bound by how
+// many bytes a CU has in flight, not by HBM.  No counter of a tile can exceed the number of records whose range
+// [lo,hi) K2 marked for it, so every tile with fewer than 2^16 of them -- all of a WGS, any amplicon stack below
+// 65,535x -- is accumulated in 16-bit counters packed two per dword:
+//   * 16 bytes of LDS per (position, sample): {A|C}, {G|T}, {other|DEL}, {REFSKIP|-}; ds_add_u32 of 1 or 1<<16; a tile
+//     takes 16 KB and eight workgroups (32 waves, the CU's limit) are resident;
+//   * position p sits in slot p ^ ((p >> 4) & 7): the ten lanes of a read, 16 positions apart, fall into different
+//     bank groups instead of one;
+//   * fast path: 16 bases per lane, ten lanes per read, six reads per pass -- 12 bytes of packed sequence per lane,
+//     plus 16 bytes of qualities only when a base-quality threshold is set (-q 0, the default, never touches the
+//     quality strings: 150 of a record's ~283 bytes stay in HBM); the loads of the next pass are issued before the
+//     LDS atomics of the current one;
+//   * span counts (kSpan) are kept as a difference array (+1 at the first, -1 behind the last covered position of
+//     a read) and integrated once when the tile is written;
+//   * blockIdx -> tile slot is XCD-aware: workgroup b runs on XCD b % 8, so XCD x takes the x-th eighth of the
+//     active tiles in order and the reads straddling two tiles are found in the L2 that fetched them.
+// Tiles with deep_thr (2^16) or more records are left to k_accumulate (launched only when tile_compact counted any).
+constexpr uint32_t kGrpLanes = 10;       // lanes per read in the fast path
+constexpr uint32_t kGrpBases = 160;      // 16 bases per lane
+
+__device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 4) & 7u); }
+
+__device__ __forceinline__ uint32_t nibble_swap(uint32_t x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
+
+template <bool kSpan, bool kQual>
+__global__ __launch_bounds__(kAccThreads) void k_accumulate16(
+    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
+    const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, uint32_t n_active,
+    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq, uint32_t deep_thr,
+    uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // XCD-aware slot: the grid has 8 * per workgroups
+    const uint32_t per = gridDim.x >> 3;
+    const uint32_t slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (slot >= n_active) return;
+    const uint32_t tile = active[slot];
+    const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
+    if (r_hi - r_lo >= deep_thr) return;                // left to the 32-bit kernel
+    uint32_t* cnt = lds;                                  // [T][S][4] dwords
+    int32_t* spn = (int32_t*)(lds + T * S * 4);           // [T + 1] difference array (kSpan), then 4 wave totals
+    const uint32_t n_lds = T * S * 4 + (kSpan ? T + 1 + 4 : 0u);
+    for (uint32_t i = threadIdx.x; i < n_lds; i += kAccThreads) lds[i] = 0;
+
+    int lo_r = 0, hi_r = n_ref;   // invariant: tile_base[lo_r] <= tile < tile_base[hi_r]
+    while (hi_r - lo_r > 1) {
+        int mid = (lo_r + hi_r) >> 1;
+        if (tile_base[mid] <= tile) lo_r = mid; else hi_r = mid;
+    }
+    const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T);
+    const int32_t te = ts + (int32_t)T;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // counter dword of (tile offset p, sample, code) and its increment
+    auto add_code = [&](uint32_t p, uint32_t sample, uint32_t code) {
+        atomicAdd(&cnt[(__umul24(swz(p), S) + sample) * 4u + (code >> 1)], 1u << ((code & 1u) << 4));
+    };
+    auto clip = [&](int32_t rp, uint32_t qp, uint32_t len, uint32_t l_seq, int32_t* i0, int32_t* i1) {
+        *i0 = ts > rp ? ts - rp : 0;
+        int32_t e = (int32_t)len < te - rp ? (int32_t)len : te - rp;
+        if ((int64_t)qp + (int64_t)e > (int64_t)l_seq) e = (int32_t)l_seq - (int32_t)qp;   // malformed record guard
+        *i1 = e;
+    };
+    // general path helpers: a run of aligned bases / of D or N positions of one read, all 64 lanes
+    auto match_run = [&](const RecU& R, int32_t rp, uint32_t qp, uint32_t len) {
+        int32_t i0, i1;
+        clip(rp, qp, len, R.l_seq, &i0, &i1);
+        for (int32_t i = i0 + 4 * (int32_t)lane; i < i1; i += 256) {
+            const uint32_t q = qp + (uint32_t)i;
+            const uint32_t nb = (uint32_t)(i1 - i) < 4u ? (uint32_t)(i1 - i) : 4u;
+            const uint32_t qw = kQual ? ld32u(R.qual + q) : 0u, sw = ld32u(R.seq + (q >> 1));
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < nb) {
+                    const uint32_t qi = (q & 1u) + k;
+                    const uint32_t byte = (sw >> (8u * (qi >> 1))) & 0xFFu;
+                    const uint32_t nib = (qi & 1u) ? (byte & 15u) : (byte >> 4);
+                    const uint32_t ql = (qw >> (8u * k)) & 0xFFu;
+                    if (!kQual || ql >= min_bq) add_code((uint32_t)(rp + i - ts) + k, R.sample, base5_of_nibble(nib));
+                }
+            }
+        }
+    };
+    auto gap_run = [&](const RecU& R, int32_t rp, uint32_t len, uint32_t code) {
+        int32_t i0 = ts > rp ? ts - rp : 0;
+        int64_t room = (int64_t)te - rp;
+        int32_t i1 = (int64_t)len < room ? (int32_t)len : (int32_t)(room < 0 ? 0 : room);
+        for (int32_t i = i0 + (int32_t)lane; i < i1; i += 64) add_code((uint32_t)(rp + i - ts), R.sample, code);
+    };
+
+    for (uint32_t c = r_lo + wave * 64u; c < r_hi; c += (kAccThreads / 64) * 64u) {
+        const uint32_t ri = c + lane;
+        RecDesc d;
+        d.kind = 0;
+        d.pos = 0; d.end = 0; d.rec_off = 0; d.l_seq = 0; d.n_cigar = 0; d.l_name = 0; d.q_start = 0; d.sample = 0;
+        if (ri < r_hi) d = desc[ri];
+        const bool take = d.kind != 0 && d.pos < te && d.end > ts;
+        if (kSpan && take) {
+            const int32_t a = d.pos > ts ? d.pos : ts, b2 = d.end < te ? d.end : te;
+            atomicAdd(&spn[a - ts], 1);
+            atomicAdd(&spn[b2 - ts], -1);
+        }
+        // ---- fast path: one run of aligned bases with at most 160 of them inside the tile ------------------
+        int32_t fi0 = 0, fi1 = 0;
+        const bool one_run = take && d.kind == 1;
+        if (one_run) clip(d.pos, d.q_start, (uint32_t)(d.end - d.pos), d.l_seq, &fi0, &fi1);
+        const uint32_t run_n = one_run && fi1 > fi0 ? (uint32_t)(fi1 - fi0) : 0u;
+        const bool fast = run_n != 0 && run_n <= kGrpBases;
+        const uint32_t f_n = fast ? run_n : 0u;                                       // bases of the run inside the tile
+        const uint32_t f_q0 = (uint32_t)d.q_start + (uint32_t)fi0;                  // query offset of the first of them
+        const uint32_t f_t0 = (uint32_t)(d.pos + fi0 - ts);                          // its tile offset
+        const uint64_t f_seq = d.rec_off + 36u + d.l_name + 4u * (uint32_t)d.n_cigar;  // offset of the packed sequence in U
+        const uint32_t f_qd = (d.l_seq + 1u) >> 1;                                   // qualities follow the sequence
+        const uint32_t f_smp = S > 1 ? (uint32_t)d.sample : 0u;
+        const uint32_t grp = lane / kGrpLanes, sub = lane - grp * kGrpLanes;         // lanes 60..63: grp 6 = idle
+        uint64_t m1 = __ballot(fast);
+
+        struct Pass { uint32_t q[4]; uint32_t s[3]; uint32_t nb, par, t, smp; };
+        auto fetch = [&](uint64_t& m) {
+            int r[6];
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                r[g] = -1;
+                if (m) { r[g] = __builtin_ctzll(m); m &= m - 1; }
+            }
+            const int src = grp == 0 ? r[0] : grp == 1 ? r[1] : grp == 2 ? r[2] : grp == 3 ? r[3] : grp == 4 ? r[4] : grp == 5 ? r[5] : -1;
+            const int sl = src < 0 ? 0 : src;
+            const uint32_t n_src = __shfl(f_n, sl, 64);     // every lane takes part
+            const uint32_t n = src < 0 ? 0u : n_src;
+            const uint32_t q0 = __shfl(f_q0, sl, 64), t0 = __shfl(f_t0, sl, 64);
+            const uint32_t s_lo = __shfl((uint32_t)f_seq, sl, 64), s_hi = __shfl((uint32_t)(f_seq >> 32), sl, 64);
+            Pass P;
+            P.smp = S > 1 ? __shfl(f_smp, sl, 64) : 0u;
+            const uint32_t qd = kQual ? __shfl(f_qd, sl, 64) : 0u;
+            const uint32_t j = 16u * sub;
+            P.nb = j < n ? (n - j < 16u ? n - j : 16u) : 0u;
+            const uint32_t q = q0 + j;
+            P.par = q & 1u;
+            P.t = t0 + j;
+            P.q[0] = P.q[1] = P.q[2] = P.q[3] = 0; P.s[0] = P.s[1] = P.s[2] = 0;
+            if (P.nb) {
+                // the <= 9 sequence bytes holding bases q..q+15 and their 16 qualities (reads past the run stay inside
+                // the record / the stream's 64-byte padding)
+                const uint8_t* seq = U + (((uint64_t)s_hi << 32) | s_lo);
+                const uint8_t* sp = seq + (q >> 1);
+                P.s[0] = ld32u(sp); P.s[1] = ld32u(sp + 4); P.s[2] = ld32u(sp + 8);
+                if (kQual) {
+                    const uint8_t* qp = seq + qd + q;
+                    P.q[0] = ld32u(qp); P.q[1] = ld32u(qp + 4); P.q[2] = ld32u(qp + 8); P.q[3] = ld32u(qp + 12);
+                }
+            }
+            return P;
+        };
+        auto consume = [&](const Pass& P) {
+            if (P.nb == 0) return;
+            // nibbles in stream order (high nibble of a byte first), the lane's first base at bit 0
+            const uint32_t y0 = nibble_swap(P.s[0]), y1 = nibble_swap(P.s[1]), y2 = nibble_swap(P.s[2]);
+            const uint32_t sh = P.par * 4u;
+            const uint32_t b0 = __builtin_amdgcn_alignbit(y1, y0, sh), b1 = __builtin_amdgcn_alignbit(y2, y1, sh);
+            const uint32_t base_dw = __umul24(P.smp, 4u);
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) {
+                if (k < P.nb) {
+                    const uint32_t nib = ((k < 8 ? b0 : b1) >> (4u * (k & 7u))) & 15u;
+                    const uint32_t ql = kQual ? (P.q[k >> 2] >> (8u * (k & 3u))) & 0xFFu : 0u;
+                    if (!kQual || ql >= min_bq) {
+                        const uint32_t code = base5_of_nibble(nib);
+                        atomicAdd(&cnt[__umul24(swz(P.t + k), S * 4u) + base_dw + (code >> 1)], 1u << ((code & 1u) << 4));
+                    }
+                }
+            }
+        };
+        if (m1) {
+            Pass cur = fetch(m1);
+            for (;;) {
+                const bool more = m1 != 0;
+                Pass nxt;
+                if (more) nxt = fetch(m1);
+                consume(cur);
+                if (!more) break;
+                cur = nxt;
+            }
+        }
+        // ---- everything else (general CIGARs, runs longer than 160 bases): one read at a time, 64 lanes -------
+        uint64_t m2 = __ballot(take && !fast && (d.kind == 2 || run_n != 0));
+        while (m2) {
+            const int r = __builtin_ctzll(m2);
+            m2 &= m2 - 1;
+            RecU R;
+            const uint32_t off_lo = __builtin_amdgcn_readlane((uint32_t)d.rec_off, r);
+            const uint32_t off_hi = __builtin_amdgcn_readlane((uint32_t)(d.rec_off >> 32), r);
+            R.pos = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.pos, r);
+            R.end = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.end, r);
+            R.l_seq = __builtin_amdgcn_readlane(d.l_seq, r);
+            const uint32_t misc = __builtin_amdgcn_readlane((uint32_t)d.n_cigar | ((uint32_t)d.l_name << 16) | ((uint32_t)d.kind << 24), r);
+            const uint32_t misc2 = __builtin_amdgcn_readlane((uint32_t)d.q_start | ((uint32_t)d.sample << 16), r);
+            R.n_cigar = misc & 0xFFFFu;
+            R.kind = misc >> 24;
+            R.q_start = misc2 & 0xFFFFu;
+            R.sample = (S > 1) ? (misc2 >> 16) : 0u;
+            const uint8_t* rec = U + (((uint64_t)off_hi << 32) | off_lo);
+            R.cig = rec + 36 + ((misc >> 16) & 0xFFu);
+            R.seq = R.cig + 4 * R.n_cigar;
+            R.qual = R.seq + ((R.l_seq + 1) >> 1);
+            // CIGAR walk as in k_accumulate: a reference-consuming op occupies max(len, 1) columns (pileup.d:195-205) and the
+            // read leaves the pileup at end = pos + sum(len) (read.d:1380-1383)
+            int32_t rp = R.pos;
+            uint32_t qp = 0;
+            for (uint32_t k = 0; k < R.n_cigar; ++k) {
+                uint32_t op = ld32u(R.cig + 4 * k);
+                uint32_t ty = (kCigarType >> ((op & 15u) * 2u)) & 3u, len = op >> 4;
+                if (ty & 2u) {
+                    if (len == 0) len = 1;
+                    const int32_t room = R.end - rp;
+                    if ((int64_t)len > (int64_t)room) len = (uint32_t)(room > 0 ? room : 0);
+                }
+                if (ty == 3) {
+                    match_run(R, rp, qp, len);
+                    rp += (int32_t)len;
+                    qp += len;
+                } else if (ty == 2) {
+                    gap_run(R, rp, len, (op & 15u) == 2u ? 5u : 6u);   // D -> DEL, otherwise (N) -> REFSKIP
+                    rp += (int32_t)len;
+                } else if (ty == 1) {
+                    qp += len;
+                }
+                if (rp >= te || rp >= R.end) break;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- write the tile once: 16-bit pairs -> u32[T][S][7], coalesced 16-byte stores --------------------------
+    const uint32_t s7 = S * 7;
+    const uint32_t n_cnt = T * s7;                  // multiple of 4 (T >= 16)
+    uint32_t* out = counters + (size_t)slot * n_cnt;
+    const uint32_t inv_s7 = 0xFFFFFFFFu / s7 + 1u;      // i / s7 by reciprocal multiplication (exact for i < 2^16)
+    const uint32_t inv_7 = 0xFFFFFFFFu / 7u + 1u;
+    for (uint32_t i4 = threadIdx.x * 4u; i4 < n_cnt; i4 += kAccThreads * 4u) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t i = i4 + e;
+            const uint32_t p = __umulhi(i, inv_s7), rem = i - __umul24(p, s7);
+            const uint32_t smp = __umulhi(rem, inv_7), k = rem - smp * 7u;
+            const uint32_t w = cnt[(__umul24(swz(p), S) + smp) * 4u + (k >> 1)];
+            v[e] = (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
+        }
+        *(uint4*)(out + i4) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    if (kSpan) {
+        // integrate the difference array: every thread owns `chunk` consecutive positions
+        const uint32_t chunk = (T + kAccThreads - 1) / kAccThreads;
+        const uint32_t p0 = threadIdx.x * chunk;
+        int32_t loc = 0;
+        for (uint32_t k = 0; k < chunk; ++k) if (p0 + k < T) loc += spn[p0 + k];
+        int32_t incl = loc;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int32_t o = __shfl_up(incl, dlt, 64);
+            if ((int)lane >= dlt) incl += o;
+        }
+        int32_t* wtot = spn + T + 1;
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int32_t run = incl - loc;
+        for (uint32_t w = 0; w < wave; ++w) run += wtot[w];
+        uint32_t* so = span_out + (size_t)slot * T;
+        for (uint32_t k = 0; k < chunk; ++k) {
+            if (p0 + k < T) { run += spn[p0 + k]; so[p0 + k] = (uint32_t)run; }
+        }
+    }
+}
+
 }  // namespace
 
 void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_tile_lo, const uint32_t* d_tile_hi,
-                       const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base, int32_t n_ref,
-                       uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
+                       const uint32_t* d_active, uint32_t n_active, uint32_t n_deep, uint32_t deep_thr, const uint32_t* d_tile_base,
+                       int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
                        hipStream_t stream) {
     if (!n_active) return;
+    {
+        const size_t lds = (size_t)tile_pos * n_samples * 16 + (d_span ? ((size_t)tile_pos + 5) * 4 : 0);
+        const dim3 grid(((n_active + 7) / 8) * 8), block(kAccThreads);
+        auto go = [&](auto kern) {
+            SBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base, n_ref,
+                               tile_pos, n_samples, min_bq, deep_thr, d_counters, d_span);
+        };
+        if (d_span) { if (min_bq) go(k_accumulate16<true, true>); else go(k_accumulate16<true, false>); }
+        else { if (min_bq) go(k_accumulate16<false, true>); else go(k_accumulate16<false, false>); }
+        SBX_HIP(hipGetLastError());
+    }
+    if (!n_deep) return;
     size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0);
     if (d_span) {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate<true>, dim3(n_active), dim3(kAccThreads), lds, stream, d_U, d_desc, d_tile_lo,
-                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, deep_thr, d_counters, d_span);
     } else {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate<false>, dim3(n_active), dim3(kAccThreads), lds, stream, d_U, d_desc, d_tile_lo,
-                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, deep_thr, d_counters, d_span);
     }
     SBX_HIP(hipGetLastError());
 }

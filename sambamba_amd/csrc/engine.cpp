@@ -64,7 +64,7 @@ struct WorkList {
 // result words of a pass, written by async copies into pinned host memory and read after one synchronisation
 struct HostResults {
     uint32_t flags[4];
-    uint32_t n_active, pad;
+    uint32_t n_active, n_deep;
     IndexStats st;
     uint64_t last_state;
     uint32_t max_partners, n_rewalked;
@@ -869,6 +869,10 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     uint64_t want_cap = std::max<uint64_t>(c->desc_cap, w.u_bytes / 160 + 4096);
     const bool dbg = getenv("SBX_DEBUG") != nullptr;
     const char* force = getenv("SBX_FORCE_REPAIR");   // debug hook (tests/test_gpu_repair.py)
+    // tiles with this many records or more keep 32-bit LDS counters in K3 (debug hook: a small value sends ordinary tiles
+    // down that path, tests/test_gpu_depth.py)
+    uint32_t deep_thr = kDeepTileRecords;
+    if (const char* e = getenv("SBX_DEEP_TILE_RECORDS")) { const long v = atol(e); if (v >= 1 && v < (long)kDeepTileRecords) deep_thr = (uint32_t)v; }
     uint32_t n_rewalked = 0;
     uint64_t n_records = 0;
     bool entries_given = false;
@@ -898,17 +902,17 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         a.inflate_status = c->d_status.p;
         a.entry_in = entries_given ? c->d_entry.p : nullptr;
         a.entry = c->d_entry.p; a.exit_ = c->d_exit.p; a.count = c->d_count.p;
-        a.state = c->d_state.p; a.ticket = c->d_flag.p + 3;
+        a.state = c->d_state.p; a.scratch = c->d_lit.p;
         a.refs = refs; a.filt = c->d_filter.p; a.rg = rg; a.tile_pos = T;
         a.desc = c->d_desc.p; a.rec_ref = c->d_rec_ref.p; a.name_hash = c->fix_mate ? c->d_name_hash.p : nullptr;
         a.desc_cap = c->desc_cap;
         a.tile_lo = c->d_tile_lo.p; a.tile_hi = c->d_tile_hi.p; a.stats = c->d_stats.p; a.flags = c->d_flag.p;
         launch_index_blocks(a, s);
-        launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
+        launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, deep_thr, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
         if (attempt == 0) t2.stop(s);
         R.last_state = 0;
         SBX_HIP(hipMemcpyAsync(R.flags, c->d_flag.p, 16, hipMemcpyDeviceToHost, s));
-        SBX_HIP(hipMemcpyAsync(&R.n_active, c->d_n_active.p, 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(&R.n_active, c->d_n_active.p, 8, hipMemcpyDeviceToHost, s));      // n_active, n_deep
         SBX_HIP(hipMemcpyAsync(&R.st, c->d_stats.p, sizeof(IndexStats), hipMemcpyDeviceToHost, s));
         if (nb) SBX_HIP(hipMemcpyAsync(&R.last_state, c->d_state.p + (nb - 1), 8, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));                            // ---- host synchronisation 1 of 2 ----
@@ -982,7 +986,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
                                  c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_covm.p, c->d_addm.p, c->d_span.p, s);
         }
     } else
-        launch_accumulate(c->U(), c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, c->d_tile_base.p,
+        launch_accumulate(c->U(), c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, R.n_deep, deep_thr, c->d_tile_base.p,
                           n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
     t3.stop(s);
     t_all.stop(s);

@@ -7,30 +7,24 @@
 // CustomBamRead (depth.d:240-250; read.d:1070-1087,1219-1230) and pileupColumns' zero-span
 // filter (pileup.d:510).
 //
-// One launch, one 256-thread workgroup per BGZF block (`k_index_blocks`):
-//   1. the block's inflated bytes (+ 4 KiB of what follows) are copied into LDS with coalesced 16-byte
-//      loads -- the only time K2 touches the stream, every line exactly once;
-//   2. the record chain (each block_size tells where the next record starts) is serial, so it is cut
-//      twice: at BGZF block granularity across workgroups and at quarter-block granularity across the
-//      four waves of a workgroup.  A run of the work list starts at an exactly known record boundary
-//      (first record of the file / a BAI chunk start); everywhere else a wave GUESSES the first record
-//      start in its stretch with a structural plausibility test (ids / positions in range, lengths
-//      consistent with block_size, NUL-terminated name, two further records chain and are
-//      coordinate-sorted), 64 candidate offsets at a time, and walks the chain through LDS to the end of
-//      its stretch;
-//   3. the guesses are VERIFIED, never trusted: inside the block, quarter q must be entered exactly where
-//      quarter q-1 was left (otherwise one wave re-walks the whole block serially); across blocks the
-//      entry of block b must equal the exit of block b-1, which the workgroup reads while it looks back
-//      for its slot range (below).  By induction from the exactly known start of the run a consistent
-//      chain IS the true chain; an inconsistency is reported to the host, which repairs the chain
-//      serially (`k_chain_repair`, rare) and launches again with the entries given;
-//   4. the slot range of the block's records in the descriptor array is the exclusive prefix sum of the
-//      per-block record counts, obtained inside the same launch by decoupled look-back over a per-block
-//      status word (aggregate / inclusive prefix), blocks taking tickets in dispatch order;
-//   5. one lane per record decodes the fields out of LDS: fixed part, CIGAR span and shape, the -F
-//      program, RG -> sample, name hash; writes the 32-byte RecDesc and marks the [lo,hi) record range of
-//      every position tile the record overlaps (one atomic per tile change inside a wave).
-// Bound: HBM -- the inflated stream read once + 32 B per record written.
+// Three launches over the BGZF blocks of the work list:
+//   1. `k_walk_blocks` -- the record chain (each block_size tells where the next record starts) is serial, so it is
+//      cut at BGZF block granularity and walked by ONE LANE PER BLOCK: hundreds of thousands of pointer chases in flight
+//      hide the latency of a dependent load per record.  A run of the work list starts at an exactly known record
+//      boundary (first record of the file / a BAI chunk start); everywhere else the lane GUESSES the first record start
+//      in its block with a structural plausibility test (ids / positions in range, lengths consistent with block_size,
+//      NUL-terminated name, two further records chain and are coordinate-sorted).  The lane leaves the block-relative
+//      offsets of its records (u16, written 16 bytes at a time) in the block's slice of K1's literal stream, which is
+//      dead once the block is inflated -- no extra memory;
+//   2. `k_check_scan` -- the guesses are VERIFIED, never trusted: the entry of block b must equal the exit of block b-1
+//      (by induction from the exactly known start of the run a consistent chain IS the true chain; an inconsistency is
+//      reported to the host, which repairs the chain serially -- `k_chain_repair`, rare -- and launches again with the
+//      entries given); the same single workgroup scans the per-block record counts into slot ranges;
+//   3. `k_describe_blocks` -- one wave per block, ONE LANE PER RECORD: fixed part, CIGAR span and shape, the -F program,
+//      RG -> sample, name hash; writes the 32-byte RecDesc and marks the [lo,hi) record range of every position tile the
+//      record overlaps (one atomic per tile change inside a wave).
+// Bound: HBM latency / line traffic -- one 128-byte line per record in the walk and one or two in the describe pass
+// (DESIGN.md section 4).
 #include "common.hpp"
 #include "kernels.hpp"
 #include "regex_nfa.hpp"
@@ -41,11 +35,6 @@ namespace sbx {
 
 namespace {
 
-constexpr int kIdxThreads = 256;
-constexpr uint32_t kWinExtra = 4096;                       // bytes after the block that are visible in LDS
-constexpr uint32_t kWinBytes = 65536 + kWinExtra + 16;     // (+16: the window starts at a 16-byte boundary)
-constexpr uint32_t kQuarterRecs = 456;                     // records starting in 16 KiB: <= 16384 / 36 + 1
-constexpr uint32_t kRecSlots = 4 * kQuarterRecs;           // also enough for a whole block walked serially (65536 / 36 + 1)
 constexpr uint64_t kStateMask = (1ull << 62) - 1;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -65,23 +54,12 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t* p) {
 constexpr uint32_t kCigarType = 0x3C1A7u;
 __device__ __forceinline__ uint32_t cig_type(uint32_t raw) { return (kCigarType >> ((raw & 15u) * 2u)) & 3u; }
 
-// View of the stream around one BGZF block: offsets in [w0, w1) are served from the LDS copy, anything
-// else from global memory (records far longer than a block).  Pointers are generic (flat loads).
-struct Win {
-    const uint8_t* lds;     // lds[0] holds stream offset w0
-    const uint8_t* U;
-    uint64_t w0, w1;
-    __device__ __forceinline__ const uint8_t* ptr(uint64_t o, uint64_t n) const {
-        return (o >= w0 && o + n <= w1) ? lds + (o - w0) : U + o;
-    }
-};
-
 // Structural plausibility of a BAM record starting at offset o of the stream (fixed part only);
 // `limit` = end of the run: no record may extend beyond it.
-__device__ bool plausible_record(const Win& W, uint64_t limit, uint64_t o, const RefTable& refs, uint64_t* next,
+__device__ bool plausible_record(const uint8_t* U, uint64_t limit, uint64_t o, const RefTable& refs, uint64_t* next,
                                  uint32_t* sort_key_ref, int32_t* sort_key_pos) {
     if (o + 36 > limit) return false;
-    const uint8_t* p = W.ptr(o, 36 + 256 + 4);
+    const uint8_t* p = U + o;
     int64_t bs = (int32_t)ld32(p);
     if (bs < 32 || bs > (int64_t)(1 << 29)) return false;
     int32_t ref = (int32_t)ld32(p + 4);
@@ -118,7 +96,7 @@ __device__ bool plausible_record(const Win& W, uint64_t limit, uint64_t o, const
 }
 
 // is `o` the start of a chain of three plausible, coordinate-sorted records (or of the last records of the run)?
-__device__ bool plausible_chain(const Win& W, uint64_t limit, uint64_t o, const RefTable& refs) {
+__device__ bool plausible_chain(const uint8_t* W, uint64_t limit, uint64_t o, const RefTable& refs) {
     uint64_t n1, n2, n3;
     uint32_t r1, r2, r3;
     int32_t p1, p2, p3;
@@ -611,249 +589,187 @@ __device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexAr
     return R;
 }
 
-// ---- decoupled look-back ------------------------------------------------------------------------
-// state[b] = flag << 62 | value: flag 0 nothing yet, 1 value = records of block b, 2 value = records of blocks 0..b.
-__device__ __forceinline__ uint64_t ld_state(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, d, 64);
-    return v;
-}
-// records in blocks 0 .. b-1 (one wave; predecessors hold lower tickets, so they are running or done)
-__device__ uint64_t look_back(const uint64_t* state, uint32_t b, uint32_t lane) {
-    uint64_t excl = 0;
-    for (int64_t idx = (int64_t)b - 1; idx >= 0; idx -= 64) {
-        const int64_t j = idx - (int64_t)lane;
-        uint64_t v;
-        do { v = j >= 0 ? ld_state(state + j) : (2ull << 62); } while (__any((v >> 62) == 0));
-        const uint64_t m2 = __ballot((v >> 62) == 2);
-        const uint32_t stop = m2 ? (uint32_t)__builtin_ctzll(m2) : 64u;
-        excl += wave_sum64(lane <= stop ? (v & kStateMask) : 0ull);
-        if (m2) break;
-    }
-    return excl;
+// ---- 1. walk ------------------------------------------------------------------------------------------
+constexpr int kWalkThreads = 64;
+
+// the block's record offsets (u16, relative to the block's first byte) live in its slice of the literal stream
+__device__ __forceinline__ uint16_t* rec_list(uint8_t* scratch, uint64_t out_off_b, uint32_t b) {
+    return (uint16_t*)(scratch + inflate_lit_offset(out_off_b, b));
 }
 
-struct IdxShared {
-    uint64_t g[4], x[4];
-    uint32_t n[4];
-    uint64_t base;
-    uint32_t b, n_adm, n_bad, n_urg;
-};
-
-__global__ __launch_bounds__(kIdxThreads) void k_index_blocks(IndexArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* win = smem;
-    uint16_t* rec = (uint16_t*)(smem + kWinBytes);
-    IdxShared* sh = (IdxShared*)(smem + kWinBytes + 2 * kRecSlots);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) {
-        sh->b = atomicAdd(a.ticket, 1u);
-        sh->n_adm = sh->n_bad = sh->n_urg = 0;
-    }
-    __syncthreads();
-    const uint32_t b = sh->b;
+__global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
+    const uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (b >= a.n_blocks) return;
     const uint64_t beg = a.out_off[b], blk_end = beg + a.isize[b];
     const ChainRun run = a.runs[a.run_of[b]];
     const uint64_t lo = beg > run.u_beg ? beg : run.u_beg, hi0 = blk_end < run.u_end ? blk_end : run.u_end;
     const uint64_t hi = hi0 > lo ? hi0 : lo;
     const bool first_of_run = b == run.blk_first, last_of_run = b == run.blk_last;
-    // ---- 1. the block (and 4 KiB of what follows) into LDS ------------------------------------------
-    Win W;
-    W.lds = win;
-    W.U = a.U;
-    W.w0 = beg & ~15ull;
-    W.w1 = W.w0 + kWinBytes < a.u_alloc ? W.w0 + kWinBytes : a.u_alloc;      // (u_alloc: multiple of 16, >= stream end + 16)
-    {
-        const uint32_t nbytes = (uint32_t)(W.w1 - W.w0);
-        const uint8_t* src = a.U + W.w0;
-        for (uint32_t off = tid * 16u; off < nbytes; off += kIdxThreads * 16u)
-            *(u32x4*)(win + off) = *(const u32x4*)(src + off);
+    uint64_t E = kOffUnknown;
+    if (first_of_run) E = run.u_beg;
+    else if (a.entry_in) E = a.entry_in[b];
+    else {
+        for (uint64_t o = lo; o < hi; ++o)
+            if (plausible_chain(a.U, run.u_end, o, a.refs)) { E = o; break; }
     }
-    __syncthreads();
-    // ---- 2. entries of the four quarters and their walks ------------------------------------------------
-    const bool given = a.entry_in != nullptr;
-    uint64_t E = first_of_run ? run.u_beg : given ? a.entry_in[b] : kOffUnknown;
-    const bool known = first_of_run || given;
-    const uint64_t qlen = (hi - lo + 3) / 4;
-    const uint64_t s_q = lo + wv * qlen < hi ? lo + wv * qlen : hi, e_q = s_q + qlen < hi ? s_q + qlen : hi;
-    {
-        uint64_t g = kOffUnknown;
-        if (wv == 0 && known) g = E;
-        else {
-            for (uint64_t o0 = s_q; o0 < e_q && g == kOffUnknown; o0 += 64) {
-                const uint64_t o = o0 + lane;
-                const bool ok = o < e_q && plausible_chain(W, run.u_end, o, a.refs);
-                const uint64_t m = __ballot(ok);
-                if (m) g = o0 + (uint64_t)__builtin_ctzll(m);
+    uint32_t n = 0;
+    uint64_t X = E;
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v grp = {0, 0, 0, 0};                  // the last 8 offsets, oldest in the low half of .x
+    uint16_t* list = rec_list(a.scratch, beg, b);
+    if (E != kOffUnknown && E != kOffInvalid && E >= lo) {
+        uint64_t o = E;
+        bool okc = true;
+        while (o < hi) {
+            if (o + 36 > run.u_end) { okc = false; break; }
+            const int64_t bs = (int32_t)ld32(a.U + o);
+            if (bs < 32 || o + 4 + (uint64_t)bs > run.u_end) { okc = false; break; }
+            grp.x = (grp.x >> 16) | (grp.y << 16);
+            grp.y = (grp.y >> 16) | (grp.z << 16);
+            grp.z = (grp.z >> 16) | (grp.w << 16);
+            grp.w = (grp.w >> 16) | ((uint32_t)(o - beg) << 16);
+            ++n;
+            if ((n & 7u) == 0) *(u32x4v*)(list + (n - 8)) = grp;
+            o += 4 + (uint64_t)bs;
+        }
+        X = okc ? o : kOffInvalid;
+        if (n & 7u) {
+            for (uint32_t k = n & 7u; k < 8; ++k) {
+                grp.x = (grp.x >> 16) | (grp.y << 16);
+                grp.y = (grp.y >> 16) | (grp.z << 16);
+                grp.z = (grp.z >> 16) | (grp.w << 16);
+                grp.w = grp.w >> 16;
             }
+            *(u32x4v*)(list + (n & ~7u)) = grp;
         }
-        // walk (wave-uniform): records starting in [g, e_q)
-        uint32_t n = 0;
-        uint64_t x = g;
-        if (g != kOffUnknown && g != kOffInvalid && g >= s_q && g < e_q) {
-            uint64_t o = g;
-            bool okc = true;
-            while (o < e_q) {
-                if (o + 36 > run.u_end) { okc = false; break; }
-                const int64_t bs = (int32_t)ld32(win + (o - W.w0));
-                if (bs < 32 || o + 4 + (uint64_t)bs > run.u_end) { okc = false; break; }
-                if (lane == 0) rec[wv * kQuarterRecs + n] = (uint16_t)(o - beg);
-                ++n;
-                o += 4 + (uint64_t)bs;
-            }
-            x = okc ? o : kOffInvalid;
-        }
-        if (lane == 0) { sh->g[wv] = g; sh->x[wv] = x; sh->n[wv] = n; }
+    } else if (E != kOffUnknown && E != kOffInvalid) {
+        X = kOffInvalid;        // an entry below the block: impossible for a true chain
     }
-    __syncthreads();
-    // ---- 3. stitch the quarters (every thread, same result) ------------------------------------------------
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    uint64_t X = kOffUnknown;
-    bool serial = false;
-    {
-        if (!known) {
-#pragma unroll
-            for (int q = 3; q >= 0; --q) if (sh->g[q] != kOffUnknown) E = sh->g[q];
-        }
-        uint64_t cur = E;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint64_t sq = lo + q * qlen < hi ? lo + q * qlen : hi, eq = sq + qlen < hi ? sq + qlen : hi;
-            if (serial || cur == kOffUnknown || cur == kOffInvalid) continue;
-            if (cur >= eq) continue;                       // no record starts in this quarter
-            if (sh->g[q] != cur) { serial = true; continue; }
-            cnt[q] = sh->n[q];
-            cur = sh->x[q];
-        }
-        X = cur;
-    }
-    if (serial) {
-        // a quarter was not entered where its wave had guessed (a decoy, or a record longer than a quarter):
-        // one wave walks the whole block from its entry
-        __syncthreads();
-        if (wv == 0) {
-            uint32_t n = 0;
-            uint64_t o = E;
-            bool okc = true;
-            while (o < hi) {
-                if (o + 36 > run.u_end) { okc = false; break; }
-                const int64_t bs = (int32_t)ld32(win + (o - W.w0));
-                if (bs < 32 || o + 4 + (uint64_t)bs > run.u_end) { okc = false; break; }
-                if (lane == 0 && n < kRecSlots) rec[n] = (uint16_t)(o - beg);
-                ++n;
-                o += 4 + (uint64_t)bs;
-            }
-            if (lane == 0) { sh->n[0] = n; sh->x[0] = okc ? o : kOffInvalid; }
-        }
-        __syncthreads();
-        cnt[0] = sh->n[0]; cnt[1] = cnt[2] = cnt[3] = 0;
-        X = sh->x[0];
-    }
-    const uint32_t count = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    a.entry[b] = E;
+    a.exit_[b] = X;
+    a.count[b] = n;
     const bool bad_block = E == kOffUnknown || E == kOffInvalid || X == kOffUnknown || X == kOffInvalid || X < E ||
                            (last_of_run && X != run.u_end);
-    // ---- 4. publish, describe the first 256 records while the predecessors publish, look back --------------
-    if (tid == 0) {
-        a.entry[b] = E;
-        a.count[b] = count;
-        __hip_atomic_store(a.exit_ + b, X, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.state + b, ((b == 0 ? 2ull : 1ull) << 62) | (uint64_t)count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (bad_block) atomicMin(a.flags + 0, b);
-        if (a.inflate_status[b] != 0) atomicMin(a.flags + 1, b);
+    if (bad_block) atomicMin(a.flags + 0, b);
+    if (a.inflate_status[b] != 0) atomicMin(a.flags + 1, b);
+}
+
+// ---- 2. chain check + scan of the per-block counts (single workgroup; n_blocks is ~1e5..1e6) ------------------
+// state[b] = 2 << 62 | records in blocks 0..b (the engine reads the last one); flags[0] = lowest inconsistent block,
+// flags[2] != 0: the descriptor array is too small for the total
+__global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
+    __shared__ uint64_t part[kScanThreads];
+    const uint32_t t = threadIdx.x, n = a.n_blocks;
+    const uint32_t per = (n + kScanThreads - 1) / kScanThreads;
+    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    uint64_t s = 0;
+    uint32_t first_bad = 0xFFFFFFFFu;
+    for (uint32_t i = lo; i < hi; ++i) {
+        s += a.count[i];
+        const ChainRun r = a.runs[a.run_of[i]];
+        if (i != r.blk_first && a.exit_[i - 1] != a.entry[i] && first_bad == 0xFFFFFFFFu) first_bad = i;
     }
-    auto rec_at = [&](uint32_t i) -> uint64_t {          // stream offset of the block's record number i
-        uint32_t q = 0, j = i;
-        if (!serial) {
-            if (j >= cnt[0]) { j -= cnt[0]; q = 1; if (j >= cnt[1]) { j -= cnt[1]; q = 2; if (j >= cnt[2]) { j -= cnt[2]; q = 3; } } }
-        }
-        return beg + rec[serial ? i : q * kQuarterRecs + j];
-    };
-    auto describe_at = [&](uint32_t i) -> Described {
-        const uint64_t o = rec_at(i);
-        const uint8_t* p = win + (o - W.w0);                 // the fixed part always lies inside the window
-        const int64_t bs = (int32_t)ld32(p);
-        if (o + 4 + (uint64_t)bs > W.w1) p = a.U + o;        // the whole record must be addressable through one pointer
-        return describe_record(p, o, a);
-    };
-    Described R;
-    R.admit = false;
-    if (tid < count) R = describe_at(tid);
-    if (wv == 0) {
-        uint64_t base = 0;
-        if (b != 0) {
-            base = look_back(a.state, b, lane);
-            if (lane == 0) {
-                __hip_atomic_store(a.state + b, (2ull << 62) | (base + count), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                if (!first_of_run) {
-                    // the predecessor's exit was stored before its status word (release / acquire)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    const uint64_t px = __hip_atomic_load(a.exit_ + (b - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (px != E) atomicMin(a.flags + 0, b);
+    if (first_bad != 0xFFFFFFFFu) atomicMin(a.flags + 0, first_bad);
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {      // Hillis-Steele inclusive scan over the partials
+        const uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t runsum = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        runsum += a.count[i];
+        a.state[i] = (2ull << 62) | runsum;
+    }
+    if (t == kScanThreads - 1 && part[kScanThreads - 1] > a.desc_cap) atomicOr(a.flags + 2, 1u);
+}
+
+// ---- 3. describe: one wave per block, one lane per record ---------------------------------------------------
+constexpr int kDescThreads = 256;
+
+__global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
+    __shared__ uint32_t tot[4];          // records, admitted, malformed, unknown read group of this workgroup's blocks
+    if (threadIdx.x < 4) tot[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * (kDescThreads / 64) + (threadIdx.x >> 6);
+    // (descriptor array too small: nothing is written, the host enlarges it and launches again)
+    const uint32_t count = (b < a.n_blocks && !a.flags[2]) ? a.count[b] : 0u;
+    uint32_t n_adm = 0, n_bad = 0, n_urg = 0;
+    if (count) {
+        const uint64_t beg = a.out_off[b];
+        const uint64_t base = (a.state[b] & kStateMask) - count;
+        const uint16_t* list = rec_list(a.scratch, beg, b);
+        for (uint32_t i0 = 0; i0 < count; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool live = i < count;
+            Described R;
+            R.admit = false; R.bad = false; R.urg = false; R.t0 = R.t1 = 0;
+            const uint64_t idx = base + i;
+            if (live) {
+                const uint64_t o = beg + list[i];
+                R = describe_record(a.U + o, o, a);
+                a.desc[idx] = R.d;
+                a.rec_ref[idx] = R.ref;
+                if (a.name_hash) a.name_hash[idx] = R.hash;
+                n_adm += R.admit ? 1u : 0u;
+                n_bad += R.bad ? 1u : 0u;
+                n_urg += R.urg ? 1u : 0u;
+            }
+            // records of a wave have consecutive indices, so the lowest index of a tile is held by the first lane of a run
+            // of equal tiles and the highest by the last one
+            const bool adm = live && R.admit;
+            const uint32_t t0 = adm ? R.t0 : 0xFFFFFFFFu;
+            const uint32_t t0_prev = __shfl_up(t0, 1, 64), t0_next = __shfl_down(t0, 1, 64);
+            if (adm) {
+                if (lane == 0 || t0_prev != t0) atomicMin(&a.tile_lo[t0], (uint32_t)idx);
+                if (lane == 63 || t0_next != t0) atomicMax(&a.tile_hi[t0], (uint32_t)idx + 1);
+                for (uint32_t t = R.t0 + 1; t <= R.t1; ++t) {
+                    atomicMin(&a.tile_lo[t], (uint32_t)idx);
+                    atomicMax(&a.tile_hi[t], (uint32_t)idx + 1);
                 }
             }
         }
-        if (lane == 0) sh->base = base;
-    }
-    __syncthreads();
-    const uint64_t base = sh->base;
-    if (base + count > a.desc_cap) {                   // descriptor array too small: the host enlarges it and launches again
-        if (tid == 0) atomicOr(a.flags + 2, 1u);
-        return;
-    }
-    // ---- 5. write descriptors, mark tile ranges -------------------------------------------------------------
-    uint32_t n_adm = 0, n_bad = 0, n_urg = 0;
-    for (uint32_t i0 = 0; i0 < count; i0 += kIdxThreads) {
-        const uint32_t i = i0 + tid;
-        if (i0 != 0) { R.admit = false; if (i < count) R = describe_at(i); }
-        const bool live = i < count;
-        const uint64_t idx = base + i;
-        if (live) {
-            a.desc[idx] = R.d;
-            a.rec_ref[idx] = R.ref;
-            if (a.name_hash) a.name_hash[idx] = R.hash;
-            n_adm += R.admit ? 1u : 0u;
-            n_bad += R.bad ? 1u : 0u;
-            n_urg += R.urg ? 1u : 0u;
+        for (int d = 32; d >= 1; d >>= 1) {
+            n_adm += __shfl_xor(n_adm, d, 64);
+            n_bad += __shfl_xor(n_bad, d, 64);
+            n_urg += __shfl_xor(n_urg, d, 64);
         }
-        // records of a wave have consecutive indices, so the lowest index of a tile is held by the first lane of a run
-        // of equal tiles and the highest by the last one
-        const bool adm = live && R.admit;
-        const uint32_t t0 = adm ? R.t0 : 0xFFFFFFFFu;
-        const uint32_t t0_prev = __shfl_up(t0, 1, 64), t0_next = __shfl_down(t0, 1, 64);
-        if (adm) {
-            if (lane == 0 || t0_prev != t0) atomicMin(&a.tile_lo[t0], (uint32_t)idx);
-            if (lane == 63 || t0_next != t0) atomicMax(&a.tile_hi[t0], (uint32_t)idx + 1);
-            for (uint32_t t = R.t0 + 1; t <= R.t1; ++t) {
-                atomicMin(&a.tile_lo[t], (uint32_t)idx);
-                atomicMax(&a.tile_hi[t], (uint32_t)idx + 1);
-            }
+        if (lane == 0) {
+            atomicAdd(&tot[0], count);
+            if (n_adm) atomicAdd(&tot[1], n_adm);
+            if (n_bad) atomicAdd(&tot[2], n_bad);
+            if (n_urg) atomicAdd(&tot[3], n_urg);
         }
     }
-    if (n_adm) atomicAdd(&sh->n_adm, n_adm);
-    if (n_bad) atomicAdd(&sh->n_bad, n_bad);
-    if (n_urg) atomicAdd(&sh->n_urg, n_urg);
     __syncthreads();
-    if (tid == 0) {
-        if (count) atomicAdd(&a.stats->n_records, (unsigned long long)count);
-        if (sh->n_adm) atomicAdd(&a.stats->n_admitted, (unsigned long long)sh->n_adm);
-        if (sh->n_bad) atomicAdd(&a.stats->n_bad, (unsigned long long)sh->n_bad);
-        if (sh->n_urg) atomicAdd(&a.stats->n_unknown_rg, (unsigned long long)sh->n_urg);
+    if (threadIdx.x == 0) {
+        if (tot[0]) atomicAdd(&a.stats->n_records, (unsigned long long)tot[0]);
+        if (tot[1]) atomicAdd(&a.stats->n_admitted, (unsigned long long)tot[1]);
+        if (tot[2]) atomicAdd(&a.stats->n_bad, (unsigned long long)tot[2]);
+        if (tot[3]) atomicAdd(&a.stats->n_unknown_rg, (unsigned long long)tot[3]);
     }
 }
 
 // ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
 __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* __restrict__ tile_lo,
-                                                                const uint32_t* __restrict__ tile_hi, uint32_t n_tiles,
+                                                                const uint32_t* __restrict__ tile_hi, uint32_t n_tiles, uint32_t deep_thr,
                                                                 uint32_t* __restrict__ active, uint32_t* __restrict__ slot_of,
                                                                 uint32_t* __restrict__ n_active) {
     // 1024 tiles per step, coalesced: rank inside the wave by ballot, wave totals through LDS
     __shared__ uint32_t wtot[kScanThreads / 64];
+    __shared__ uint32_t deep_total;
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    if (t == 0) deep_total = 0;
+    uint32_t n_deep = 0;                 // this thread's tiles with >= 2^16 records (K3 keeps 32-bit counters for them)
     uint32_t run = 0;                    // active tiles before this step (workgroup-uniform)
     for (uint32_t i0 = 0; i0 < n_tiles; i0 += kScanThreads) {
         const uint32_t i = i0 + t;
-        const bool on = i < n_tiles && tile_hi[i] > tile_lo[i];
+        const uint32_t lo_i = i < n_tiles ? tile_lo[i] : 0u, hi_i = i < n_tiles ? tile_hi[i] : 0u;
+        const bool on = hi_i > lo_i;
+        n_deep += on && hi_i - lo_i >= deep_thr ? 1u : 0u;
         const uint64_t m = __ballot(on);
         if (lane == 0) wtot[wv] = (uint32_t)__popcll(m);
         __syncthreads();
@@ -876,7 +792,9 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* _
         run += all;
         __syncthreads();
     }
-    if (t == 0) *n_active = run;
+    if (n_deep) atomicAdd(&deep_total, n_deep);
+    __syncthreads();
+    if (t == 0) { n_active[0] = run; n_active[1] = deep_total; }
 }
 
 
@@ -898,17 +816,14 @@ void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream
     SBX_HIP(hipGetLastError());
 }
 
-size_t index_lds_bytes() { return (size_t)kWinBytes + 2 * kRecSlots + sizeof(IdxShared); }
-
 void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
     if (!a.n_blocks) return;
-    const size_t lds = index_lds_bytes();
-    static bool attr_set = false;
-    if (!attr_set) {
-        SBX_HIP(hipFuncSetAttribute((const void*)k_index_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_index_blocks, dim3(a.n_blocks), dim3(kIdxThreads), lds, stream, a);
+    hipLaunchKernelGGL(k_walk_blocks, dim3((a.n_blocks + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, stream, a);
+    SBX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_check_scan, dim3(1), dim3(kScanThreads), 0, stream, a);
+    SBX_HIP(hipGetLastError());
+    const uint32_t per = kDescThreads / 64;
+    hipLaunchKernelGGL(k_describe_blocks, dim3((a.n_blocks + per - 1) / per), dim3(kDescThreads), 0, stream, a);
     SBX_HIP(hipGetLastError());
 }
 
@@ -927,9 +842,9 @@ void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_b
     SBX_HIP(hipGetLastError());
 }
 
-void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t* d_active,
+void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t deep_thr, uint32_t* d_active,
                          uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream) {
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(kScanThreads), 0, stream, d_tile_lo, d_tile_hi, n_tiles, d_active,
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(kScanThreads), 0, stream, d_tile_lo, d_tile_hi, n_tiles, deep_thr, d_active,
                        d_slot_of, d_n_active);
     SBX_HIP(hipGetLastError());
 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy
 // output overrun only at the end of a loop iteration, kLitPerIter literals late at most)
 // entry stream of block b  : u32 at ent[ent_off(b) ..], 16-byte aligned, capacity isize/3 + isize/255 + 7
 // Both offsets are pure functions of (out_off[b], b) so that no extra table is needed.
-__host__ __device__ __forceinline__ uint64_t lit_off(uint64_t out_off_b, uint32_t b) { return (out_off_b + 48ull * b + 15ull) & ~15ull; }
+__host__ __device__ __forceinline__ uint64_t lit_off(uint64_t out_off_b, uint32_t b) { return inflate_lit_offset(out_off_b, b); }
 __host__ __device__ __forceinline__ uint64_t ent_off(uint64_t out_off_b, uint32_t b) { return (out_off_b / 3 + out_off_b / 255 + 12ull * b + 3ull) & ~3ull; }
 
 __device__ __forceinline__ uint32_t make_entry(uint32_t lit_run, uint32_t len, uint32_t dist) {

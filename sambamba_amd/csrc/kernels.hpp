@@ -78,6 +78,9 @@ struct RgTable {            // read-group id strings -> sample id (depth.d:1170-
 // K1b lz77_resolve (wave per block -> inflated bytes).  The per-block arrays are indexed from 0 for
 // the n_blocks blocks of this launch; block0 is the index of the first one in the whole file (it
 // only positions the blocks' slices inside the token streams).
+// offset of block b's 16-byte aligned slice (capacity >= isize[b] + 33 bytes) in the literal stream; a pure function of
+// (out_off[b], b).  K2 reuses the slice, dead once the block is inflated, for the block's record offsets.
+__host__ __device__ __forceinline__ uint64_t inflate_lit_offset(uint64_t out_off_b, uint32_t b) { return (out_off_b + 48ull * b + 15ull) & ~15ull; }
 size_t inflate_scratch_bytes(uint32_t n_blocks);
 size_t inflate_lit_bytes(uint64_t total_out, uint32_t n_blocks);
 size_t inflate_ent_words(uint64_t total_out, uint32_t n_blocks);
@@ -113,8 +116,8 @@ struct IndexArgs {
     uint64_t* entry;                // [n_blocks] out: first record start at or after the block's first byte (may lie beyond it)
     uint64_t* exit_;                // [n_blocks] out: where the chain leaves the block
     uint32_t* count;                // [n_blocks] out: records starting inside the block
-    uint64_t* state;                // [n_blocks] look-back status words, zeroed before the launch
-    uint32_t* ticket;               // zeroed before the launch
+    uint64_t* state;                // [n_blocks] out: 2 << 62 | records in blocks 0..b
+    uint8_t* scratch;               // K1's literal stream (launch-local block indices): block b's record offsets go to its slice
     RefTable refs;
     const DeviceFilter* filt;
     RgTable rg;
@@ -129,7 +132,6 @@ struct IndexArgs {
     uint32_t* flags;                // [0] lowest block with an inconsistent chain (0xFFFFFFFF: none), [1] lowest block whose
                                     // inflate failed, [2] != 0: desc_cap was too small (nothing useful was written)
 };
-size_t index_lds_bytes();
 void launch_index_blocks(const IndexArgs& a, hipStream_t stream);
 // serial (one wave) repair of the recorded chain from block `from` on; *d_n_rewalked += blocks re-walked
 void launch_chain_repair(const uint8_t* d_U, const uint64_t* d_out_off, const uint32_t* d_isize, const uint32_t* d_run_of,
@@ -139,14 +141,17 @@ void launch_chain_repair(const uint8_t* d_U, const uint64_t* d_out_off, const ui
 void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_base, void* d_tmp, size_t tmp_bytes,
                        hipStream_t stream);
 size_t count_scan_tmp_bytes(uint32_t n_blocks);
-// compact the tiles that have work: active[] = tile ids, slot_of[t] = index into active or ~0u
-void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t* d_active,
+// compact the tiles that have work: active[] = tile ids, slot_of[t] = index into active or ~0u;
+// d_n_active[0] = number of active tiles, [1] = how many of them have >= 65536 records
+void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t deep_thr, uint32_t* d_active,
                          uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream);
 
 // ---- K3: decode + accumulate (depth.hip) -------------------------------------------------
+// n_deep: active tiles with >= deep_thr (<= 65536) records, counted by tile_compact; they keep 32-bit LDS counters
+constexpr uint32_t kDeepTileRecords = 65536;
 void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_tile_lo, const uint32_t* d_tile_hi,
-                       const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base, int32_t n_ref,
-                       uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
+                       const uint32_t* d_active, uint32_t n_active, uint32_t n_deep, uint32_t deep_thr, const uint32_t* d_tile_base,
+                       int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
                        hipStream_t stream);
 
 // ---- K7: --fix-mate-overlaps, base mode (mates.hip) ---------------------------------------

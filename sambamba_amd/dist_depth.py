@@ -55,6 +55,9 @@ def region_row(prefix, length, n_reads, n_bases, cov, thresholds, sample, combin
     return row + "\n"
 
 
+MATE_SLACK = 16384     # positions fetched left of a slice so that overlapping mates of its reads are in the run
+
+
 class Unsupported(RuntimeError):
     pass
 
@@ -172,7 +175,7 @@ def run_sharded(a, dist, device, out):
                 keep = lambda r: has_cols[r] or not with_cols or r < with_cols[0] or r > with_cols[-1]
                 pieces = [p for p in pieces if keep(p[0])]
             chunks = [p[3] for p in pieces if p[3]]
-            send_text_to_rank0(chunks, dist, out.write)
+            send_text_to_rank0(chunks, dist, out.write if out is not None else None)
             return
 
         if mode == "region":
@@ -215,8 +218,12 @@ def run_sharded(a, dist, device, out):
         has_cols = [0] * n_ref
         ids, rows = [], []
         win_base = np.cumsum([0] + [L // w for L in d.ref_lengths])
+        # With --fix-mate-overlaps a read that lies past the overlap with its mate is counted differently from an unpaired one
+        # (status `past`, depth.d:717-845), so the mate must be in the run even when it ends before the slice: fetch one
+        # linear-index window more on the left (mates overlap, so the partner starts within one read span of the cut).
+        slack = MATE_SLACK if a.fix_mate_overlaps else 0
         for ref, beg, end in mine:
-            d.run_interval(ref, beg, end)
+            d.run_interval(ref, max(0, beg - slack), end)
             fc = first_column_in(d, ref, beg, end)
             if fc is not None:
                 has_cols[ref] = 1

@@ -80,6 +80,49 @@ def test_counters_min_base_quality(synth_small, min_bq):
         assert np.array_equal(cov.astype(bool), want0.sum(axis=(1, 2)) > 0)
 
 
+@pytest.mark.parametrize("min_bq", [0, 20])
+def test_deep_tiles_keep_32_bit_counters(synth_small, synth_multisample, min_bq, monkeypatch):
+    """K3 accumulates tiles with fewer than 2^16 records in 16-bit LDS counters and leaves the others to the 32-bit
+    kernel; the hook lowers the limit so that ordinary tiles (30x: ~230 records) are split between the two."""
+    import sambamba_amd
+    for bam, ns in ((synth_small, 1), (synth_multisample, 3)):
+        for thr in ("1", "150"):
+            monkeypatch.setenv("SBX_DEEP_TILE_RECORDS", thr)
+            with sambamba_amd.Depth(bam) as d:
+                d.set_params(min_bq=min_bq)
+                d.run()
+                got, cov = d.base_counters(0, 0, 90000, with_covered=True)
+                want = oracle_base_counters(bam, 0, 0, 90000, n_samples=ns, min_bq=min_bq)
+                assert np.array_equal(got, want), (bam, thr)
+                want0 = oracle_base_counters(bam, 0, 0, 90000, n_samples=ns, min_bq=0)
+                assert np.array_equal(cov.astype(bool), want0.sum(axis=(1, 2)) > 0)
+
+
+@pytest.mark.parametrize("read_len", [36, 161, 250])
+def test_read_lengths_around_the_fast_path_limit(tmp_path, read_len):
+    """The fast path of K3 takes single-run reads with up to 160 bases inside the tile; longer runs go one read at a time."""
+    import sambamba_amd
+    bam = gen_bam(str(tmp_path / "rl.bam"), "c1:120000", coverage=25, seed=17,
+                  extra=["--read-len", str(read_len), "--insert-mean", str(2 * read_len + 50), "--insert-sd", "20"])
+    for min_bq in (0, 15):
+        with sambamba_amd.Depth(bam) as d:
+            d.set_params(min_bq=min_bq)
+            d.run()
+            got = d.base_counters(0, 0, 120000)
+            want = oracle_base_counters(bam, 0, 0, 120000, min_bq=min_bq)
+            assert np.array_equal(got, want), (read_len, min_bq)
+
+
+def test_multisample_min_base_quality(synth_multisample):
+    import sambamba_amd
+    with sambamba_amd.Depth(synth_multisample) as d:
+        d.set_params(min_bq=17)
+        d.run()
+        got = d.base_counters(1, 0, d.ref_lengths[1])
+        want = oracle_base_counters(synth_multisample, 1, 0, d.ref_lengths[1], n_samples=3, min_bq=17)
+        assert np.array_equal(got, want)
+
+
 def test_cli_text_matches_oracle_synthetic(synth_small):
     for args in (["base"], ["base", "-c", "0", "-L", "chrB:1000-3000"], ["base", "-q", "20", "-a", "-c", "25"],
                  ["base", "-F", "mapping_quality >= 0"]):

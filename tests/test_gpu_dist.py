@@ -29,7 +29,9 @@ def run_sharded(args, world, port, first=b"# "):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "sambamba_amd.dist_depth"] + args
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    err = r.stderr.decode()
+    own = [ln for ln in err.splitlines() if "sambamba-depth" in ln or "Error" in ln or "error" in ln]
+    assert r.returncode == 0, "\n".join(own[:30]) + "\n...\n" + err[-600:]
     # gloo announces its connections on stdout while the process group comes up (the ranks' lines interleave);
     # rank 0 prints afterwards, starting with the "# chrom ..." header
     at = r.stdout.find(first)

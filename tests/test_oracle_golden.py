@@ -41,3 +41,18 @@ def test_oracle_requires_regions_in_region_mode(oracle_bin, golden_dir):
     r = subprocess.run([oracle_bin, "region", "issue225.bam"], cwd=golden_dir, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE)
     assert r.returncode == 1
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(min_bq=20), dict(fix_mate=True, min_bq=13)])
+def test_oracle_counters_fetched_through_the_index_equal_the_whole_file_pass(tmp_path, opts):
+    """bench.py samples windows of the full-size run with the indexed variant: inside the window it must give exactly what
+    the pass over the whole file gives (every read covering a position of the window overlaps the fetched region)."""
+    import numpy as np
+    from tests.util import gen_bam, oracle_base_counters
+    bam = gen_bam(str(tmp_path / "ix.bam"), "cA:90000,cB:70000", coverage=25, seed=23,
+                  extra=["--insert-mean", "260", "--insert-sd", "40", "--tie-free-overlaps"])
+    for ref, name, beg, end in ((0, "cA", 20000, 31000), (1, "cB", 0, 5000), (1, "cB", 66000, 70000)):
+        whole = oracle_base_counters(bam, ref, beg, end, **opts)
+        fetched = oracle_base_counters(bam, ref, beg, end, ref_name=name, **opts)
+        assert whole.sum() > 0
+        assert np.array_equal(whole, fetched), (name, beg, end)

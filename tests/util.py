@@ -48,17 +48,25 @@ def oracle_lib():
         _olib = C.CDLL(ORACLE_LIB)
         _olib.orc_base_counters.argtypes = [C.c_char_p, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                             C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+        _olib.orc_base_counters_indexed.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
+                                                    C.c_char_p, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
         _olib.orc_inflate_all.argtypes = [C.c_char_p, C.c_void_p, C.c_ulonglong]
         _olib.orc_inflate_all.restype = C.c_longlong
     return _olib
 
 
-def oracle_base_counters(bam, ref_id, beg, end, n_samples=1, min_bq=0, fix_mate=False, combined=False, flt=None):
+def oracle_base_counters(bam, ref_id, beg, end, n_samples=1, min_bq=0, fix_mate=False, combined=False, flt=None, ref_name=None):
+    """Counters of [beg, end) from the oracle's literal column pipeline; with `ref_name` the reads are fetched through the
+    BAI (`-L name:beg+1-end`) instead of a pass over the whole file."""
     L = oracle_lib()
     out = np.zeros((end - beg, n_samples, 7), dtype=np.uint32)
     err = C.create_string_buffer(512)
-    rc = L.orc_base_counters(bam.encode(), ref_id, beg, end, min_bq, int(fix_mate), int(combined),
-                             flt.encode() if flt else None, n_samples, out.ctypes.data, err, 512)
+    if ref_name is not None:
+        rc = L.orc_base_counters_indexed(bam.encode(), ref_name.encode(), ref_id, beg, end, min_bq, int(fix_mate), int(combined),
+                                         flt.encode() if flt else None, n_samples, out.ctypes.data, err, 512)
+    else:
+        rc = L.orc_base_counters(bam.encode(), ref_id, beg, end, min_bq, int(fix_mate), int(combined),
+                                 flt.encode() if flt else None, n_samples, out.ctypes.data, err, 512)
     if rc != 0:
         raise RuntimeError("oracle failed: " + err.value.decode())
     return out
