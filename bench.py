@@ -498,19 +498,17 @@ def main():
 
 
 PMC_KERNELS = {"huffman_decode": ["k_huffman_decode"], "lz77_resolve": ["k_lz77_resolve"],
-               "record_index": ["k_index_blocks", "k_tile_compact", "k_chain_repair", "k_block_walk", "k_chain_check", "k_count_scan", "k_describe"],
-               "decode_accumulate": ["k_accumulate"]}
+               "record_index": ["k_walk_blocks", "k_check_scan", "k_describe_blocks", "k_tile_compact", "k_chain_repair", "k_rewalk_mismatched"],
+               "decode_accumulate": ["k_accumulate16", "k_accumulate"]}
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same workload
     (tools/profile_round.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, KiB).
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is."""
-    for rnd in ("round2", "round1"):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_fetch_write_chr1_30x.csv")
-        if os.path.exists(path):
-            break
-    else:
+    rnd = "round2"
+    path = os.path.join(ROOT, "profiles", rnd, "pmc_fetch_write_chr1_30x.csv")
+    if not os.path.exists(path):
         return {}
     fetch = write = 0.0
     best = {}

@@ -97,6 +97,9 @@ extern (C) nothrow @nogc {
     int sbx_depth_window_stats(sbx_ctx*, uint ref_id, ulong first_win, ulong n_win, sbx_region_stats*, uint* cov_counts);
     int sbx_format_base_rows(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
                              char* out_buf, size_t cap, size_t* out_len);
+    alias sbx_write_fn = int function(void* user, const(char)* data, size_t n);
+    int sbx_stream_base_rows(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
+                             sbx_write_fn write, void* user);
     int sbx_last_run_stats(sbx_ctx*, sbx_run_stats*);
     int sbx_next_active_range(sbx_ctx*, uint ref_id, ulong from, ulong* beg, ulong* end);
     int sbx_tile_info(sbx_ctx*, uint* tile_pos, uint* n_samples);
@@ -187,7 +190,6 @@ bool sbxDepthRun(sbx_ctx* ctx, ref const SbxDepthOptions o, File output) {
     auto r_cov = new uint[o.raw_bed.length * S * n_thr];
     auto r_seen = new ubyte[o.raw_bed.length];
     bool seen_columns = false;       // window mode: nothing is printed before the first pileup column (SURVEY App. B-12)
-    char[] text;
 
     foreach (b; plan) {
         if (plan.length == 1) sbxEnforce(ctx, sbx_run(ctx));
@@ -199,22 +201,14 @@ bool sbxDepthRun(sbx_ctx* ctx, ref const SbxDepthOptions o, File output) {
             final switch (o.mode) {
             case SBX_MODE_BASE:
                 // rows of [p, q) formatted on the device; with -c > 0 only active stretches can hold rows
+                // (sbx_stream_base_rows hands the text over piece by piece from pinned buffers while the device formats
+                // and copies the next piece; sbx_format_base_rows into a caller buffer is the synchronous form)
                 void emit(ulong p, ulong q) {
-                    enum ulong CH = 8u << 20;
-                    for (; p < q; p += CH) {
-                        const ulong e = min(q, p + CH);
-                        size_t need;
-                        if (text.length < (e - p) * 40) text.length = cast(size_t)((e - p) * 40);
-                        int rc = sbx_format_base_rows(ctx, r, cast(uint) p, cast(uint) e, o.min_cov, o.max_cov, o.annotate ? 1 : 0,
-                                                      text.ptr, text.length, &need);
-                        if (rc == SBX_ENOMEM && need > text.length) {
-                            text.length = need;
-                            rc = sbx_format_base_rows(ctx, r, cast(uint) p, cast(uint) e, o.min_cov, o.max_cov, o.annotate ? 1 : 0,
-                                                      text.ptr, text.length, &need);
-                        }
-                        sbxEnforce(ctx, rc);
-                        output.rawWrite(text[0 .. need]);
+                    static extern (C) int sink(void* user, const(char)* data, size_t n) {
+                        try { (cast(File*) user).rawWrite(data[0 .. n]); return 0; } catch (Exception) { return 1; }
                     }
+                    sbxEnforce(ctx, sbx_stream_base_rows(ctx, r, cast(uint) p, cast(uint) q, o.min_cov, o.max_cov, o.annotate ? 1 : 0,
+                                                         &sink, &output));
                 }
                 if (o.merged_bed.length) {
                     foreach (g; o.merged_bed) if (g.ref_id == r) emit(g.start, g.end);     // outputRequired, depth.d:558-565

@@ -253,6 +253,14 @@ int sbx_depth_window_stats(sbx_ctx*, uint32_t ref_id, uint64_t first_win, uint64
 int sbx_format_base_rows(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov,
                          int annotate, char* out, size_t cap, size_t* out_len);
 
+/* The same rows handed to a writer piece by piece, in output order.  The device formats the next piece while the
+ * previous one travels to pinned host memory and the writer consumes the one before; `write` returns 0 on success
+ * (anything else aborts with SBX_EIO).  `data` is only valid during the call.  Replaces the per-column
+ * output.write(...) calls of writeColumn / writeEmptyColumns (depth.d:452-487,534-555) for a whole interval. */
+typedef int (*sbx_write_fn)(void* user, const char* data, size_t n);
+int sbx_stream_base_rows(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov,
+                         int annotate, sbx_write_fn write, void* user);
+
 /* Timing / accounting of the last sbx_run() (for bench.py): per-kernel milliseconds measured
  * with HIP events on the engine's stream, record counts, byte counts. */
 typedef struct {

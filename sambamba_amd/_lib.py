@@ -73,12 +73,14 @@ ENOMEM = -8
 class Batch(C.Structure):
     _fields_ = [("first_ref", C.c_uint32), ("n_refs", C.c_uint32), ("est_bytes", C.c_uint64)]
 
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_char), C.c_size_t)
+
 EXPORTS = [
     "sbx_abi_sizeof", "sbx_run_interval", "sbx_parse_regions", "sbx_parsed_regions", "sbx_parsed_region_line", "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
     "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_regex_search", "sbx_set_params",
     "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_region_stats_from",
     "sbx_depth_window_stats",
-    "sbx_format_base_rows", "sbx_plan_batches", "sbx_run_batch", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
+    "sbx_format_base_rows", "sbx_stream_base_rows", "sbx_plan_batches", "sbx_run_batch", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
 ]
 
 _lib = None
@@ -131,6 +133,7 @@ def lib():
     L.sbx_depth_window_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     L.sbx_format_base_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_int,
                                        C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sbx_stream_base_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_int, WRITE_FN, C.c_void_p]
     L.sbx_plan_batches.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sbx_run_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.sbx_last_run_stats.argtypes = [C.c_void_p, C.POINTER(RunStats)]
@@ -319,6 +322,17 @@ class Depth:
             self._check(rc)
             return buf.raw[:need.value]
         self._check(rc)
+
+    def stream_base_rows(self, ref_id, beg, end, write, min_cov=1.0, max_cov=float("inf"), annotate=False):
+        """sbx_stream_base_rows: `write(bytes)` is called with consecutive pieces of the text of [beg, end)."""
+        def cb(_user, data, n):
+            try:
+                write(C.string_at(data, n))
+                return 0
+            except Exception:       # the library turns it into SBX_EIO
+                return 1
+        fn = WRITE_FN(cb)
+        self._check(self._L.sbx_stream_base_rows(self._ctx, ref_id, beg, end, float(min_cov), float(max_cov), int(annotate), fn, None))
 
     def base_counters(self, ref_id, beg, end, with_covered=False):
         S = self.n_samples_eff

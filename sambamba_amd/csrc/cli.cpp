@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -198,24 +199,13 @@ public:
         return !bed_provided_ || o_.min_cov > 0;
     }
     void run_device(int r0, int r1) {
-        std::vector<char> text;
-        const uint64_t CH = 8u << 20;      // positions per call (~300 MB of text at one sample)
+        // the library formats on the device and hands the text over piece by piece (pinned buffers, the next piece is
+        // formatted and copied while this one is written)
         auto range = [&](uint32_t r, uint64_t b, uint64_t e) {
-            for (uint64_t p = b; p < e; p += CH) {
-                const uint64_t q = std::min(e, p + CH);
-                size_t need = 0;
-                if (text.size() < (size_t)(q - p) * 40) text.resize((size_t)(q - p) * 40);
-                int rc = sbx_format_base_rows(c_, r, (uint32_t)p, (uint32_t)q, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
-                                              text.data(), text.size(), &need);
-                if (rc == SBX_ENOMEM && need > text.size()) {
-                    text.resize(need);
-                    rc = sbx_format_base_rows(c_, r, (uint32_t)p, (uint32_t)q, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
-                                              text.data(), text.size(), &need);
-                }
-                check(c_, rc);
-                out_.flush();
-                fwrite(text.data(), 1, need, out_.fp);
-            }
+            out_.flush();
+            check(c_, sbx_stream_base_rows(c_, r, (uint32_t)b, (uint32_t)e, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
+                                           [](void* u, const char* d, size_t n) -> int { return fwrite(d, 1, n, (FILE*)u) == n ? 0 : 1; },
+                                           out_.fp));
         };
         if (bed_provided_) {      // merged, sorted regions
             for (auto& g : bed_)
@@ -757,8 +747,13 @@ int depth_main(int argc, char** argv) {
         } else if (o.mode == "window") {
             print_bed_header(out, o, 3);   // PerWindowPrinter.init (depth.d:1036)
         }
+        const bool timing = getenv("SBX_TIMING") != nullptr;      // phase wall clock on stderr (profiles/, tools/cli_e2e.sh)
+        auto now = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+        const double t_start = now();
         ctx = sbx_open(paths.data(), (int)paths.size(), -1, ebuf, sizeof ebuf);
         if (!ctx) throw Fail{ebuf};
+        const double t_open = now();
+        double t_run = 0, t_print = 0;
         sbx_header_info hi;
         check(ctx, sbx_header(ctx, &hi));
         if (!hi.sorted_by_coordinate) throw Fail{"All files must be coordinate-sorted"};
@@ -818,20 +813,34 @@ int depth_main(int argc, char** argv) {
         WindowPrinter wp{ctx, o, out, samples, false, 0, 0, -1, 0, {}, {}, {}};
         RegionPrinter rp{ctx, o, out, samples, raw, raw_lines, {}, {}, {}};
         for (auto& b : plan) {
+            const double t0 = now();
             if (plan.size() == 1) check(ctx, sbx_run(ctx));
             else check(ctx, sbx_run_batch(ctx, b.first_ref, b.n_refs));
+            const double t1 = now();
             const int r0 = (int)b.first_ref, r1 = (int)(b.first_ref + b.n_refs);
             // "Processing reference #N (name)" lines go to stderr in the reference (depth.d:1225-1229)
             if (o.mode == "region") rp.run_refs(r0, r1);
             else if (o.mode == "window") wp.run_refs(r0, r1);
             else bp.run_refs(r0, r1);
+            t_run += t1 - t0;
+            t_print += now() - t1;
+            if (timing) {
+                sbx_run_stats st;
+                if (sbx_last_run_stats(ctx, &st) == SBX_OK)
+                    fprintf(stderr, "[sbx-depth] batch refs [%d,%d): run %.3f s (h2d %.1f ms, device %.1f ms: inflate %.1f index %.1f accumulate %.1f), %llu records\n",
+                            r0, r1, t1 - t0, st.ms_h2d, st.ms_total, st.ms_inflate, st.ms_index, st.ms_accumulate, (unsigned long long)st.n_records);
+            }
         }
         if (o.mode == "region") rp.finish();
         else if (o.mode == "window") wp.finish();
         else if (o.mode == "base") bp.finish();
         out.flush();
         if (out.fp != stdout) fclose(out.fp);
+        const double t_out = now();
         sbx_close(ctx);
+        if (timing)
+            fprintf(stderr, "[sbx-depth] open %.3f s, run %.3f s, print %.3f s, finish %.3f s, close %.3f s, total %.3f s since main\n", t_open - t_start,
+                    t_run, t_print, t_out - t_open - t_run - t_print, now() - t_out, now() - t_start);
         return 0;
     } catch (const Fail& f) {
         out.flush();

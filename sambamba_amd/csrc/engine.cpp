@@ -105,6 +105,13 @@ struct sbx_ctx {
     DevBuf<uint32_t> d_comp_len, d_isize, d_run_of, d_status;
     DevBuf<ChainRun> d_runs;
     // pinned staging for host -> device copies of file bytes
+    // sbx_stream_base_rows: two pieces of text in flight (device buffer, pinned host buffer, events)
+    DevBuf<uint8_t> d_fmt_text2[2];
+    uint8_t* text_host[2] = {nullptr, nullptr};
+    size_t text_host_cap[2] = {0, 0};
+    hipEvent_t text_ev_fmt[2] = {nullptr, nullptr}, text_ev_copy[2] = {nullptr, nullptr};
+    std::string h_fmt_blob;
+    std::vector<uint32_t> h_fmt_soff;
     uint8_t* stage[2] = {nullptr, nullptr};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     hipEvent_t upload_done = nullptr;
@@ -158,6 +165,9 @@ struct sbx_ctx {
 
     ~sbx_ctx() {
         for (int i = 0; i < 2; ++i) {
+            if (text_host[i]) (void)hipHostFree(text_host[i]);
+            if (text_ev_fmt[i]) (void)hipEventDestroy(text_ev_fmt[i]);
+            if (text_ev_copy[i]) (void)hipEventDestroy(text_ev_copy[i]);
             if (stage[i]) (void)hipHostFree(stage[i]);
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
         }
@@ -501,15 +511,24 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
     std::unique_ptr<sbx_ctx> c(new sbx_ctx());
     try {
         if (n_bams < 1 || !bam_paths || !bam_paths[0]) throw Error(SBX_EINVAL, "no input files");
+        const bool timing = getenv("SBX_TIMING") != nullptr;
+        auto now = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+        const double t0 = now();
         require_device(device);
         SBX_HIP(hipGetDevice(&c->device));
         SBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SBX_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        const double t1 = now();
         c->file.open(bam_paths[0]);
         c->blocks = scan_bgzf(c->file.data, c->file.size);
+        const double t2 = now();
         c->has_index = load_bai(c->file.path, &c->bai);
         default_filter(&c->filter);
+        const double t3 = now();
         parse_header_on_device(c.get());
+        if (timing)
+            fprintf(stderr, "[sbx] open %s: device %.3f s, BGZF scan of %zu blocks %.3f s, BAI %.3f s, header %.3f s\n", bam_paths[0], t1 - t0,
+                    c->blocks.size(), t2 - t1, t3 - t2, now() - t3);
         // further files: MultiBamReader semantics that matter for depth -- identical reference dictionaries
         // (the reference merges compatible ones, multireader.d:174-215; anything else is rejected here), samples =
         // union of the @RG SM values in order of first appearance (depth.d:1170-1181 over the merged header), every
@@ -928,15 +947,45 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         if (force && attempt == 0 && !entries_given) { const uint32_t f = (uint32_t)atoi(force); if (f < first_bad && f < nb) { first_bad = f; forced = true; } }
         if (dbg) fprintf(stderr, "[sbx]   index attempt %d: records=%llu first_bad=%u overflow=%u cap=%llu\n", attempt,
                          (unsigned long long)n_records, first_bad, R.flags[2], (unsigned long long)c->desc_cap);
+        if (dbg && first_bad != 0xFFFFFFFFu && first_bad < nb) {
+            const uint32_t b0 = first_bad >= 2 ? first_bad - 2 : 0, b1 = std::min<uint32_t>(nb, first_bad + 3);
+            std::vector<uint64_t> he(b1 - b0), hx(b1 - b0);
+            std::vector<uint32_t> hc(b1 - b0);
+            SBX_HIP(hipMemcpy(he.data(), c->d_entry.p + b0, (b1 - b0) * 8ull, hipMemcpyDeviceToHost));
+            SBX_HIP(hipMemcpy(hx.data(), c->d_exit.p + b0, (b1 - b0) * 8ull, hipMemcpyDeviceToHost));
+            SBX_HIP(hipMemcpy(hc.data(), c->d_count.p + b0, (b1 - b0) * 4ull, hipMemcpyDeviceToHost));
+            for (uint32_t b = b0; b < b1; ++b)
+                fprintf(stderr, "[sbx]     block %u: out_off=%llu isize=%u entry=%lld exit=%lld count=%u\n", b, (unsigned long long)w.out_off[b], w.isize[b],
+                        (long long)he[b - b0], (long long)hx[b - b0], hc[b - b0]);
+        }
         if (first_bad != 0xFFFFFFFFu && first_bad < nb) {
             // a guessed entry was wrong (or a block holds no record start): follow the chain serially from there and
             // launch again with the entries given; a chain that is still inconsistent then is a corrupt file
             if (entries_given && !forced) throw Error(SBX_EFORMAT, "BAM record chain is broken (truncated or corrupt record)");
-            launch_chain_repair(c->d_U.p, c->d_out_off.p, c->d_isize.p, c->d_run_of.p, c->d_runs.p, nb, first_bad, c->d_entry.p, c->d_exit.p,
-                                c->d_count.p, c->d_flag.p + 4, s);
-            SBX_HIP(hipMemcpyAsync(&R.n_rewalked, c->d_flag.p + 4, 4, hipMemcpyDeviceToHost, s));
-            SBX_HIP(hipStreamSynchronize(s));
-            n_rewalked += R.n_rewalked;
+            // Wrong guesses are isolated, so they are repaired in parallel first: every block that is not entered where
+            // its predecessor was left is walked again from there, round after round until nothing changes.  What is
+            // left after a few rounds (a long stretch of blocks without record starts, a corrupt file) -- and the test
+            // hook -- goes to the serial repair, which follows the chain from the first inconsistent block on.
+            bool settled = false;
+            if (!forced) {
+                for (int round = 0; round < 8 && !settled; ++round) {
+                    SBX_HIP(hipMemsetAsync(c->d_flag.p + 4, 0, 4, s));
+                    launch_rewalk_mismatched(a, c->d_flag.p + 4, s);
+                    SBX_HIP(hipMemcpyAsync(&R.n_rewalked, c->d_flag.p + 4, 4, hipMemcpyDeviceToHost, s));
+                    SBX_HIP(hipStreamSynchronize(s));
+                    n_rewalked += R.n_rewalked;
+                    settled = R.n_rewalked == 0 && round > 0;
+                    if (R.n_rewalked == 0) break;
+                }
+            }
+            if (!settled) {
+                SBX_HIP(hipMemsetAsync(c->d_flag.p + 4, 0, 4, s));
+                launch_chain_repair(c->d_U.p, c->d_out_off.p, c->d_isize.p, c->d_run_of.p, c->d_runs.p, nb, first_bad, c->d_entry.p, c->d_exit.p,
+                                    c->d_count.p, c->d_flag.p + 4, s);
+                SBX_HIP(hipMemcpyAsync(&R.n_rewalked, c->d_flag.p + 4, 4, hipMemcpyDeviceToHost, s));
+                SBX_HIP(hipStreamSynchronize(s));
+                n_rewalked += R.n_rewalked;
+            }
             entries_given = true;
             continue;
         }
@@ -1472,61 +1521,80 @@ int sbx_depth_window_stats(sbx_ctx* c, uint32_t ref_id, uint64_t first_win, uint
     });
 }
 // K6: the text of `depth base` for [beg, end) of ref_id, formatted on the device (format.hip).
+// FormatArgs of a `depth base` run for rows of ref_id (the names blob travels on the stream first); beg / end are set by the caller
+static FormatArgs format_args(sbx_ctx* c, uint32_t ref_id, double min_cov, double max_cov, int annotate, hipStream_t s) {
+    const uint32_t S = c->n_samples_eff;
+    // names blob: contig name, then the sample names ("*" when the header has no read groups, as the CLI prints)
+    c->h_fmt_blob = c->hdr.refs[ref_id].name;
+    c->h_fmt_soff.clear();
+    for (uint32_t i = 0; i < S; ++i) {
+        c->h_fmt_soff.push_back((uint32_t)c->h_fmt_blob.size());
+        if (!c->combined && i < c->hdr.sample_names.size()) c->h_fmt_blob += c->hdr.sample_names[i];
+    }
+    c->h_fmt_soff.push_back((uint32_t)c->h_fmt_blob.size());
+    c->d_fmt_names.ensure(c->h_fmt_blob.size() + 1);
+    c->d_fmt_soff.ensure(c->h_fmt_soff.size());
+    SBX_HIP(hipMemcpyAsync(c->d_fmt_names.p, c->h_fmt_blob.data(), c->h_fmt_blob.size(), hipMemcpyHostToDevice, s));
+    SBX_HIP(hipMemcpyAsync(c->d_fmt_soff.p, c->h_fmt_soff.data(), c->h_fmt_soff.size() * 4, hipMemcpyHostToDevice, s));
+    SBX_HIP(hipStreamSynchronize(s));         // (the host copies may be reused by the next call)
+    FormatArgs a{};
+    a.counters = c->d_counters.p;
+    a.span = c->span_valid ? c->d_span.p : nullptr;
+    a.slot_of = c->d_slot_of.p;
+    a.tile_first = c->h_tile_base[ref_id];
+    a.tile_end = c->h_tile_base[ref_id + 1];
+    a.T = c->tile_pos;
+    a.S = S;
+    // COV is an integer: the reference's double comparisons (depth.d:538) become integer bounds
+    if (!(max_cov >= 0) || !(min_cov <= max_cov)) { a.lo = 1; a.hi = 0; }
+    else {
+        a.lo = min_cov <= 0 ? 0 : (min_cov >= 1.8e19 ? ~0ull : (uint64_t)std::ceil(min_cov));
+        a.hi = max_cov >= 1.8e19 ? ~0ull : (uint64_t)std::floor(max_cov);
+    }
+    a.annotate = annotate ? 1u : 0u;
+    a.combined = c->combined ? 1u : 0u;
+    a.zero_fill = min_cov <= 0 ? 1u : 0u;
+    a.names = c->d_fmt_names.p;
+    a.ref_name_len = (uint32_t)c->hdr.refs[ref_id].name.size();
+    a.sample_off = c->d_fmt_soff.p;
+    return a;
+}
+
+// measure the rows of [a.beg, a.end): chunk offsets on the device, total bytes on the host (one synchronisation)
+static uint64_t format_measure(sbx_ctx* c, const FormatArgs& a, uint32_t* n_chunks_out, hipStream_t s) {
+    const uint32_t per = format_chunk_positions();
+    const uint32_t n_chunks = (uint32_t)(((uint64_t)(a.end - a.beg) + per - 1) / per);
+    c->d_fmt_len.ensure(n_chunks);
+    c->d_fmt_off.ensure((size_t)n_chunks + 1);
+    launch_format_measure(a, n_chunks, c->d_fmt_len.p, s);
+    launch_count_scan(c->d_fmt_len.p, n_chunks, c->d_fmt_off.p, nullptr, 0, s);
+    if (!c->res) SBX_HIP(hipHostMalloc((void**)&c->res, sizeof(HostResults), hipHostMallocDefault));
+    SBX_HIP(hipMemcpyAsync(&c->res->last_state, c->d_fmt_off.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
+    SBX_HIP(hipStreamSynchronize(s));
+    *n_chunks_out = n_chunks;
+    return c->res->last_state;
+}
+
+static void check_base_run(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, const char* who) {
+    if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
+    if (c->mode != SBX_MODE_BASE) throw Error(SBX_EINVAL, std::string(who) + " needs a `depth base` run");
+    if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
+}
+
 int sbx_format_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov, int annotate,
                          char* out, size_t cap, size_t* out_len) {
     return guarded(c, [&] {
         if (!c || !out_len) throw Error(SBX_EINVAL, "null argument");
-        if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
-        if (c->mode != SBX_MODE_BASE) throw Error(SBX_EINVAL, "sbx_format_base_rows needs a `depth base` run");
-        if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
+        check_base_run(c, ref_id, beg, end, "sbx_format_base_rows");
         SBX_HIP(hipSetDevice(c->device));
         hipStream_t s = c->stream;
         *out_len = 0;
         if (beg == end) return;
-        const uint32_t S = c->n_samples_eff;
-        // names blob: contig name, then the sample names ("*" when the header has no read groups, as the CLI prints)
-        std::string blob = c->hdr.refs[ref_id].name;
-        std::vector<uint32_t> soff;
-        for (uint32_t i = 0; i < S; ++i) {
-            soff.push_back((uint32_t)blob.size());
-            if (!c->combined && i < c->hdr.sample_names.size()) blob += c->hdr.sample_names[i];
-        }
-        soff.push_back((uint32_t)blob.size());
-        c->d_fmt_names.ensure(blob.size() + 1);
-        c->d_fmt_soff.ensure(soff.size());
-        SBX_HIP(hipMemcpyAsync(c->d_fmt_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
-        SBX_HIP(hipMemcpyAsync(c->d_fmt_soff.p, soff.data(), soff.size() * 4, hipMemcpyHostToDevice, s));
-        FormatArgs a{};
-        a.counters = c->d_counters.p;
-        a.span = c->span_valid ? c->d_span.p : nullptr;
-        a.slot_of = c->d_slot_of.p;
-        a.tile_first = c->h_tile_base[ref_id];
-        a.tile_end = c->h_tile_base[ref_id + 1];
-        a.T = c->tile_pos;
-        a.S = S;
+        FormatArgs a = format_args(c, ref_id, min_cov, max_cov, annotate, s);
         a.beg = beg;
         a.end = end;
-        // COV is an integer: the reference's double comparisons (depth.d:538) become integer bounds
-        if (!(max_cov >= 0) || !(min_cov <= max_cov)) { a.lo = 1; a.hi = 0; }
-        else {
-            a.lo = min_cov <= 0 ? 0 : (min_cov >= 1.8e19 ? ~0ull : (uint64_t)std::ceil(min_cov));
-            a.hi = max_cov >= 1.8e19 ? ~0ull : (uint64_t)std::floor(max_cov);
-        }
-        a.annotate = annotate ? 1u : 0u;
-        a.combined = c->combined ? 1u : 0u;
-        a.zero_fill = min_cov <= 0 ? 1u : 0u;
-        a.names = c->d_fmt_names.p;
-        a.ref_name_len = (uint32_t)c->hdr.refs[ref_id].name.size();
-        a.sample_off = c->d_fmt_soff.p;
-        const uint32_t per = format_chunk_positions();
-        const uint32_t n_chunks = (uint32_t)(((uint64_t)(end - beg) + per - 1) / per);
-        c->d_fmt_len.ensure(n_chunks);
-        c->d_fmt_off.ensure((size_t)n_chunks + 1);
-        launch_format_measure(a, n_chunks, c->d_fmt_len.p, s);
-        launch_count_scan(c->d_fmt_len.p, n_chunks, c->d_fmt_off.p, nullptr, 0, s);
-        uint64_t total = 0;
-        SBX_HIP(hipMemcpyAsync(&total, c->d_fmt_off.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
-        SBX_HIP(hipStreamSynchronize(s));
+        uint32_t n_chunks = 0;
+        const uint64_t total = format_measure(c, a, &n_chunks, s);
         *out_len = (size_t)total;
         if (total > cap || (!out && total)) throw Error(SBX_ENOMEM, "output buffer too small for the formatted rows");
         if (!total) return;
@@ -1534,6 +1602,71 @@ int sbx_format_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end
         launch_format_write(a, n_chunks, c->d_fmt_off.p, c->d_fmt_text.p, s);
         SBX_HIP(hipMemcpyAsync(out, c->d_fmt_text.p, (size_t)total, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// The same text handed to a writer piece by piece, in order: the device formats piece k + 1 while piece k travels to a
+// pinned host buffer on the copy stream and the writer consumes piece k - 1 -- the D side passes the delegate that
+// wraps its output File (sambamba/depth.d:1233-1234 flushes one in the reference).
+int sbx_stream_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov, int annotate,
+                         sbx_write_fn write, void* user) {
+    return guarded(c, [&] {
+        if (!c || !write) throw Error(SBX_EINVAL, "null argument");
+        check_base_run(c, ref_id, beg, end, "sbx_stream_base_rows");
+        if (beg == end) return;
+        SBX_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        FormatArgs a = format_args(c, ref_id, min_cov, max_cov, annotate, s);
+        uint64_t piece = 4u << 20;                // positions per piece (~110 MB of text at one sample, 30x)
+        if (const char* e = getenv("SBX_STREAM_PIECE")) { const long v = atol(e); if (v >= 256) piece = (uint64_t)v; }      // (tests)
+        for (int i = 0; i < 2; ++i) {
+            if (!c->text_ev_fmt[i]) SBX_HIP(hipEventCreateWithFlags(&c->text_ev_fmt[i], hipEventDisableTiming));
+            if (!c->text_ev_copy[i]) SBX_HIP(hipEventCreateWithFlags(&c->text_ev_copy[i], hipEventDisableTiming));
+        }
+        size_t pending_len[2] = {0, 0};
+        bool pending[2] = {false, false};
+        auto drain = [&](int i) {
+            if (!pending[i]) return;
+            SBX_HIP(hipEventSynchronize(c->text_ev_copy[i]));
+            pending[i] = false;
+            if (pending_len[i] && write(user, (const char*)c->text_host[i], pending_len[i]) != 0)
+                throw Error(SBX_EIO, "the output writer reported an error");
+        };
+        int k = 0;
+        try {
+        for (uint64_t p = beg; p < end; p += piece, k ^= 1) {
+            a.beg = (uint32_t)p;
+            a.end = (uint32_t)std::min<uint64_t>(end, p + piece);
+            uint32_t n_chunks = 0;
+            const uint64_t total = format_measure(c, a, &n_chunks, s);       // (synchronises the compute stream only)
+            drain(k);                                                          // buffer k is free again once its piece is written
+            if (total) {
+                c->d_fmt_text2[k].ensure((size_t)total + 64);
+                if (c->text_host_cap[k] < total) {
+                    if (c->text_host[k]) SBX_HIP(hipHostFree(c->text_host[k]));
+                    c->text_host[k] = nullptr;
+                    c->text_host_cap[k] = (size_t)(total + total / 8 + (1u << 20));
+                    SBX_HIP(hipHostMalloc((void**)&c->text_host[k], c->text_host_cap[k], hipHostMallocDefault));
+                }
+                launch_format_write(a, n_chunks, c->d_fmt_off.p, c->d_fmt_text2[k].p, s);
+                SBX_HIP(hipEventRecord(c->text_ev_fmt[k], s));
+                SBX_HIP(hipStreamWaitEvent(c->copy_stream, c->text_ev_fmt[k], 0));
+                SBX_HIP(hipMemcpyAsync(c->text_host[k], c->d_fmt_text2[k].p, (size_t)total, hipMemcpyDeviceToHost, c->copy_stream));
+                SBX_HIP(hipEventRecord(c->text_ev_copy[k], c->copy_stream));
+                pending[k] = true;
+                pending_len[k] = (size_t)total;
+                // d_fmt_off / d_fmt_len are reused by the next measure: format_write of this piece must have read them
+                SBX_HIP(hipEventSynchronize(c->text_ev_fmt[k]));
+            }
+            drain(k ^ 1);                                                      // the previous piece: copied while this one was formatted
+        }
+        drain(0);
+        drain(1);
+        } catch (...) {      // leave nothing in flight on the buffers the next call reuses
+            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamSynchronize(s);
+            throw;
+        }
     });
 }
 

@@ -84,10 +84,21 @@ __device__ bool plausible_record(const uint8_t* U, uint64_t limit, uint64_t o, c
     // read name: printable, NUL only at the end
     const uint8_t* name = p + 36;
     if (name[l_name - 1] != 0) return false;
-    if (l_name > 1 && (name[0] < 33 || name[0] > 126)) return false;
+    for (uint32_t k = 0; k + 1 < l_name; ++k)
+        if (name[k] < 33 || name[k] > 126) return false;
+    // CIGAR: known operations whose query-consuming lengths add up to l_seq (SAM 1.4; what every aligner and htslib
+    // write).  A window that starts a byte or two off a true record passes every test above for a few percent of the
+    // positions (the shifted fields stay in range) and, one time in a record length, chains into the true records
+    // behind it -- a dozen decoys per chromosome-sized file without this test, none with it.
     if (n_cigar) {
-        uint32_t op = ld32(name + l_name) & 15u;
-        if (op > 8) return false;
+        const uint8_t* cg = name + l_name;
+        uint64_t qlen = 0;
+        for (uint32_t k = 0; k < n_cigar; ++k) {
+            const uint32_t op = ld32(cg + 4 * k);
+            if ((op & 15u) > 8u) return false;
+            if (cig_type(op) & 1u) qlen += op >> 4;
+        }
+        if (l_seq > 0 && qlen != (uint64_t)l_seq) return false;
     }
     *next = o + 4 + (uint64_t)bs;
     *sort_key_ref = (uint32_t)ref;
@@ -597,21 +608,13 @@ __device__ __forceinline__ uint16_t* rec_list(uint8_t* scratch, uint64_t out_off
     return (uint16_t*)(scratch + inflate_lit_offset(out_off_b, b));
 }
 
-__global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
-    const uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
-    if (b >= a.n_blocks) return;
+// walk block b from entry E (known or guessed), leave its record offsets in the block's list, record entry / exit / count
+__device__ void walk_block_from(const IndexArgs& a, uint32_t b, uint64_t E) {
     const uint64_t beg = a.out_off[b], blk_end = beg + a.isize[b];
     const ChainRun run = a.runs[a.run_of[b]];
     const uint64_t lo = beg > run.u_beg ? beg : run.u_beg, hi0 = blk_end < run.u_end ? blk_end : run.u_end;
     const uint64_t hi = hi0 > lo ? hi0 : lo;
-    const bool first_of_run = b == run.blk_first, last_of_run = b == run.blk_last;
-    uint64_t E = kOffUnknown;
-    if (first_of_run) E = run.u_beg;
-    else if (a.entry_in) E = a.entry_in[b];
-    else {
-        for (uint64_t o = lo; o < hi; ++o)
-            if (plausible_chain(a.U, run.u_end, o, a.refs)) { E = o; break; }
-    }
+    const bool last_of_run = b == run.blk_last;
     uint32_t n = 0;
     uint64_t X = E;
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
@@ -651,7 +654,38 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
     const bool bad_block = E == kOffUnknown || E == kOffInvalid || X == kOffUnknown || X == kOffInvalid || X < E ||
                            (last_of_run && X != run.u_end);
     if (bad_block) atomicMin(a.flags + 0, b);
+}
+
+__global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
+    const uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (b >= a.n_blocks) return;
+    const uint64_t beg = a.out_off[b], blk_end = beg + a.isize[b];
+    const ChainRun run = a.runs[a.run_of[b]];
+    const uint64_t lo = beg > run.u_beg ? beg : run.u_beg, hi0 = blk_end < run.u_end ? blk_end : run.u_end;
+    const uint64_t hi = hi0 > lo ? hi0 : lo;
+    uint64_t E = kOffUnknown;
+    if (b == run.blk_first) E = run.u_beg;
+    else if (a.entry_in) E = a.entry_in[b];
+    else {
+        for (uint64_t o = lo; o < hi; ++o)
+            if (plausible_chain(a.U, run.u_end, o, a.refs)) { E = o; break; }
+    }
+    walk_block_from(a, b, E);
     if (a.inflate_status[b] != 0) atomicMin(a.flags + 1, b);
+}
+
+// Parallel repair of wrong guesses: every block that is not entered where its predecessor was left is walked again
+// from there.  A wrong guess is isolated (its neighbours guessed right), so one round settles it; a block whose new
+// exit disagrees with the next block's entry is caught by the next round.  *n_changed counts the blocks re-walked.
+__global__ __launch_bounds__(kWalkThreads) void k_rewalk_mismatched(IndexArgs a, uint32_t* n_changed) {
+    const uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (b >= a.n_blocks) return;
+    const ChainRun run = a.runs[a.run_of[b]];
+    if (b == run.blk_first) return;
+    const uint64_t want = a.exit_[b - 1];
+    if (want == kOffUnknown || want == kOffInvalid || want == a.entry[b]) return;
+    walk_block_from(a, b, want);
+    atomicAdd(n_changed, 1u);
 }
 
 // ---- 2. chain check + scan of the per-block counts (single workgroup; n_blocks is ~1e5..1e6) ------------------
@@ -824,6 +858,12 @@ void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
     SBX_HIP(hipGetLastError());
     const uint32_t per = kDescThreads / 64;
     hipLaunchKernelGGL(k_describe_blocks, dim3((a.n_blocks + per - 1) / per), dim3(kDescThreads), 0, stream, a);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_rewalk_mismatched(const IndexArgs& a, uint32_t* d_n_changed, hipStream_t stream) {
+    if (!a.n_blocks) return;
+    hipLaunchKernelGGL(k_rewalk_mismatched, dim3((a.n_blocks + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, stream, a, d_n_changed);
     SBX_HIP(hipGetLastError());
 }
 

@@ -73,12 +73,12 @@ __device__ __forceinline__ uint32_t ldu32(const uint8_t* p) { uint32_t v; __buil
 __device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
 // ---- token streams between K1a and K1b -----------------------------------------------------------
-// literal stream of block b: bytes at lit[lit_off(b) ..], 16-byte aligned, capacity >= isize[b] + 33 (K1a notices an
+// literal stream of block b: bytes at lit[lit_off(b) ..], 64-byte aligned, capacity >= isize[b] + 49 (K1a notices an
 // output overrun only at the end of a loop iteration, kLitPerIter literals late at most)
-// entry stream of block b  : u32 at ent[ent_off(b) ..], 16-byte aligned, capacity isize/3 + isize/255 + 7
+// entry stream of block b  : u32 at ent[ent_off(b) ..], 64-byte aligned, capacity >= isize/3 + isize/255 + 11
 // Both offsets are pure functions of (out_off[b], b) so that no extra table is needed.
 __host__ __device__ __forceinline__ uint64_t lit_off(uint64_t out_off_b, uint32_t b) { return inflate_lit_offset(out_off_b, b); }
-__host__ __device__ __forceinline__ uint64_t ent_off(uint64_t out_off_b, uint32_t b) { return (out_off_b / 3 + out_off_b / 255 + 12ull * b + 3ull) & ~3ull; }
+__host__ __device__ __forceinline__ uint64_t ent_off(uint64_t out_off_b, uint32_t b) { return (out_off_b / 3 + out_off_b / 255 + 28ull * b + 15ull) & ~15ull; }
 
 __device__ __forceinline__ uint32_t make_entry(uint32_t lit_run, uint32_t len, uint32_t dist) {
     return (lit_run << 24) | ((dist - 1) << 9) | len;      // len == 0: literal-run-only entry
@@ -304,34 +304,46 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
     return true;
 }
 
-// Token emitter of one lane (K1a).  Scattered 4-byte stores from 64 lanes are 64 partial-line write
-// requests each; the emitter therefore keeps the last 16 literal bytes and the last 4 match entries in
-// registers (byte / dword shift registers) and writes both streams with aligned 16-byte stores only.
-// The stores are DEFERRED: a full 16-byte group is parked in a second register set and written by flush(),
-// which the decode loop calls right after the input-ring service.  gfx9 counts loads and stores in the
-// same in-order vmcnt, so the wait in front of the ring service would otherwise also wait for token stores
-// issued moments before -- a store round trip of stall in every iteration; this way every VMEM operation of
-// an iteration is issued at its top and has a whole iteration to complete.
+// Token emitter of one lane (K1a).  Scattered small stores from 64 lanes are 64 partial-line write requests each, and a
+// line that is completed by eight separate 16-byte stores over ~50 loop iterations does not survive in L2 next to the
+// 230,000 other open lines of the launch: it goes to HBM half-filled, several times (WRITE_SIZE 2.9x the token bytes,
+// profiles/round1).  The emitter therefore keeps the last 16 literal bytes and the last 4 match entries in registers
+// (byte / dword shift registers), parks every completed 16-byte group in a four-deep register FIFO and writes a stream
+// only in aligned 64-BYTE bursts -- four back-to-back 16-byte stores that fill a whole 64-byte sector at once.
+// The stores are DEFERRED: flush(), which the decode loop calls right after the input-ring service, writes the bursts
+// that are full.  gfx9 counts loads and stores in the same in-order vmcnt, so the wait in front of the ring service
+// would otherwise also wait for token stores issued moments before -- a store round trip of stall in every iteration;
+// this way every VMEM operation of an iteration is issued at its top and has a whole iteration to complete.
 struct Emitter {
-    uint8_t* lit;         // 16-byte aligned literal stream of this block
-    uint32_t* ent;        // 16-byte aligned entry stream of this block
-    u32x4 la, ea;
-    u32x4 lp, ep;         // parked groups
-    uint32_t lp_at, ep_at;    // where they go (byte offset / entry index), kNone = nothing parked
+    uint8_t* lit;         // 64-byte aligned literal stream of this block
+    uint32_t* ent;        // 64-byte aligned entry stream of this block
+    u32x4 la, ea;         // group being filled
+    u32x4 l0, l1, l2, l3; // parked literal groups: the newest in l3, the oldest of lq_n in l[4 - lq_n]
+    u32x4 e0, e1, e2, e3;
+    uint32_t lq_n, eq_n;  // parked groups
+    uint32_t lq_at, eq_at;    // byte offset / entry index of the oldest parked group
     uint32_t n_lit, n_ent, run;
-    static constexpr uint32_t kNone = 0xFFFFFFFFu;
     __device__ __forceinline__ static void store16(void* p, u32x4 v) { *(u32x4*)p = v; }
     __device__ __forceinline__ void init(uint8_t* l, uint32_t* e) {
         lit = l; ent = e; n_lit = n_ent = run = 0;
-        la = u32x4{0, 0, 0, 0};
-        ea = u32x4{0, 0, 0, 0};
-        lp = u32x4{0, 0, 0, 0};
-        ep = u32x4{0, 0, 0, 0};
-        lp_at = ep_at = kNone;
+        const u32x4 z = {0, 0, 0, 0};
+        la = ea = z;
+        l0 = l1 = l2 = l3 = z;
+        e0 = e1 = e2 = e3 = z;
+        lq_n = eq_n = 0;
+        lq_at = eq_at = 0;
+    }
+    __device__ __forceinline__ void burst_lit() {
+        store16(lit + lq_at, l0); store16(lit + lq_at + 16, l1); store16(lit + lq_at + 32, l2); store16(lit + lq_at + 48, l3);
+        lq_n = 0;
+    }
+    __device__ __forceinline__ void burst_ent() {
+        store16(ent + eq_at, e0); store16(ent + eq_at + 4, e1); store16(ent + eq_at + 8, e2); store16(ent + eq_at + 12, e3);
+        eq_n = 0;
     }
     __device__ __forceinline__ void flush() {
-        if (lp_at != kNone) { store16(lit + lp_at, lp); lp_at = kNone; }
-        if (ep_at != kNone) { store16(ent + ep_at, ep); ep_at = kNone; }
+        if (lq_n == 4u) burst_lit();
+        if (eq_n == 4u) burst_ent();
     }
     __device__ __forceinline__ void push_byte(uint32_t byte) {      // la = (la >> 8) | byte << 120
         la.x = __builtin_amdgcn_alignbit(la.y, la.x, 8);
@@ -343,18 +355,20 @@ struct Emitter {
         ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = e;
         ++n_ent;
         if ((n_ent & 3u) == 0) {
-            if (ep_at != kNone) store16(ent + ep_at, ep);      // (second group within one iteration: split runs only)
-            ep = ea;
-            ep_at = n_ent - 4;
+            if (eq_n == 4u) burst_ent();                       // (a second group within one iteration: split runs only)
+            if (eq_n == 0u) eq_at = n_ent - 4;
+            e0 = e1; e1 = e2; e2 = e3; e3 = ea;
+            ++eq_n;
         }
     }
     __device__ __forceinline__ void literal(uint32_t byte) {
         push_byte(byte);
         ++n_lit;
         if ((n_lit & 15u) == 0) {
-            if (lp_at != kNone) store16(lit + lp_at, lp);      // (stored blocks emit more than 16 bytes between flushes)
-            lp = la;
-            lp_at = n_lit - 16;
+            if (lq_n == 4u) burst_lit();                       // (stored blocks emit more than 16 bytes between flushes)
+            if (lq_n == 0u) lq_at = n_lit - 16;
+            l0 = l1; l1 = l2; l2 = l3; l3 = la;
+            ++lq_n;
         }
         ++run;
     }
@@ -368,9 +382,25 @@ struct Emitter {
         run = 0;
     }
     __device__ __forceinline__ void finish() {
-        flush();
         split_run();
         if (run) { push_entry(make_entry(run, 0, 1)); run = 0; }
+        // parked groups (an incomplete burst: the oldest sits in slot 4 - n)
+        {
+            const uint32_t skip = 4u - lq_n;
+            if (skip <= 0u) store16(lit + lq_at + 16u * (0u - skip), l0);
+            if (skip <= 1u) store16(lit + lq_at + 16u * (1u - skip), l1);
+            if (skip <= 2u) store16(lit + lq_at + 16u * (2u - skip), l2);
+            if (skip <= 3u) store16(lit + lq_at + 16u * (3u - skip), l3);
+            lq_n = 0;
+        }
+        {
+            const uint32_t skip = 4u - eq_n;
+            if (skip <= 0u) store16(ent + eq_at + 4u * (0u - skip), e0);
+            if (skip <= 1u) store16(ent + eq_at + 4u * (1u - skip), e1);
+            if (skip <= 2u) store16(ent + eq_at + 4u * (2u - skip), e2);
+            if (skip <= 3u) store16(ent + eq_at + 4u * (3u - skip), e3);
+            eq_n = 0;
+        }
         const uint32_t rl = n_lit & 15u;
         if (rl) {
             for (uint32_t k = rl; k < 16; ++k) push_byte(0);
@@ -382,7 +412,6 @@ struct Emitter {
             for (uint32_t k = re; k < 4; ++k) { ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = 0; }
             store16(ent + (keep & ~3u), ea);
         }
-        flush();
     }
 };
 

@@ -78,9 +78,9 @@ struct RgTable {            // read-group id strings -> sample id (depth.d:1170-
 // K1b lz77_resolve (wave per block -> inflated bytes).  The per-block arrays are indexed from 0 for
 // the n_blocks blocks of this launch; block0 is the index of the first one in the whole file (it
 // only positions the blocks' slices inside the token streams).
-// offset of block b's 16-byte aligned slice (capacity >= isize[b] + 33 bytes) in the literal stream; a pure function of
+// offset of block b's 64-byte aligned slice (capacity >= isize[b] + 49 bytes) in the literal stream; a pure function of
 // (out_off[b], b).  K2 reuses the slice, dead once the block is inflated, for the block's record offsets.
-__host__ __device__ __forceinline__ uint64_t inflate_lit_offset(uint64_t out_off_b, uint32_t b) { return (out_off_b + 48ull * b + 15ull) & ~15ull; }
+__host__ __device__ __forceinline__ uint64_t inflate_lit_offset(uint64_t out_off_b, uint32_t b) { return (out_off_b + 112ull * b + 63ull) & ~63ull; }
 size_t inflate_scratch_bytes(uint32_t n_blocks);
 size_t inflate_lit_bytes(uint64_t total_out, uint32_t n_blocks);
 size_t inflate_ent_words(uint64_t total_out, uint32_t n_blocks);
@@ -133,6 +133,9 @@ struct IndexArgs {
                                     // inflate failed, [2] != 0: desc_cap was too small (nothing useful was written)
 };
 void launch_index_blocks(const IndexArgs& a, hipStream_t stream);
+// parallel repair round: blocks not entered where their predecessor was left are walked again from there
+// (*d_n_changed += blocks re-walked; reads exit_[b-1] of the previous round: launch until it stays 0)
+void launch_rewalk_mismatched(const IndexArgs& a, uint32_t* d_n_changed, hipStream_t stream);
 // serial (one wave) repair of the recorded chain from block `from` on; *d_n_rewalked += blocks re-walked
 void launch_chain_repair(const uint8_t* d_U, const uint64_t* d_out_off, const uint32_t* d_isize, const uint32_t* d_run_of,
                          const ChainRun* d_runs, uint32_t n_blocks, uint32_t from, uint64_t* d_entry, uint64_t* d_exit,

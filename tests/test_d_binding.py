@@ -117,4 +117,4 @@ def test_d_declares_every_function_of_the_header():
 
 def test_d_glue_is_code_not_a_comment():
     text = _d_source()
-    assert re.search(r"\bbool\s+sbxDepthRun\s*\(", text) and "sbx_format_base_rows(ctx" in text and "sbx_depth_window_stats(ctx" in text
+    assert re.search(r"\bbool\s+sbxDepthRun\s*\(", text) and "sbx_stream_base_rows(ctx" in text and "sbx_depth_window_stats(ctx" in text

@@ -122,3 +122,30 @@ def test_zero_fill_skips_contigs_between_columns(tmp_path):
         assert dev == run_cli_host_format(args + [p], cwd=None)
     out = run_cli(["base", "-c", "0", p]).decode()
     assert "e0\t0\t" in out and "e3\t0\t" in out and "e4\t2\t" in out and "e1\t" not in out and "e2\t" not in out
+
+
+@pytest.mark.parametrize("piece", ["256", "5000", "70000"])
+def test_streamed_rows_equal_the_buffered_form(synth_ms, piece, monkeypatch):
+    """sbx_stream_base_rows (pinned double-buffered pieces, what the CLI prints through) == sbx_format_base_rows, for piece
+    sizes that cut the interval into many, a few and one piece; a failing writer surfaces as SBX_EIO."""
+    import sambamba_amd
+    monkeypatch.setenv("SBX_STREAM_PIECE", piece)
+    with sambamba_amd.Depth(synth_ms) as d:
+        d.set_params()
+        d.run()
+        for ref, beg, end, kw in ((0, 0, 150000, {}), (0, 777, 60001, dict(min_cov=0)), (2, 100, 40000, dict(min_cov=3, annotate=True)),
+                                  (1, 0, 3000, dict(min_cov=0))):
+            want = d.format_base_rows(ref, beg, end, **kw)
+            got = []
+            d.stream_base_rows(ref, beg, end, got.append, **kw)
+            assert b"".join(got) == want, (ref, beg, end, kw)
+            assert len(want) > 0
+        def broken(_):
+            raise IOError("disk full")
+        with pytest.raises(sambamba_amd.SbxError) as e:
+            d.stream_base_rows(0, 0, 150000, broken)
+        assert e.value.code == -2 and "writer" in str(e.value)
+        # the context stays usable
+        got = []
+        d.stream_base_rows(2, 0, 1000, got.append)
+        assert b"".join(got) == d.format_base_rows(2, 0, 1000)

@@ -15,15 +15,15 @@ export TMPDIR=/tmp
 python bench.py --steps "$STEPS" --warmup 1 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- \
-    python "$REPO/bench.py" --steps "$STEPS" --warmup 1 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
+    python "$REPO/bench.py" --steps "$STEPS" --warmup 1 --no-cpu-baseline --no-e2e --parity-windows 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- \
-    python "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$OUT/fetch.err"
+    python "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --parity-windows 0 > /dev/null 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- \
-    python "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$OUT/write.err"
+    python "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --parity-windows 0 > /dev/null 2> "$OUT/write.err"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/sq1" -o s -- \
-    python "$REPO/bench.py" --length 90000000 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$OUT/sq1.err"
+    python "$REPO/bench.py" --length 90000000 --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --parity-windows 0 > /dev/null 2> "$OUT/sq1.err"
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/sq2" -o s -- \
-    python "$REPO/bench.py" --length 90000000 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$OUT/sq2.err"
+    python "$REPO/bench.py" --length 90000000 --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --parity-windows 0 > /dev/null 2> "$OUT/sq2.err"
 cd "$REPO"
 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 # raw traces are large: keep the summaries
