@@ -8,12 +8,13 @@ synthetic coordinate-sorted BAM of BASELINE.json configs[1] (chr1, L=248,956,422
 paired reads), whose compressed bytes are already resident in HBM when the timed
 region starts.
 
-N == 1: the whole BAM on one GPU.  N > 1: ONE BAM sharded over the ranks by reference position
-(sambamba_amd.shard.plan_position_shards: every rank takes a contiguous slice of the positions, fetches
-the reads overlapping it through the BAI and clips its contributions to the slice) -- the total work is
-fixed as N grows ("scaling": "strong"), ranks never exchange per-position data, and `value` is the reads
-of the whole BAM divided by the slowest rank's time.  --mode replicas keeps round 1's weak-scaling form
-(every rank processes the same full BAM).
+N == 1: the whole BAM on one GPU.  N > 1 (default --mode auto): the path partitions by reference position and has no
+data-path collective, so the timed region keeps the per-GPU work fixed ("scaling": "weak"): every rank runs the
+chr1-sized workload on its own GPU and `value` is the aggregate.  The same invocation then cuts that ONE BAM into N
+position slices (sambamba_amd.shard.plan_position_shards: every rank fetches the reads overlapping its slice through
+the BAI and clips its contributions to the slice), times that too and reports it as `sharded_one_bam` (strong
+scaling, parity-checked against the oracle on every rank).  --mode shard makes the sharded form the headline;
+--mode replicas skips it.
 
 Other BASELINE configs (builder-run lines, committed under profiles/): --config 3 (window -w 1000 on the
 25-contig genome, streamed in batches), --config 4 (region -L exome BED on the same BAM), --config 5
@@ -212,25 +213,35 @@ def parity_text(d, bam, ref_name, ref, beg, end, extra_args):
 
 
 def cli_e2e(bam, mode_args, reads):
-    """The product CLI end to end: file (page cache) -> device -> text on /dev/null, wall clock of the process."""
+    """The product CLI end to end: file (page cache) -> device -> text on /dev/null, wall clock of the process.
+    Three runs a few seconds apart (the driver scrubs the device memory a process frees, which stalls the allocations of
+    one started right behind it); the best is reported, all are listed, with the CLI's own phase clock of the best one."""
     from sambamba_amd import cli_path
-    out = []
-    for _ in range(2):     # first call pays the page-in of the shared libraries
+    runs = []
+    env = dict(os.environ, SBX_TIMING="1")
+    for k in range(3):
+        if k:
+            time.sleep(3.0)
         t0 = time.time()
-        r = subprocess.run([cli_path()] + mode_args + ["-o", "/dev/null", bam], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        out.append(time.time() - t0)
+        r = subprocess.run([cli_path()] + mode_args + ["-o", "/dev/null", bam], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+        dt = time.time() - t0
         if r.returncode != 0:
             return {"error": r.stderr.decode()[-300:]}
-    best = min(out)
-    return {"seconds": round(best, 3), "Mreads_per_s": round(reads / best / 1e6, 2), "what": "sbx-depth %s -o /dev/null <bam> (file in page cache, "
-            "H2D + device pipeline + device text formatting + D2H + write), best of 2" % " ".join(mode_args)}
+        phases = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("[sbx")]
+        runs.append((dt, phases))
+    best = min(runs, key=lambda x: x[0])
+    return {"seconds": round(best[0], 3), "Mreads_per_s": round(reads / best[0] / 1e6, 2), "all_seconds": [round(x[0], 3) for x in runs],
+            "phases": best[1][-4:],
+            "what": "sbx-depth %s -o /dev/null <bam> (file in page cache; process start, open, pinned double-buffered H2D, device "
+                    "pipeline, device text formatting, pinned double-buffered D2H, write), best of 3" % " ".join(mode_args)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=int(os.environ.get("SBX_BENCH_STEPS", 150)),
+                    help="passes in the timed region (default: ~10 s of device time on configs[1])")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=int(os.environ.get("SBX_BENCH_CONFIG", 2)), help="BASELINE.json config number (2..5)")
     ap.add_argument("--mode", choices=["auto", "shard", "replicas"], default=os.environ.get("SBX_BENCH_MODE", "auto"))
     ap.add_argument("--length", type=int, default=int(os.environ.get("SBX_BENCH_LEN", CHR1_LEN)),
@@ -285,7 +296,7 @@ def main():
     if rank != 0:
         info = json.load(open(path + ".json"))
 
-    sharded = world > 1 and args.mode != "replicas"
+    sharded = world > 1 and args.mode == "shard"
     d = sambamba_amd.Depth(path, device=dev_index)
     SBX = sambamba_amd
     mode_args, min_bq, fix_mate = ["base"], 0, False
@@ -309,28 +320,29 @@ def main():
         d.set_params(min_bq=20, fix_mate_overlaps=True)
         mode_args = ["base", "-m", "-q", "20"]
 
-    # ---- the work of this rank: a list of steps [(kind, args)] that together make one pass ----------------------
+    # ---- the work of this rank: one pass = the runs of its share ---------------------------------------------------
     ref_lengths = d.ref_lengths
-    if sharded:
-        align = 1000 if args.config == 3 else 1024
-        my = shardmod.plan_position_shards(ref_lengths, world, align=align)[rank]      # [(ref, beg, end)]
-        if regions is not None:
-            my = shardmod.clip_regions_to_shards(regions, my)
-    else:
-        my = None
-    if my is None:
-        if args.config in (3, 4) and regions is None:
-            d.preload()
-            plan = d.plan_batches()
-        elif regions is not None:
-            d.set_regions(shardmod.merge_regions(regions))
-            plan = [None]
-        else:
-            d.preload()                # compressed BAM resident in HBM before the timed region
-            plan = [None]
     window_rows = [0]
 
-    def one_pass():
+    def share(sharded_):
+        """(my, plan): `my` = this rank's position slice [(ref, beg, end)] of ONE sharded BAM, or None with `plan` = the
+        batches of the whole BAM."""
+        if sharded_:
+            align = 1000 if args.config == 3 else 1024
+            mine = shardmod.plan_position_shards(ref_lengths, world, align=align)[rank]
+            if regions is not None:
+                mine = shardmod.clip_regions_to_shards(regions, mine)
+            return mine, None
+        if args.config in (3, 4) and regions is None:
+            d.preload()
+            return None, d.plan_batches()
+        if regions is not None:
+            d.set_regions(shardmod.merge_regions(regions))
+            return None, [None]
+        d.preload()                    # compressed BAM resident in HBM before the timed region
+        return None, [None]
+
+    def one_pass(my, plan):
         """One pass of the hot path over this rank's share; returns the list of per-run statistics."""
         sts = []
         if my is not None:
@@ -369,30 +381,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    log("context open, input resident; warmup")
-    for _ in range(args.warmup):
-        one_pass()
-    sync()
-    log("timed region: %d steps" % args.steps)
-    t0 = time.perf_counter()
-    kstats = []
-    for _ in range(args.steps):
-        kstats.append(one_pass())
-    sync()
-    elapsed = time.perf_counter() - t0
+    def timed(sharded_, warmup, steps):
+        """warmup + `steps` timed passes (barrier + device synchronisation on both sides, MAX over the ranks)."""
+        my, plan = share(sharded_)
+        for _ in range(warmup):
+            one_pass(my, plan)
+        sync()
+        t0 = time.perf_counter()
+        ks = []
+        for _ in range(steps):
+            ks.append(one_pass(my, plan))
+        sync()
+        el = time.perf_counter() - t0
+        lastp = ks[-1]
+        reads = float(sum(s["n_records"] for s in lastp))
+        adm = float(sum(s["n_admitted"] for s in lastp))
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            r = torch.tensor([reads, adm], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            reads, adm = float(r[0].item()), float(r[1].item())
+        return {"my": my, "plan": plan, "kstats": ks, "elapsed": el, "sum_reads": reads, "sum_adm": adm}
+
+    log("context open; warmup + timed region: %d steps (%s)" % (args.steps, "one BAM sharded over the ranks" if sharded else
+                                                                "whole BAM per rank"))
+    main_run = timed(sharded, args.warmup, args.steps)
+    my, plan, kstats, elapsed = main_run["my"], main_run["plan"], main_run["kstats"], main_run["elapsed"]
+    sum_reads, sum_adm = main_run["sum_reads"], main_run["sum_adm"]
     log("timed region done: %.1f ms per step; parity" % (elapsed / args.steps * 1e3))
     last = kstats[-1]
-    my_reads = float(sum(s["n_records"] for s in last))
-    my_adm = float(sum(s["n_admitted"] for s in last))
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([my_reads, my_adm], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        sum_reads, sum_adm = float(r[0].item()), float(r[1].item())
-    else:
-        sum_reads, sum_adm = my_reads, my_adm
     # sharded: reads near a cut are seen by both neighbours, the job's reads are the file's
     total_reads = float(info["reads"]) if sharded else sum_reads
     total_admitted = sum_adm * (total_reads / sum_reads) if (sharded and sum_reads) else sum_adm
@@ -415,6 +434,44 @@ def main():
             md_got, md_want, nbytes = parity_text(d, path, d.ref_names[ref], ref, a2, b2, mode_args[1:])
             par.update({"text_slab": [ref, a2, b2], "text_bytes": nbytes, "text_md5": md_got, "text_ok": md_got == md_want})
             par["ok"] = par["ok"] and md_got == md_want
+    if args.parity_windows > 0 and args.config in (3, 4) and my is None:
+        # window / region statistics of the batch that is still resident against the oracle's `depth region -L chr:a-b`
+        # (a window is the region [k w, (k + 1) w); the reads come through the BAI, seconds per call)
+        import numpy as np
+        rng = random.Random(seed ^ 0x33)
+        checked, bad = 0, []
+        if args.config == 3:
+            lastb = plan[-1]
+            refs_res = range(lastb[0], lastb[0] + lastb[1]) if lastb is not None else range(len(ref_lengths))
+            cands = [r for r in refs_res if ref_lengths[r] >= 4000]
+            for _ in range(args.parity_windows):
+                if not cands:
+                    break
+                r = cands[rng.randrange(len(cands))]
+                k = rng.randrange(1, ref_lengths[r] // 1000 - 1)
+                nr, nb, _cov = d.window_stats(r, k, 1)
+                got = (int(nr[0][0]), "%g" % float(np.float32(nb[0][0]) / np.float32(1000)))
+                out = subprocess.run([os.path.join(ROOT, "oracle", "depth_oracle"), "region", "-L", "%s:%d-%d" % (d.ref_names[r], k * 1000 + 1, (k + 1) * 1000), path],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode().splitlines()
+                f = out[-1].split("\t")
+                want = (int(f[3]), f[4])
+                checked += 1
+                if got != want:
+                    bad.append([r, k, list(got), list(want)])
+        else:
+            picks = [regions[rng.randrange(len(regions))] for _ in range(args.parity_windows)]
+            nr, nb, _cov, _seen = d.region_stats(picks)
+            for j, (r, a, b) in enumerate(picks):
+                got = (int(nr[j][0]), "%g" % float(np.float32(nb[j][0]) / np.float32(b - a)))
+                out = subprocess.run([os.path.join(ROOT, "oracle", "depth_oracle"), "region", "-L", "%s:%d-%d" % (d.ref_names[r], a + 1, b), path],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode().splitlines()
+                f = out[-1].split("\t")
+                want = (int(f[3]), f[4])
+                checked += 1
+                if got != want:
+                    bad.append([r, a, b, list(got), list(want)])
+        par = {"windows": checked, "ok": not bad, "mismatches": bad[:4],
+               "what": "readCount and meanCoverage of sampled %s against `depth_oracle region -L`" % ("windows" if args.config == 3 else "BED regions")}
     if dist:
         okt = torch.tensor([1.0 if par["ok"] else 0.0, float(par["windows"])], dtype=torch.float64, device=red_dev)
         allok = okt.clone()
@@ -423,6 +480,25 @@ def main():
         par["ok_all_ranks"] = bool(allok[0].item() >= 1.0)
         par["windows_all_ranks"] = int(okt[1].item())
     parity_ok = par.get("ok_all_ranks", par["ok"])
+
+    # ---- N > 1, default mode: the SAME BAM once more, now sharded over the ranks by position (strong scaling) -------
+    strong = None
+    if world > 1 and args.mode == "auto" and args.config in (2, 5):
+        s_steps = max(3, args.steps // 4)
+        log("one BAM sharded over %d ranks: %d steps" % (world, s_steps))
+        sh = timed(True, 1, s_steps)
+        ok_s = True
+        if args.parity_windows > 0 and sh["my"]:
+            n_s, bad_s = parity_windows(d, path, [sh["my"][-1]], max(2, args.parity_windows // 2), seed ^ (rank + 77), min_bq=min_bq, fix_mate=fix_mate)
+            ok_s = not bad_s
+        okt = torch.tensor([1.0 if ok_s else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok_s = bool(okt[0].item() >= 1.0)
+        strong = {"scaling": "strong", "steps": s_steps, "ms_per_step": round(sh["elapsed"] / s_steps * 1e3, 3),
+                  "value": round(float(info["reads"]) / (sh["elapsed"] / s_steps) / 1e6, 3), "unit": "Mreads/s", "parity_ok": ok_s,
+                  "what": "the same BAM cut into %d position slices (sambamba_amd.shard.plan_position_shards), every rank fetches the reads "
+                          "of its slice through the BAI and clips its contributions to the slice; no data-path collective" % world}
+        parity_ok = parity_ok and ok_s
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -480,7 +556,12 @@ def main():
             "roofline": roof, "kernels": per_kernel,
             "fused_path": {"algorithmic_GBps": round(fused, 1), "frac_of_hbm_peak": round(fused / HBM_PEAK_GBS, 5),
                            "what": "(compressed bytes in + counter bytes out) / sum of the kernel times of a pass, rank 0"},
+            "sharded_one_bam": strong,
             "cpu_baseline": cpu, "parity_checked": par, "e2e": e2e,
+            "e2e_Mreads_per_s": (e2e or {}).get("Mreads_per_s"),
+            "e2e_vs_cpu_baseline": (e2e or {}).get("vs_cpu_baseline"),
+            "kernel_only_vs_cpu_baseline_note": "`value` is the device pipeline with the compressed bytes resident; the like-for-like pair is "
+                                                "e2e_Mreads_per_s (file -> text) against cpu_baseline.value (file -> text)",
             "host": {"nproc": os.cpu_count(), "bam_gen_seconds": round(info.get("gen_seconds", 0.0), 1),
                      "bam_gen_phases": info.get("gen_phases"), "h2d_ms": round(max(s.get("ms_h2d", 0.0) for s in last), 1),
                      "runs_per_pass": len(last), "chain_runs": int(sum(s["n_runs"] for s in last)),

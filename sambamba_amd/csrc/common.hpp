@@ -1,6 +1,7 @@
 // common.hpp -- shared host-side helpers for libsbx_depth (HIP error handling, device buffers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <ctime>
 
 #include <cstdint>
 #include <cstdio>
@@ -27,6 +28,11 @@ struct Error : std::runtime_error {
     } while (0)
 
 // RAII device allocation
+// wall clock spent in hipMalloc / hipFree (SBX_TIMING reports it: device memory that another process has just freed is
+// scrubbed by the driver before it is handed out again, which can dominate a one-shot run)
+inline double& alloc_seconds() { static double s = 0; return s; }
+inline double wall_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -45,7 +51,9 @@ struct DevBuf {
         release();
         n = count;
         if (count) {
+            const double t0 = wall_now();
             hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+            alloc_seconds() += wall_now() - t0;
             if (e != hipSuccess) {
                 p = nullptr; n = 0;
                 throw Error(e == hipErrorOutOfMemory ? SBX_ENOMEM : SBX_ENODEVICE,
@@ -55,7 +63,10 @@ struct DevBuf {
     }
     // grow-only (keeps the allocation when it is already large enough)
     void ensure(size_t count) { if (count > n) alloc(count); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() {
+        if (p) { const double t0 = wall_now(); (void)hipFree(p); alloc_seconds() += wall_now() - t0; }
+        p = nullptr; n = 0;
+    }
     size_t bytes() const { return n * sizeof(T); }
 };
 

@@ -11,9 +11,11 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -65,12 +67,15 @@ struct BlockTable {
     size_t size() const { return comp_len.size(); }
 };
 
-// Scans block headers until the EOF block / end of file (the stream stops at the first empty
-// block, inputstream.d:393-394).
-inline BlockTable scan_bgzf(const uint8_t* f, size_t n) {
-    BlockTable t;
-    uint64_t off = 0, uo = 0;
+// Scans block headers from file offset `off` until the EOF block / end of file / `limit` (the stream stops at the first
+// empty block, inputstream.d:393-394).  Returns the offset where the scan ended; *hit_eof: it ended at an empty block or at
+// the end of the file rather than at `limit`.
+inline uint64_t scan_bgzf_range(const uint8_t* f, size_t n, uint64_t off, uint64_t limit, BlockTable* tp, bool* hit_eof) {
+    BlockTable& t = *tp;
+    uint64_t uo = 0;
+    *hit_eof = true;
     while (off < n) {
+        if (off >= limit) { *hit_eof = false; break; }
         if (n - off < 4) break;  // short read of the magic == end of stream (inputstream.d:75-80)
         auto fail = [&](const std::string& m) {
             throw Error(SBX_EFORMAT, "Error reading BGZF block starting from offset " + std::to_string(off) + ": " + m);
@@ -112,6 +117,76 @@ inline BlockTable scan_bgzf(const uint8_t* f, size_t n) {
         off += (uint64_t)bsize + 1;
     }
     t.out_off.push_back(uo);
+    return off;
+}
+
+// The whole file.  `hints` (optional): file offsets that are known block starts -- the index names thousands of them (the
+// coffset part of every BAI virtual offset) -- cut the serial header chain into pieces that are scanned by separate
+// threads; a piece that does not end exactly where the next one starts (a stale index) falls back to the serial scan, so
+// the hints can change the speed of the scan, never its result.
+inline BlockTable scan_bgzf(const uint8_t* f, size_t n, const std::vector<uint64_t>* hints = nullptr) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    std::vector<uint64_t> cuts;
+    size_t min_bytes = 64u << 20;
+    if (const char* e = getenv("SBX_SCAN_PARALLEL_MIN")) min_bytes = (size_t)strtoull(e, nullptr, 10);      // (tests)
+    if (hints && n > min_bytes && hw > 1) {
+        std::vector<uint64_t> h;
+        for (uint64_t x : *hints) if (x > 0 && x < n) h.push_back(x);
+        std::sort(h.begin(), h.end());
+        h.erase(std::unique(h.begin(), h.end()), h.end());
+        const size_t pieces = std::min<size_t>({(size_t)16, (size_t)hw, h.size() + 1});
+        for (size_t k = 1; k < pieces; ++k) {      // the hint closest to k/pieces of the file
+            const uint64_t want = (uint64_t)((double)n * k / pieces);
+            auto it = std::lower_bound(h.begin(), h.end(), want);
+            if (it == h.end()) break;
+            if (cuts.empty() || *it > cuts.back()) cuts.push_back(*it);
+        }
+    }
+    if (!cuts.empty()) {
+        const size_t P = cuts.size() + 1;
+        std::vector<BlockTable> part(P);
+        std::vector<uint64_t> ended(P, 0);
+        std::vector<char> eof(P, 0), failed(P, 0);
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < P; ++k)
+            th.emplace_back([&, k] {
+                try {
+                    bool e = false;
+                    ended[k] = scan_bgzf_range(f, n, k ? cuts[k - 1] : 0, k + 1 < P ? cuts[k] : ~0ull, &part[k], &e);
+                    eof[k] = e ? 1 : 0;
+                } catch (const std::exception&) { failed[k] = 1; }
+            });
+        for (auto& t : th) t.join();
+        bool ok = true;
+        size_t last = P - 1;          // the piece in which the stream ends
+        for (size_t k = 0; k < P && ok; ++k) {
+            if (failed[k]) { ok = false; break; }
+            if (eof[k]) { last = k; break; }
+            if (k + 1 < P && ended[k] != cuts[k]) ok = false;
+        }
+        if (ok) {
+            BlockTable t;
+            uint64_t uo = 0;
+            size_t total = 0;
+            for (size_t k = 0; k <= last; ++k) total += part[k].size();
+            t.coffset.reserve(total); t.comp_off.reserve(total); t.comp_len.reserve(total); t.isize.reserve(total); t.out_off.reserve(total + 1);
+            for (size_t k = 0; k <= last; ++k) {
+                const BlockTable& q = part[k];
+                t.coffset.insert(t.coffset.end(), q.coffset.begin(), q.coffset.end());
+                t.comp_off.insert(t.comp_off.end(), q.comp_off.begin(), q.comp_off.end());
+                t.comp_len.insert(t.comp_len.end(), q.comp_len.begin(), q.comp_len.end());
+                t.isize.insert(t.isize.end(), q.isize.begin(), q.isize.end());
+                for (size_t i = 0; i < q.size(); ++i) t.out_off.push_back(uo + q.out_off[i]);
+                uo += q.out_off.back();
+            }
+            t.out_off.push_back(uo);
+            return t;
+        }
+        // (a piece failed or the pieces do not join: the serial scan reports what is wrong, exactly as before)
+    }
+    BlockTable t;
+    bool e = false;
+    scan_bgzf_range(f, n, 0, ~0ull, &t, &e);
     return t;
 }
 

@@ -692,32 +692,40 @@ __global__ __launch_bounds__(kWalkThreads) void k_rewalk_mismatched(IndexArgs a,
 // state[b] = 2 << 62 | records in blocks 0..b (the engine reads the last one); flags[0] = lowest inconsistent block,
 // flags[2] != 0: the descriptor array is too small for the total
 __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
-    __shared__ uint64_t part[kScanThreads];
-    const uint32_t t = threadIdx.x, n = a.n_blocks;
-    const uint32_t per = (n + kScanThreads - 1) / kScanThreads;
-    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
-    uint64_t s = 0;
+    // 1024 blocks per step, coalesced: inclusive scan inside the wave by shuffles, wave totals through LDS
+    __shared__ uint64_t wtot[kScanThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6, n = a.n_blocks;
+    uint64_t run = 0;                    // records in the blocks before this step (workgroup-uniform)
     uint32_t first_bad = 0xFFFFFFFFu;
-    for (uint32_t i = lo; i < hi; ++i) {
-        s += a.count[i];
-        const ChainRun r = a.runs[a.run_of[i]];
-        if (i != r.blk_first && a.exit_[i - 1] != a.entry[i] && first_bad == 0xFFFFFFFFu) first_bad = i;
+    for (uint32_t i0 = 0; i0 < n; i0 += kScanThreads) {
+        const uint32_t i = i0 + t;
+        uint64_t v = 0;
+        if (i < n) {
+            v = a.count[i];
+            const ChainRun r = a.runs[a.run_of[i]];
+            if (i != r.blk_first && a.exit_[i - 1] != a.entry[i] && first_bad == 0xFFFFFFFFu) first_bad = i;
+        }
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = (uint64_t)__shfl_up((unsigned long long)incl, d, 64);
+            if ((int)lane >= d) incl += o;
+        }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        uint64_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+            const uint64_t x = wtot[w];
+            before += w < wv ? x : 0;
+            all += x;
+        }
+        if (i < n) a.state[i] = (2ull << 62) | (run + before + incl);
+        run += all;
+        __syncthreads();
     }
     if (first_bad != 0xFFFFFFFFu) atomicMin(a.flags + 0, first_bad);
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {      // Hillis-Steele inclusive scan over the partials
-        const uint64_t v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint64_t runsum = t ? part[t - 1] : 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        runsum += a.count[i];
-        a.state[i] = (2ull << 62) | runsum;
-    }
-    if (t == kScanThreads - 1 && part[kScanThreads - 1] > a.desc_cap) atomicOr(a.flags + 2, 1u);
+    if (t == 0 && run > a.desc_cap) atomicOr(a.flags + 2, 1u);
 }
 
 // ---- 3. describe: one wave per block, one lane per record ---------------------------------------------------

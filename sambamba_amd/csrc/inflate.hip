@@ -317,7 +317,9 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
 struct Emitter {
     uint8_t* lit;         // 64-byte aligned literal stream of this block
     uint32_t* ent;        // 64-byte aligned entry stream of this block
-    u32x4 la, ea;         // group being filled
+    u32x4 la, ea;         // the last 20 literal bytes (la + lx: a group that has just been completed stays whole while up
+    uint32_t lx;          //  to three more literals of the same loop iteration are pushed) / the entry group being filled
+    uint32_t n_grp;       // literal groups parked so far
     u32x4 l0, l1, l2, l3; // parked literal groups: the newest in l3, the oldest of lq_n in l[4 - lq_n]
     u32x4 e0, e1, e2, e3;
     uint32_t lq_n, eq_n;  // parked groups
@@ -328,6 +330,7 @@ struct Emitter {
         lit = l; ent = e; n_lit = n_ent = run = 0;
         const u32x4 z = {0, 0, 0, 0};
         la = ea = z;
+        lx = 0; n_grp = 0;
         l0 = l1 = l2 = l3 = z;
         e0 = e1 = e2 = e3 = z;
         lq_n = eq_n = 0;
@@ -345,11 +348,32 @@ struct Emitter {
         if (lq_n == 4u) burst_lit();
         if (eq_n == 4u) burst_ent();
     }
-    __device__ __forceinline__ void push_byte(uint32_t byte) {      // la = (la >> 8) | byte << 120
+    __device__ __forceinline__ void push_byte(uint32_t byte) {      // {lx, la} = ({lx, la} >> 8) | byte << 152
         la.x = __builtin_amdgcn_alignbit(la.y, la.x, 8);
         la.y = __builtin_amdgcn_alignbit(la.z, la.y, 8);
         la.z = __builtin_amdgcn_alignbit(la.w, la.z, 8);
-        la.w = (la.w >> 8) | (byte << 24);
+        la.w = __builtin_amdgcn_alignbit(lx, la.w, 8);
+        lx = (lx >> 8) | (byte << 24);
+    }
+    // Parks the literal group completed since the last call (at most one: call it at least every four literals).  The
+    // decode loop has ONE park site per iteration instead of one per literal slot -- with 64 lanes some lane completes
+    // a group in almost every slot, so a per-slot site is executed by the whole wave nearly every time.
+    __device__ __forceinline__ void park_lits() {
+        if ((n_lit >> 4) != n_grp) {
+            const uint32_t k = n_lit & 15u;                    // literals already pushed behind the completed group (0..3)
+            const uint32_t sh = (4u - k) & 3u;                 // the group starts 4 - k bytes above the bottom of {lx, la}
+            u32x4 g;
+            g.x = __builtin_amdgcn_alignbyte(la.y, la.x, sh);
+            g.y = __builtin_amdgcn_alignbyte(la.z, la.y, sh);
+            g.z = __builtin_amdgcn_alignbyte(la.w, la.z, sh);
+            g.w = __builtin_amdgcn_alignbyte(lx, la.w, sh);
+            if (k == 0u) { g.x = la.y; g.y = la.z; g.z = la.w; g.w = lx; }
+            if (lq_n == 4u) burst_lit();                       // (stored blocks: a group every 16 iterations, flush() keeps up)
+            if (lq_n == 0u) lq_at = n_grp * 16u;
+            l0 = l1; l1 = l2; l2 = l3; l3 = g;
+            ++lq_n;
+            ++n_grp;
+        }
     }
     __device__ __forceinline__ void push_entry(uint32_t e) {
         ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = e;
@@ -364,12 +388,6 @@ struct Emitter {
     __device__ __forceinline__ void literal(uint32_t byte) {
         push_byte(byte);
         ++n_lit;
-        if ((n_lit & 15u) == 0) {
-            if (lq_n == 4u) burst_lit();                       // (stored blocks emit more than 16 bytes between flushes)
-            if (lq_n == 0u) lq_at = n_lit - 16;
-            l0 = l1; l1 = l2; l2 = l3; l3 = la;
-            ++lq_n;
-        }
         ++run;
     }
     // an entry carries at most 255 literals: longer runs are split here, not in the per-literal path
@@ -382,6 +400,7 @@ struct Emitter {
         run = 0;
     }
     __device__ __forceinline__ void finish() {
+        park_lits();
         split_run();
         if (run) { push_entry(make_entry(run, 0, 1)); run = 0; }
         // parked groups (an incomplete burst: the oldest sits in slot 4 - n)
@@ -404,7 +423,7 @@ struct Emitter {
         const uint32_t rl = n_lit & 15u;
         if (rl) {
             for (uint32_t k = rl; k < 16; ++k) push_byte(0);
-            store16(lit + (n_lit & ~15u), la);
+            store16(lit + (n_lit & ~15u), u32x4{la.y, la.z, la.w, lx});
         }
         const uint32_t re = n_ent & 3u;
         if (re) {
@@ -479,6 +498,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                 em.literal(br.take(8));
                 --stored_left;
             }
+            em.park_lits();
             br.service();
         }
         int nlit = 0, ndist = 0;
@@ -614,6 +634,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                     bad = ok ? INF_OK : INF_BAD_SYMBOL;
                 }
             }
+            em.park_lits();
             if (opos > osize && bad == INF_OK) { bad = INF_OUTPUT_OVERRUN; msym = 0; }
             if (msym != 0) {
                 // One refill covers the whole match: <= 5 length-extra + 15 code + 13 distance-extra bits.

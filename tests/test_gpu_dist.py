@@ -86,3 +86,27 @@ def test_sharded_equals_single_gpu_cli(genome, args, world):
     port = 29700 + 10 * world + (sum(map(ord, " ".join(args))) % 10)      # one port per case: no reuse while a socket lingers
     got = run_sharded([a[0], bam] + a[1:], world, port)
     assert got == want
+
+
+@pytest.mark.parametrize("mode", ["auto", "shard"])
+def test_bench_multi_rank_line(tmp_path, mode):
+    """bench.py as the driver launches it for N > 1 (here: two ranks sharing the box's GPU over gloo, a 3 Mbp contig):
+    one JSON line, parity of the timed results against the oracle on every rank, and -- in the default mode -- the same BAM
+    once more sharded over the ranks."""
+    import json
+    env = dict(os.environ, SBX_BENCH_BACKEND="gloo", PYTHONPATH=ROOT, TMPDIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29871" if mode == "auto" else "29872", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--length", "3000000", "--no-cpu-baseline", "--no-e2e", "--parity-windows", "3", "--mode", mode]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_checked"]["ok"] and d["parity_checked"]["ok_all_ranks"]
+    if mode == "auto":
+        assert d["scaling"] == "weak" and d["sharded_one_bam"]["parity_ok"] and d["sharded_one_bam"]["value"] > 0
+        assert d["reads_total"] == 2 * 600000
+    else:
+        assert d["scaling"] == "strong" and d["sharded_one_bam"] is None
+        assert d["reads_total"] == 600000

@@ -99,3 +99,20 @@ def test_short_records_overflow_the_descriptor_estimate_and_retry(tmp_path):
         assert st["uncompressed_bytes"] / st["n_records"] < 160
         assert np.array_equal(d.base_counters(0, 100000, 160000), oracle_base_counters(p, 0, 100000, 160000))
     assert run_cli(["window", "-w", "5000", p]) == run_oracle(["window", "-w", "5000", p])
+
+
+def test_block_table_scanned_in_pieces_equals_the_serial_scan(genome, monkeypatch):
+    """sbx_open cuts the serial BGZF header chain at block starts the BAI names and scans the pieces on separate threads
+    (files above 64 MB; the hook lowers the limit): same block table, same results."""
+    import sambamba_amd
+    def run():
+        with sambamba_amd.Depth(genome) as d:
+            d.set_params()
+            st = d.run()
+            return d.info.n_bgzf_blocks, d.info.uncompressed_bytes, st["n_records"], d.base_counters(11, 0, d.ref_lengths[11])
+    monkeypatch.setenv("SBX_SCAN_PARALLEL_MIN", "1000000000000")
+    a = run()
+    monkeypatch.setenv("SBX_SCAN_PARALLEL_MIN", "0")
+    b = run()
+    assert a[:3] == b[:3] and np.array_equal(a[3], b[3])
+    assert a[0] > 50
