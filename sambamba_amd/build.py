@@ -35,15 +35,21 @@ def build(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-Wno-unused-result"]
     if force or _stale(LIB, deps):
-        objs = []
+        objs, jobs = [], []
         for s in srcs:
             o = s.rsplit(".", 1)[0] + ".o"
             if force or _stale(o, deps):
                 cmd = [_hipcc()] + flags + ["-x", "hip", "-c", s, "-o", o]
                 if verbose:
                     print(" ".join(cmd))
-                subprocess.check_call(cmd)
+                jobs.append(cmd)
             objs.append(o)
+        # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+            for rc in ex.map(subprocess.call, jobs):
+                if rc != 0:
+                    raise subprocess.CalledProcessError(rc, "hipcc")
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))

@@ -127,7 +127,7 @@ struct sbx_ctx {
     DevBuf<int32_t> d_rec_ref;
     DevBuf<uint64_t> d_name_hash;
     uint64_t desc_cap = 0;
-    DevBuf<uint32_t> d_mate, d_n_partners;
+    DevBuf<uint32_t> d_mate, d_n_partners, d_mate_ext;
     DevBuf<int32_t> d_ref_len;
     DevBuf<uint32_t> d_tile_base, d_tile_lo, d_tile_hi, d_active, d_slot_of, d_n_active;
     DevBuf<uint32_t> d_counters, d_span;
@@ -1028,12 +1028,27 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         launch_max_u32(c->d_n_partners.p, n_records, c->d_flag.p + 5, s);
         SBX_HIP(hipMemcpyAsync(&R.max_partners, c->d_flag.p + 5, 4, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));
-        if (R.max_partners > 1)
-            throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps: a read overlaps two or more records with the same name; the reference's "
-                                          "result then depends on per-column status history (depth.d:343-377) and is not on the device path");
+        const char* many_msg = "--fix-mate-overlaps: four or more overlapping records with the same name cover one position (or, in region / "
+                               "window mode, a record overlaps two or more such records); the reference's result then depends on the hash "
+                               "order of unrelated reads (depth.d:343-377) and is not on the device path";
+        if (R.max_partners > 1 && c->mode != SBX_MODE_BASE) throw Error(SBX_EUNSUPPORTED, many_msg);
         if (c->mode == SBX_MODE_BASE) {
+            const bool multi = R.max_partners > 1;
+            if (multi) {
+                // groups of more than two same-name records: list up to three partners per record
+                c->d_mate_ext.ensure(3 * (size_t)n_records + 64);
+                SBX_HIP(hipMemsetAsync(c->d_mate_ext.p, 0xFF, 3 * (size_t)n_records * 4, s));
+                SBX_HIP(hipMemsetAsync(c->d_n_partners.p, 0, (size_t)n_records * 4, s));
+                launch_find_partners(c->U(), c->d_desc.p, c->d_name_hash.p, c->d_rec_ref.p, n_records, c->d_mate_ext.p, c->d_n_partners.p, s);
+            }
             launch_accumulate_mates(c->U(), c->d_desc.p, c->d_mate.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active,
-                                    c->d_tile_base.p, n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+                                    c->d_tile_base.p, n_ref, T, S, c->min_bq, multi ? c->d_mate_ext.p : nullptr, c->d_n_partners.p,
+                                    c->d_flag.p + 6, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+            if (multi) {
+                SBX_HIP(hipMemcpyAsync(&R.max_partners, c->d_flag.p + 6, 4, hipMemcpyDeviceToHost, s));
+                SBX_HIP(hipStreamSynchronize(s));
+                if (R.max_partners) throw Error(SBX_EUNSUPPORTED, many_msg);
+            }
         } else {
             // region / window: the statistics come from per-column quantities, not from the base counters
             c->d_covm.ensure((size_t)n_active * T * S + 1);

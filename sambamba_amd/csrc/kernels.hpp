@@ -162,10 +162,16 @@ void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t
 // d_n_partners[i] = how many were found (> 1 is outside the supported scope)
 void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
                        uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream);
+// second pass when some record has more than one partner: up to three partners per record in d_ext[3 i ..] (d_n_partners is
+// counted again and must be zero on entry)
+void launch_find_partners(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
+                          uint32_t* d_ext, uint32_t* d_n_partners, hipStream_t stream);
+// d_ext == nullptr: every record has at most one partner (d_mate); otherwise records with two or three partners take them
+// from d_ext, and *d_too_many is set when four or more same-name records cover one column
 void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,
                              const uint32_t* d_tile_hi, const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base,
-                             int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters,
-                             uint32_t* d_span, hipStream_t stream);
+                             int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, const uint32_t* d_ext,
+                             const uint32_t* d_n_partners, uint32_t* d_too_many, uint32_t* d_counters, uint32_t* d_span, hipStream_t stream);
 // max over records of n_partners (single block reduction into *d_out)
 void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream_t stream);
 

@@ -13,11 +13,18 @@
 //   * `accumulate_mates` the tile kernel of depth.hip with a per-position path for linked reads: each
 //                       lane takes one reference position, evaluates both mates' CIGAR cursors there
 //                       and applies the reference's rule.
-// Scope: name groups of exactly two overlapping records.  A record with two or more overlapping
-// same-name partners (the reference's behaviour then depends on per-column status history and on the
-// order produced by an unstable sort) raises SBX_EUNSUPPORTED.  Ties are
-// resolved as in the oracle: the record later in the file wins (column order; parity unpinned).
-// Names are compared byte for byte after the hashes match (depth.d:352-353).
+// Name groups of more than two records (supplementary / secondary alignments next to their primaries; depth.d:373
+// "don't consider rare cases of >= 3 reads with the same name") follow the reference's loop literally: at a column the
+// same-name records covering it pair up in column order -- (1st, 2nd), (3rd, 4th) -- and an odd one is left alone.  What a
+// record contributes then also depends on its status (depth.d:355-371, 522-532): a record is processed on its own at
+// every column where its status is not `detected`, and the better mate of every pair is processed in addition, so a
+// record that was paired, was alone again (`past`) and is paired a second time counts twice where it wins.  For up to
+// three same-name records per column all of this follows from geometry (`k_find_partners` lists up to three partners per
+// record, `MultiPlan` below); four or more mutually overlapping same-name records -- where the status of the odd one
+// depends on the hash order of unrelated reads in the column -- raise SBX_EUNSUPPORTED, as do groups of more than two in
+// region / window mode, whose closed form (reduce.hip) is derived for pairs.  Ties are resolved as in the oracle: the
+// record later in the file wins (column order; parity unpinned).  Names are compared byte for byte after the hashes
+// match (depth.d:352-353).
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -50,9 +57,70 @@ __device__ bool same_name(const uint8_t* U, const RecDesc& a, const RecDesc& b) 
     return true;
 }
 
+// The scan of record i runs over the records that start inside its span -- a few hundred at 300x -- and nearly all of it
+// is "different hash, next": the workgroup therefore stages {pos, low half of the hash, reference id | not-admitted bit}
+// of the 1024 records from its first one on in LDS (coalesced, each record's descriptor read four times in all instead
+// of once per neighbour) and the lanes scan that; only a hash match touches global memory again, and a lane whose span
+// reaches beyond the window (coverage in the thousands) finishes in global memory.
+constexpr uint32_t kFindWin = 1024;
+
+__device__ __forceinline__ void link_if_mates(const uint8_t* U, const RecDesc* desc, const uint64_t* hash, const RecDesc& a, uint64_t h,
+                                              uint64_t i, uint64_t j, uint32_t* mate, uint32_t* n_partners) {
+    const RecDesc b = desc[j];
+    if (b.kind != 0 && hash[j] == h && b.sample == a.sample && b.end > a.pos && same_name(U, a, b)) {
+        mate[i] = (uint32_t)j;
+        mate[j] = (uint32_t)i;
+        atomicAdd(&n_partners[i], 1u);
+        atomicAdd(&n_partners[j], 1u);
+    }
+}
+
 __global__ __launch_bounds__(kMateThreads) void k_find_mates(const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc,
                                                               const uint64_t* __restrict__ hash, const int32_t* __restrict__ rec_ref,
                                                               uint64_t n, uint32_t* mate, uint32_t* n_partners) {
+    __shared__ int32_t s_pos[kFindWin];
+    __shared__ uint32_t s_h[kFindWin], s_ref[kFindWin];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kMateThreads;
+    for (uint32_t k = threadIdx.x; k < kFindWin; k += kMateThreads) {
+        const uint64_t j = i0 + k;
+        if (j < n) {
+            const RecDesc d = desc[j];
+            s_pos[k] = d.pos;
+            s_h[k] = (uint32_t)hash[j];
+            s_ref[k] = ((uint32_t)rec_ref[j] & 0x7FFFFFFFu) | (d.kind == 0 ? 0x80000000u : 0u);
+        } else {
+            s_pos[k] = 0x7FFFFFFF;
+            s_h[k] = 0;
+            s_ref[k] = 0x7FFFFFFEu;      // no reference has this id: the scan stops here
+        }
+    }
+    __syncthreads();
+    const uint64_t i = i0 + threadIdx.x;
+    if (i >= n) return;
+    const RecDesc a = desc[i];
+    if (a.kind == 0) return;
+    const uint64_t h = hash[i];
+    const int32_t ref = rec_ref[i];
+    const uint32_t ref_tag = (uint32_t)ref & 0x7FFFFFFFu, h32 = (uint32_t)h;
+    bool done = false;
+    for (uint32_t k = threadIdx.x + 1; k < kFindWin; ++k) {
+        const uint32_t rj = s_ref[k];
+        if ((rj & 0x7FFFFFFFu) != ref_tag || s_pos[k] >= a.end) { done = true; break; }     // coordinate sorted: nothing further can overlap A
+        if (s_h[k] == h32 && !(rj >> 31)) link_if_mates(U, desc, hash, a, h, i, i0 + k, mate, n_partners);
+    }
+    if (!done)
+        for (uint64_t j = i0 + kFindWin; j < n; ++j) {
+            const RecDesc b = desc[j];
+            if (rec_ref[j] != ref || b.pos >= a.end) break;
+            if (hash[j] == h) link_if_mates(U, desc, hash, a, h, i, j, mate, n_partners);
+        }
+}
+
+// Second pass, only when some record has more than one partner: up to three partners per record in ext[3 i ..],
+// in no particular order (n_partners is counted again; a fourth partner only raises the count).
+__global__ __launch_bounds__(kMateThreads) void k_find_partners(const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc,
+                                                                 const uint64_t* __restrict__ hash, const int32_t* __restrict__ rec_ref,
+                                                                 uint64_t n, uint32_t* ext, uint32_t* n_partners) {
     const uint64_t i = (uint64_t)blockIdx.x * kMateThreads + threadIdx.x;
     if (i >= n) return;
     const RecDesc a = desc[i];
@@ -61,12 +129,11 @@ __global__ __launch_bounds__(kMateThreads) void k_find_mates(const uint8_t* __re
     const int32_t ref = rec_ref[i];
     for (uint64_t j = i + 1; j < n; ++j) {
         const RecDesc b = desc[j];
-        if (rec_ref[j] != ref || b.pos >= a.end) break;          // coordinate sorted: nothing further can overlap A
+        if (rec_ref[j] != ref || b.pos >= a.end) break;
         if (b.kind != 0 && hash[j] == h && b.sample == a.sample && b.end > a.pos && same_name(U, a, b)) {
-            mate[i] = (uint32_t)j;
-            mate[j] = (uint32_t)i;
-            atomicAdd(&n_partners[i], 1u);
-            atomicAdd(&n_partners[j], 1u);
+            const uint32_t si = atomicAdd(&n_partners[i], 1u), sj = atomicAdd(&n_partners[j], 1u);
+            if (si < 3u) ext[3 * i + si] = (uint32_t)j;
+            if (sj < 3u) ext[3 * j + sj] = (uint32_t)i;
         }
     }
 }
@@ -116,11 +183,72 @@ __device__ Cursor state_at(const uint8_t* U, const RecDesc& d, int32_t p) {
     return c;
 }
 
+// What record A (index ia) with two or three same-name partners does along its span, wave-uniform: the span is cut at
+// the partners' starts and ends into at most seven intervals of constant company; in each, the records covering it pair
+// up in file order, which gives A's partner there (or none).  A's status is `none` before its first paired column,
+// `detected` from there until the first column at which it is alone again, `past` ever after (depth.d:355-371).
+struct MultiPlan {
+    int32_t cut[8];          // interval k = [cut[k], cut[k + 1])
+    uint32_t partner[7];     // index of A's partner in interval k, 0xFFFFFFFF = alone
+    int n_iv;
+    int32_t first_paired, first_alone_again;      // columns; INT32_MAX when there is none
+    bool too_many;           // four or more same-name records cover some column
+};
+
+__device__ MultiPlan plan_multi(const RecDesc* __restrict__ desc, uint32_t ia, const RecDesc& a, const uint32_t* __restrict__ ext, uint32_t np) {
+    MultiPlan P;
+    uint32_t pi[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    int32_t pb[3] = {0, 0, 0}, pe[3] = {0, 0, 0};
+    const uint32_t n = np < 3u ? np : 3u;
+    for (uint32_t k = 0; k < n; ++k) {
+        pi[k] = ext[3 * (size_t)ia + k];
+        const RecDesc b = desc[pi[k]];
+        pb[k] = b.pos; pe[k] = b.end;
+    }
+    // breakpoints inside (a.pos, a.end), sorted, duplicates removed
+    int32_t c[8];
+    int nc = 0;
+    c[nc++] = a.pos;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (pb[k] > a.pos && pb[k] < a.end) c[nc++] = pb[k];
+        if (pe[k] > a.pos && pe[k] < a.end) c[nc++] = pe[k];
+    }
+    c[nc++] = a.end;
+    for (int x = 1; x < nc; ++x)
+        for (int y = x; y > 0 && c[y] < c[y - 1]; --y) { const int32_t t = c[y]; c[y] = c[y - 1]; c[y - 1] = t; }
+    int m = 0;
+    for (int x = 0; x < nc; ++x) if (m == 0 || c[x] != P.cut[m - 1]) P.cut[m++] = c[x];
+    P.n_iv = m - 1;
+    P.too_many = np > 3u;
+    P.first_paired = 0x7FFFFFFF;
+    P.first_alone_again = 0x7FFFFFFF;
+    for (int v = 0; v < P.n_iv; ++v) {
+        const int32_t q = P.cut[v];                   // company is constant on the interval: test its first column
+        // records covering q, in file order: rank of A and its neighbours
+        uint32_t before = 0, total = 1, prev = 0xFFFFFFFFu, next = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < n; ++k) {
+            if (q < pb[k] || q >= pe[k]) continue;
+            ++total;
+            if (pi[k] < ia) { ++before; if (prev == 0xFFFFFFFFu || pi[k] > prev) prev = pi[k]; }
+            else if (next == 0xFFFFFFFFu || pi[k] < next) next = pi[k];
+        }
+        if (total >= 4u) P.too_many = true;
+        uint32_t partner = 0xFFFFFFFFu;
+        if (before & 1u) partner = prev;              // second of a pair
+        else if (before + 1u < total) partner = next; // first of a pair
+        P.partner[v] = partner;
+        if (partner != 0xFFFFFFFFu) { if (P.first_paired == 0x7FFFFFFF) P.first_paired = q; }
+        else if (P.first_paired != 0x7FFFFFFF && P.first_alone_again == 0x7FFFFFFF) P.first_alone_again = q;
+    }
+    return P;
+}
+
 template <bool kSpan>
 __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ mate,
     const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active,
     const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq,
+    const uint32_t* __restrict__ ext, const uint32_t* __restrict__ n_partners, uint32_t* __restrict__ too_many,
     uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t s7 = S * 7;
@@ -137,18 +265,56 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T), te = ts + (int32_t)T;
     const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // one record per wave iteration; every lane owns one reference position of it per pass
-    for (uint32_t ri = r_lo + wave; ri < r_hi; ri += kMateThreads / 64) {
+    // One record per QUARTER wave and iteration, every lane one reference position of it per pass: a 150-base read
+    // fills 16 lanes ten times over (94 % of the lanes busy, 78 % with 64 lanes per read), and the chain of dependent
+    // loads a record needs -- descriptor -> mate index -> mate's descriptor -> both reads' bytes -- is in flight for
+    // four records per wave instead of one.
+    const uint32_t lane = threadIdx.x & 15u, quarter = threadIdx.x >> 4;
+    for (uint32_t ri = r_lo + quarter; ri < r_hi; ri += kMateThreads / 16) {
         const RecDesc a = desc[ri];
         if (a.kind == 0 || a.pos >= te || a.end <= ts) continue;
+        const uint32_t sample = S > 1 ? a.sample : 0u;
+        const int32_t p0 = a.pos > ts ? a.pos : ts, p1 = a.end < te ? a.end : te;
+        const uint32_t np = ext ? n_partners[ri] : 0u;
+        if (np >= 2u) {
+            // ---- two or three same-name partners: pairing and status per interval of constant company ----------------
+            const MultiPlan P = plan_multi(desc, ri, a, ext, np);
+            if (P.too_many) { if (lane == 0) atomicOr(too_many, 1u); continue; }
+            for (int32_t p = p0 + (int32_t)lane; p < p1; p += 16) {
+                const Cursor ca = state_at(U, a, p);
+                if (ca.kind == 0) continue;
+                if (kSpan) atomicAdd(&spn[p - ts], 1u);
+                int v = 0;
+                while (v + 1 < P.n_iv && p >= P.cut[v + 1]) ++v;
+                const uint32_t mi2 = P.partner[v];
+                // processed on its own unless `detected`: paired now or earlier, and never alone in between
+                uint32_t times = (p >= P.first_paired && p < P.first_alone_again) ? 0u : 1u;
+                if (mi2 != 0xFFFFFFFFu) {
+                    const RecDesc b2 = desc[mi2];
+                    const Cursor cb = state_at(U, b2, p);
+                    if (cb.kind != 0) {
+                        const bool a_first = ri < mi2;
+                        const Cursor& c1 = a_first ? ca : cb;
+                        const Cursor& c2 = a_first ? cb : ca;
+                        const uint32_t q1 = a_first ? a.mapq : b2.mapq, q2 = a_first ? b2.mapq : a.mapq;
+                        bool first_wins;
+                        if (c1.kind != 1 || c2.kind != 1) first_wins = q1 > q2;
+                        else first_wins = c1.qual > c2.qual;
+                        if (first_wins == a_first) ++times;          // the better mate of the pair is processed (once more)
+                    }
+                }
+                if (!times) continue;
+                uint32_t* cp = &cnt[pos_dw_m((uint32_t)(p - ts), sub_dw, s7) + sample * 7];
+                if (ca.kind == 1) { if (ca.qual >= min_bq) atomicAdd(&cp[base5_m(ca.nib)], times); }
+                else atomicAdd(&cp[ca.kind == 2 ? 5 : 6], times);
+            }
+            continue;
+        }
         const uint32_t mi = mate[ri];
         RecDesc b;
         b.kind = 0; b.pos = 0; b.end = 0; b.rec_off = 0; b.l_seq = 0; b.n_cigar = 0; b.l_name = 0; b.q_start = 0; b.sample = 0; b.mapq = 0;
         if (mi != 0xFFFFFFFFu) b = desc[mi];
-        const uint32_t sample = S > 1 ? a.sample : 0u;
-        const int32_t p0 = a.pos > ts ? a.pos : ts, p1 = a.end < te ? a.end : te;
-        for (int32_t p = p0 + (int32_t)lane; p < p1; p += 64) {
+        for (int32_t p = p0 + (int32_t)lane; p < p1; p += 16) {
             const Cursor ca = state_at(U, a, p);
             if (ca.kind == 0) continue;
             if (kSpan) atomicAdd(&spn[p - ts], 1u);
@@ -268,20 +434,28 @@ void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t
     SBX_HIP(hipGetLastError());
 }
 
+void launch_find_partners(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
+                          uint32_t* d_ext, uint32_t* d_n_partners, hipStream_t stream) {
+    if (!n_records) return;
+    hipLaunchKernelGGL(k_find_partners, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
+                       d_U, d_desc, d_hash, d_rec_ref, n_records, d_ext, d_n_partners);
+    SBX_HIP(hipGetLastError());
+}
+
 void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_mate, const uint32_t* d_tile_lo,
                              const uint32_t* d_tile_hi, const uint32_t* d_active, uint32_t n_active, const uint32_t* d_tile_base,
-                             int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters,
-                             uint32_t* d_span, hipStream_t stream) {
+                             int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, const uint32_t* d_ext,
+                             const uint32_t* d_n_partners, uint32_t* d_too_many, uint32_t* d_counters, uint32_t* d_span, hipStream_t stream) {
     if (!n_active) return;
     size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0);
     if (d_span) {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate_mates<true>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,
-                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_ext, d_n_partners, d_too_many, d_counters, d_span);
     } else {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate_mates<false>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,
-                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_counters, d_span);
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_ext, d_n_partners, d_too_many, d_counters, d_span);
     }
     SBX_HIP(hipGetLastError());
 }

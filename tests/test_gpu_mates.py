@@ -2,6 +2,7 @@
 restatement of depth.d:319-399,495-556 with column-order tie breaking; no reference golden pins base
 mode -m -- SURVEY.md 8c).  Fixture: the reference's own, otherwise unused, mate_overlaps_1_3M_4M.bam."""
 import os
+import random
 
 import numpy as np
 import pytest
@@ -76,14 +77,51 @@ def test_mate_rules_on_hand_made_pairs(tmp_path):
         assert run_cli(args + [p]) == run_oracle(args + [p]), args
 
 
-def test_three_overlapping_same_name_records_are_rejected(tmp_path):
-    refs = [("c1", 2000)]
-    raw = [bg.make_record(0, 100 + 10 * i, "60M", "ACGT" * 15, 30, name="trio", mapq=60) for i in range(3)]
-    p = str(tmp_path / "trio.bam")
-    bg.write_bam(p, refs, raw)
-    r = run_cli(["base", "-m", p], check=False)
+def test_name_groups_of_three_follow_the_reference_loop(tmp_path):
+    """Same-name records beyond a pair (supplementary alignments): at a column they pair up in file order and the odd one is
+    counted on its own (depth.d:343-377); a record that is paired, alone again and paired a second time is processed on its
+    own AND through its pair (status `past`, depth.d:355-371,522-532).  Base mode follows that; region / window mode and four
+    or more records over one column are rejected."""
+    rng = random.Random(5)
+    refs = [("c1", 4000)]
+    seq = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    qual = lambda n: [rng.choice([5, 12, 22, 30, 38]) for _ in range(n)]
+    raw = []
+    def rec(pos, cigar, n, name, mapq=60):
+        raw.append((pos, bg.make_record(0, pos, cigar, seq(n), qual(n), name=name, mapq=mapq)))
+    # trio, all three overlapping: (1st, 2nd) pair, the third alone, then (2nd, 3rd) once the first has ended
+    rec(100, "60M", 60, "trio"); rec(110, "60M", 60, "trio", 40); rec(120, "70M", 70, "trio", 50)
+    # chain: X - R - Z, X and Z do not overlap: R is paired, alone, paired again
+    rec(400, "50M", 50, "chain"); rec(420, "180M", 180, "chain", 30); rec(500, "150M", 150, "chain", 20)
+    # the long record first, two short ones inside it, with an indel and a skip
+    rec(900, "40M10D40M200N20M", 100, "nest"); rec(910, "30M", 30, "nest", 10); rec(1000, "60M", 60, "nest", 55)
+    # trio where the second record ends first
+    rec(1500, "100M", 100, "t2"); rec(1510, "20M", 20, "t2"); rec(1520, "100M", 100, "t2")
+    # an ordinary pair and an unrelated read next to them
+    rec(2000, "80M", 80, "pair"); rec(2030, "80M", 80, "pair"); rec(2040, "50M", 50, "solo")
+    raw.sort(key=lambda t: t[0])
+    p = str(tmp_path / "groups.bam")
+    bg.write_bam(p, refs, [r for _, r in raw])
+    import sambamba_amd
+    for q in (0, 20):
+        with sambamba_amd.Depth(p) as d:
+            d.set_params(min_bq=q, fix_mate_overlaps=True)
+            d.run()
+            got = d.base_counters(0, 0, 4000)
+        want = oracle_base_counters(p, 0, 0, 4000, min_bq=q, fix_mate=True)
+        assert np.array_equal(got, want), q
+    for args in (["base", "-m"], ["base", "-m", "-q", "20", "-c", "0"]):
+        assert run_cli(args + [p]) == run_oracle(args + [p]), args
+    # region / window statistics are derived for pairs only
+    r = run_cli(["window", "-w", "500", "-m", p], check=False)
     assert r.returncode == 1 and b"same name" in r.stderr
-    assert run_cli(["base", p]) == run_oracle(["base", p])      # without -m the file is fine
+    # four records over one column
+    raw4 = [bg.make_record(0, 100 + 10 * i, "60M", "ACGT" * 15, 30, name="quad", mapq=60) for i in range(4)]
+    p4 = str(tmp_path / "quad.bam")
+    bg.write_bam(p4, refs, raw4)
+    r = run_cli(["base", "-m", p4], check=False)
+    assert r.returncode == 1 and b"same name" in r.stderr
+    assert run_cli(["base", p4]) == run_oracle(["base", p4])      # without -m the file is fine
 
 
 def test_region_mode_with_m_small_genome():
