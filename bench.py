@@ -515,7 +515,7 @@ def main():
         # algorithmic bytes per pass of rank 0
         alg = {"huffman_decode": comp + 0.57 * unc,          # compressed in; literal + match-entry streams out (~0.57 B per output byte)
                "lz77_resolve": 0.57 * unc + unc,              # token streams in; inflated bytes out
-               "record_index": unc + nrec * 32,               # the inflated stream read once, 32-B descriptor written per record
+               "record_index": nrec * (36 + 32),              # 36-B fixed part read + 32-B descriptor written per record
                "decode_accumulate": unc + cnt}               # record bytes read once + 28 B/position/sample written once
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(alg[dom] / (kern[dom] * 1e-3) / 1e9, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
