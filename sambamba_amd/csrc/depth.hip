@@ -307,13 +307,15 @@ __device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 4) & 7u)
 
 __device__ __forceinline__ uint32_t nibble_swap(uint32_t x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
 
-template <bool kSpan, bool kQual>
+template <bool kSpan, bool kQual, bool kOneSample>
 __global__ __launch_bounds__(kAccThreads) void k_accumulate16(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
     const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, uint32_t n_active,
-    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq, uint32_t deep_thr,
+    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S_arg, uint32_t min_bq, uint32_t deep_thr,
     uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t S = kOneSample ? 1u : S_arg;      // (one sample -- a single-sample BAM or --combined -- is the common case:
+                                                     //  the per-base address arithmetic loses its multiplications)
     // XCD-aware slot: the grid has 8 * per workgroups
     const uint32_t per = gridDim.x >> 3;
     const uint32_t slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
@@ -571,8 +573,13 @@ void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t
             hipLaunchKernelGGL(kern, grid, block, lds, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base, n_ref,
                                tile_pos, n_samples, min_bq, deep_thr, d_counters, d_span);
         };
-        if (d_span) { if (min_bq) go(k_accumulate16<true, true>); else go(k_accumulate16<true, false>); }
-        else { if (min_bq) go(k_accumulate16<false, true>); else go(k_accumulate16<false, false>); }
+        if (n_samples == 1) {
+            if (d_span) { if (min_bq) go(k_accumulate16<true, true, true>); else go(k_accumulate16<true, false, true>); }
+            else { if (min_bq) go(k_accumulate16<false, true, true>); else go(k_accumulate16<false, false, true>); }
+        } else {
+            if (d_span) { if (min_bq) go(k_accumulate16<true, true, false>); else go(k_accumulate16<true, false, false>); }
+            else { if (min_bq) go(k_accumulate16<false, true, false>); else go(k_accumulate16<false, false, false>); }
+        }
         SBX_HIP(hipGetLastError());
     }
     if (!n_deep) return;
