@@ -334,6 +334,14 @@ class Depth:
         fn = WRITE_FN(cb)
         self._check(self._L.sbx_stream_base_rows(self._ctx, ref_id, beg, end, float(min_cov), float(max_cov), int(annotate), fn, None))
 
+    def next_active_range(self, ref_id, start):
+        """[beg, end) of the next stretch of tiles at or after `start` that hold admitted reads, or None (sbx_next_active_range)."""
+        b, e = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.sbx_next_active_range(self._ctx, ref_id, int(start), C.byref(b), C.byref(e)))
+        if b.value == 0xFFFFFFFFFFFFFFFF:
+            return None
+        return int(b.value), int(e.value)
+
     def base_counters(self, ref_id, beg, end, with_covered=False):
         S = self.n_samples_eff
         out = np.zeros((end - beg, S, NCOUNTERS), dtype=np.uint32)

@@ -686,10 +686,12 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
 //     ... of a BAM stream -- are resolved LDS -> LDS in rounds that cost an LDS round trip each;
 //   * the finished span of the batch is written to HBM once, contiguous and coalesced.
 constexpr int kResThreads = 256;
-constexpr uint32_t kHist = 2048;            // bytes of history guaranteed to be in LDS
-constexpr uint32_t kSpanMax = 1536;         // output bytes per batch (a batch is <= 64 entries AND <= this)
-constexpr uint32_t kCap = 4608;             // LDS bytes per wave: kHist + slide hysteresis + kSpanMax
-constexpr uint32_t kWaveLds = kCap + 16;
+// Window geometry (template parameters of the kernel): kHist = bytes of history guaranteed to be in LDS, kSpanMax = output
+// bytes per batch (a batch is <= 64 entries AND <= this), kCap = LDS bytes per wave = kHist + slide hysteresis (1 KiB) +
+// kSpanMax.  A sweep on config 2 (profiles/round2/README.md): 1 KiB / 1 KiB, 1 / 1.5, 2 / 1 and 2 / 1.5 KiB are within
+// 0.1 ms of each other (23.9-24.0 ms); anything larger costs occupancy (2 / 2: 25.3, 3 / 1.5: 25.5, 4 / 2 KiB: 29.8 ms) --
+// the kernel is bound by VALU issue, not by where its bytes come from.
+constexpr uint32_t kHistDefault = 2048, kSpanDefault = 1536;
 
 // inclusive prefix sum over the 64 lanes: four row-shift steps inside each row of 16 lanes, then the row
 // totals are broadcast across rows (DPP row_bcast15 / row_bcast31) -- VALU only, no LDS crossbar trips
@@ -778,6 +780,7 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
     }
 }
 
+template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -787,6 +790,7 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
     if (b >= n_blocks) return;
     if (status[b] != INF_OK) return;
+    constexpr uint32_t kCap = kHist + 1024u + kSpanMax, kWaveLds = kCap + 16u;
     uint8_t* buf = smem + wv * kWaveLds;
     const uint64_t oo = out_off[b];
     const uint8_t* lit = lit_stream + lit_off(oo, block0 + b);
@@ -929,8 +933,9 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
     {
         const uint32_t per = kResThreads / 64;
         dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
-        hipLaunchKernelGGL(k_lz77_resolve, grid, block, (kResThreads / 64) * kWaveLds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks, block0,
-                           d_out, d_status);
+        const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
+        hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks,
+                           block0, d_out, d_status);
         SBX_HIP(hipGetLastError());
     }
 }

@@ -94,13 +94,21 @@ def _max_flags(dist, flags):
 
 
 def first_column_in(d, ref, beg, end):
-    """Position of the first pileup column of the resident run inside [beg, end) of contig `ref`, or None."""
-    step = 1 << 16
-    for b in range(beg, end, step):
-        _, cov = d.base_counters(ref, b, min(end, b + step), with_covered=True)
-        nz = np.flatnonzero(cov)
-        if len(nz):
-            return b + int(nz[0])
+    """Position of the first pileup column of the resident run inside [beg, end) of contig `ref`, or None.  Only tiles
+    that hold admitted reads are looked at (sbx_next_active_range), a few kilobytes at a time."""
+    pos = beg
+    while pos < end:
+        r = d.next_active_range(ref, pos)
+        if r is None or r[0] >= end:
+            return None
+        b, e = max(r[0], pos), min(r[1], end)
+        step = 1 << 13
+        for x in range(b, e, step):
+            _, cov = d.base_counters(ref, x, min(e, x + step), with_covered=True)
+            nz = np.flatnonzero(cov)
+            if len(nz):
+                return x + int(nz[0])
+        pos = e
     return None
 
 
