@@ -39,6 +39,17 @@ def _raw_deflate(payload, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8, flus
     return out
 
 
+def _records(rng, n, size):
+    """n records of `size` bytes, each a copy of the previous one with a few bytes changed (what a BAM stream looks like)."""
+    rec = bytearray(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+    out = bytearray()
+    for _ in range(n):
+        for _k in range(int(rng.integers(1, 6))):
+            rec[int(rng.integers(0, size))] = int(rng.integers(0, 256))
+        out += rec
+    return bytes(out[:65280])
+
+
 def _cases():
     rng = np.random.default_rng(1234)
     text = (b"ACGTTTGACCA" * 4000)[:40000]
@@ -58,6 +69,13 @@ def _cases():
         ("many_blocks_memlevel1", quals, dict(level=6, mem=1)),
         ("full_flush_stored_markers", text, dict(level=6, flush_every=3000)),
         ("max_distance", rand[:32768] + rand[:32768 - 7], dict(level=9)),
+        # match chains inside one batch of the resolver: every "record" copies most of its bytes from the previous one, which
+        # copied them from the one before; short matches over a four-letter alphabet reference recent output densely
+        ("record_chain", _records(rng, 230, 283), dict(level=6)),
+        ("record_chain_short", _records(rng, 1200, 41), dict(level=9)),
+        ("acgt_random", rng.choice(np.frombuffer(b"ACGT", np.uint8), 65280).tobytes(), dict(level=6)),
+        ("packed_bases", rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88],
+                                             dtype=np.uint8), 65280).tobytes(), dict(level=6)),
     ]
     return cases
 
@@ -103,3 +121,16 @@ def test_inflate_rejects_wrong_isize():
     c = _raw_deflate(payload)
     with pytest.raises(sambamba_amd.SbxError):
         sambamba_amd.inflate_blocks(np.frombuffer(c, np.uint8), [0], [len(c)], [len(payload) - 1], [0], len(payload))
+
+
+def test_inflate_bench_like_bam_bit_exact(tmp_path):
+    """Every block of a BAM with the bench's statistics (tools/gen_bam: 41 % of the literal/length symbols are matches of 8
+    bytes on average, record-to-record chains, short far matches): ~800 BGZF blocks against zlib."""
+    import sambamba_amd
+    from tests.util import gen_bam
+    path = gen_bam(str(tmp_path / "b.bam"), "chrB:1200000", coverage=30, seed=77)
+    data, co, cl, isz, oo, total = scan_bgzf(path)
+    assert len(cl) > 500
+    got = sambamba_amd.inflate_blocks(data, co, cl, isz, oo, total)
+    want = oracle_inflate_all(path)
+    assert got.shape == want.shape and np.array_equal(got, want)
