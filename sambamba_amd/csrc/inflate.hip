@@ -93,7 +93,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // loads that ALL lanes issue in the same iteration (`service`), and a chunk loaded at one event is
 // only written to the ring at the next one -- so the vmcnt wait the compiler puts in front of that
 // write finds the load long finished, and no other VMEM result is ever consumed in the decode loops.
-constexpr int kLitPerIter = 3;       // literal/length symbols decoded per lane and loop iteration (K1a)
+constexpr int kLitPerIter = 2;       // literal/length symbols decoded per lane and loop iteration (K1a)
 constexpr int kRingDwords = 8;
 constexpr int kRingLow = 3;          // an event is triggered when some lane has <= this many dwords left
 
