@@ -351,9 +351,23 @@ static void bgzf_compress(const uint8_t* src, uint32_t n, int level, std::vector
         dst.resize(total);
         return;
     }
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    // one deflate state per thread, reset per block: deflateInit2 allocates ~270 KB, which glibc serves with mmap --
+    // 256 threads doing that once per 64 KiB block serialise on the address-space lock (44 s for chr1 in round 2)
+    struct ZState {
+        z_stream zs;
+        int level = -100;
+        ~ZState() { if (level != -100) deflateEnd(&zs); }
+    };
+    thread_local ZState st;
+    z_stream& zs = st.zs;
+    if (st.level != level) {
+        if (st.level != -100) deflateEnd(&zs);
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { fprintf(stderr, "deflateInit2 failed\n"); exit(1); }
+        st.level = level;
+    } else {
+        deflateReset(&zs);
+    }
     zs.next_in = (Bytef*)src;
     zs.avail_in = n;
     zs.next_out = dst.data() + 18;
@@ -361,7 +375,6 @@ static void bgzf_compress(const uint8_t* src, uint32_t n, int level, std::vector
     int rc = deflate(&zs, Z_FINISH);
     if (rc != Z_STREAM_END) { fprintf(stderr, "deflate failed\n"); exit(1); }
     uint32_t clen = (uint32_t)zs.total_out;
-    deflateEnd(&zs);
     uint32_t total = 18 + clen + 8;
     if (total > 65536) { fprintf(stderr, "block too large\n"); exit(1); }
     static const uint8_t hdr[12] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0};
