@@ -8,13 +8,16 @@ synthetic coordinate-sorted BAM of BASELINE.json configs[1] (chr1, L=248,956,422
 paired reads), whose compressed bytes are already resident in HBM when the timed
 region starts.
 
-N == 1: the whole BAM on one GPU.  N > 1 (default --mode auto): the path partitions by reference position and has no
-data-path collective, so the timed region keeps the per-GPU work fixed ("scaling": "weak"): every rank runs the
-chr1-sized workload on its own GPU and `value` is the aggregate.  The same invocation then cuts that ONE BAM into N
-position slices (sambamba_amd.shard.plan_position_shards: every rank fetches the reads overlapping its slice through
-the BAI and clips its contributions to the slice), times that too and reports it as `sharded_one_bam` (strong
-scaling, parity-checked against the oracle on every rank).  --mode shard makes the sharded form the headline;
---mode replicas skips it.
+N == 1: the whole BAM on one GPU.  N > 1 (default --mode auto == shard): ONE BAM with N chr1-sized contigs (N x 49.8 M
+reads, the per-GPU work of configs[1] kept fixed: "scaling": "weak") is sharded over the ranks by reference position
+(sambamba_amd.shard.plan_position_shards -- with equal contigs every rank owns one): every rank fetches the reads
+overlapping its slice through the BAI, keeps the BGZF blocks of its slice resident in its HBM, clips its contributions to
+the slice and checks windows of its slice against the oracle.  The path has no data-path collective; torch.distributed
+(RCCL) carries the barrier, the max-over-ranks time and the read totals.  Side fields of the same line: `strong_one_contig`
+(the single chr1 BAM cut into N position slices: strong scaling, bounded below by one K1a residency)
+and `allreduce_option` (reads partitioned by start position, per-position counters summed with an RCCL all-reduce: the
+alternative north_star names, measured next to the collective-free form).  --mode strong makes the one-contig cut the
+headline; --mode replicas runs the full chr1 BAM on every GPU (round 2's headline).
 
 Other BASELINE configs (builder-run lines, committed under profiles/): --config 3 (window -w 1000 on the
 25-contig genome, streamed in batches), --config 4 (region -L exome BED on the same BAM), --config 5
@@ -68,18 +71,44 @@ def tmp_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
 
 
-def workload(args):
-    """(contigs string, coverage, seed, extra gen_bam options, description) of the selected BASELINE config."""
+def workload(args, copies=1):
+    """(contigs string, coverage, seed, extra gen_bam options, description) of the selected BASELINE config.
+    copies > 1 (configs 2 and 5, N GPUs): that many contigs of the config's length in ONE BAM -- the per-GPU work of the
+    config kept fixed while the BAM is sharded over the ranks by contig."""
     sc = args.scale
     if args.config == 2:
-        return "chr1:%d" % args.length, args.coverage, 0x5A4D0002, [], "configs[1]"
+        return ",".join("chr%d:%d" % (i + 1, args.length) for i in range(copies)), args.coverage, 0x5A4D0002, [], "configs[1]"
     if args.config in (3, 4):
         contigs = ",".join("%s:%d" % (n, max(2000, int(l * sc))) for n, l in zip(GRCH38_NAMES, GRCH38))
         return contigs, args.coverage, 0x5A4D0003, [], "configs[%d]" % (args.config - 1)
     if args.config == 5:
-        return "chr1:%d" % max(2000, int(50_000_000 * sc)), 300.0 if args.coverage == 30.0 else args.coverage, 0x5A4D0005, \
+        L = max(2000, int(50_000_000 * sc))
+        return ",".join("chr%d:%d" % (i + 1, L) for i in range(copies)), 300.0 if args.coverage == 30.0 else args.coverage, 0x5A4D0005, \
             ["--insert-mean", "250", "--insert-sd", "40", "--tie-free-overlaps"], "configs[4]"
     raise SystemExit("unknown --config")
+
+
+def bam_path(contigs, coverage, seed, level, codec, extra):
+    key = "%s_%g_%x_%d_%s_%s" % (contigs, coverage, seed, level, codec, " ".join(extra))
+    return os.path.join(tmp_dir(), "sbx_bench_%s.bam" % hashlib.sha1(key.encode()).hexdigest()[:12])
+
+
+def make_room(keep, need_bytes):
+    """Drop cached bench BAMs of other workloads when the scratch directory is short of space."""
+    import glob
+    import shutil
+    try:
+        if shutil.disk_usage(tmp_dir()).free > need_bytes:
+            return
+    except OSError:
+        return
+    for f in glob.glob(os.path.join(tmp_dir(), "sbx_bench_*.bam")):
+        if f not in keep:
+            for g in (f, f + ".bai", f + ".json", f + ".exome.bed"):
+                try:
+                    os.remove(g)
+                except OSError:
+                    pass
 
 
 def generate(path, contigs, coverage, seed, level, codec, extra):
@@ -236,6 +265,194 @@ def cli_e2e(bam, mode_args, reads):
                     "pipeline, device text formatting, pinned double-buffered D2H, write), best of 3" % " ".join(mode_args)}
 
 
+class Job:
+    """One BAM opened on this rank's GPU with the parameters of a BASELINE config, and the passes over it."""
+
+    def __init__(self, args, path, info, dev_index, rank, world, dist, seed):
+        import sambamba_amd
+        from sambamba_amd import shard as shardmod
+        self.args, self.path, self.info, self.rank, self.world, self.dist, self.seed = args, path, info, rank, world, dist, seed
+        self.shardmod = shardmod
+        SBX = sambamba_amd
+        d = self.d = sambamba_amd.Depth(path, device=dev_index)
+        self.mode_args, self.min_bq, self.fix_mate, self.regions = ["base"], 0, False, None
+        if args.config == 2:
+            d.set_params()             # depth base, default filter, -q 0
+        elif args.config == 3:
+            d.set_params(mode=SBX.SBX_MODE_WINDOW, window=1000)
+            self.mode_args = ["window", "-w", "1000"]
+        elif args.config == 4:
+            bed = path + ".exome.bed"
+            if rank == 0:
+                exome_bed(bed, d.ref_names, d.ref_lengths, scale=args.scale)
+            if dist:
+                dist.barrier()
+            d.set_params(mode=SBX.SBX_MODE_REGION)
+            self.regions = shardmod.read_bed_regions(bed, d.ref_names)
+            self.mode_args = ["region", "-L", bed]
+        elif args.config == 5:
+            self.min_bq, self.fix_mate = 20, True
+            d.set_params(min_bq=20, fix_mate_overlaps=True)
+            self.mode_args = ["base", "-m", "-q", "20"]
+        self.ref_lengths = d.ref_lengths
+        self.window_rows = 0
+
+    def share(self, sharded):
+        """(my, plan): `my` = this rank's position slice [(ref, beg, end)] of the sharded BAM, or None with `plan` = the
+        batches of the whole BAM."""
+        d, args, regions, shardmod = self.d, self.args, self.regions, self.shardmod
+        if sharded:
+            align = 1000 if args.config == 3 else 1024
+            mine = shardmod.plan_position_shards(self.ref_lengths, self.world, align=align)[self.rank]
+            if regions is not None:
+                mine = shardmod.clip_regions_to_shards(regions, mine)
+            return mine, None
+        if args.config in (3, 4) and regions is None:
+            d.preload()
+            return None, d.plan_batches()
+        if regions is not None:
+            d.set_regions(shardmod.merge_regions(regions))
+            return None, [None]
+        d.preload()                    # compressed BAM resident in HBM before the timed region
+        return None, [None]
+
+    def one_pass(self, my, plan):
+        """One pass of the hot path over this rank's share; returns the list of per-run statistics."""
+        d, args, regions, ref_lengths = self.d, self.args, self.regions, self.ref_lengths
+        sts = []
+        if my is not None:
+            if regions is not None:
+                d.set_regions(self.shardmod.merge_regions(my))
+                sts.append(d.run())
+                if my:
+                    d.region_stats(my)
+            else:
+                for ref, beg, end in my:
+                    sts.append(d.run_interval(ref, beg, end))
+                    if args.config == 3:
+                        n = (min(end, ref_lengths[ref]) // 1000) - beg // 1000
+                        if n > 0:
+                            d.window_stats(ref, beg // 1000, n)
+                            self.window_rows += n
+            return sts
+        for b in plan:
+            if b is None:
+                sts.append(d.run())
+                if regions is not None:
+                    d.region_stats(regions)
+            else:
+                sts.append(d.run_batch(b[0], b[1]))
+                if args.config == 3:
+                    for r in range(b[0], b[0] + b[1]):
+                        n = ref_lengths[r] // 1000
+                        if n:
+                            d.window_stats(r, 0, n)
+                            self.window_rows += n
+        return sts
+
+    def timed(self, sharded, warmup, steps, sync, red_dev):
+        """warmup + `steps` timed passes (barrier + device synchronisation on both sides, MAX over the ranks)."""
+        import torch
+        dist = self.dist
+        my, plan = self.share(sharded)
+        for _ in range(warmup):
+            self.one_pass(my, plan)
+        sync()
+        t0 = time.perf_counter()
+        ks = []
+        for _ in range(steps):
+            ks.append(self.one_pass(my, plan))
+        sync()
+        el = time.perf_counter() - t0
+        lastp = ks[-1]
+        reads = float(sum(s["n_records"] for s in lastp))
+        adm = float(sum(s["n_admitted"] for s in lastp))
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            r = torch.tensor([reads, adm], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            reads, adm = float(r[0].item()), float(r[1].item())
+        return {"my": my, "plan": plan, "kstats": ks, "elapsed": el, "sum_reads": reads, "sum_adm": adm}
+
+    def parity(self, my, plan, n_windows):
+        """Device results of the LAST pass against the CPU oracle (every rank checks its own share)."""
+        import numpy as np
+        d, args, path, seed, rank = self.d, self.args, self.path, self.seed, self.rank
+        ref_lengths, regions = self.ref_lengths, self.regions
+        par = {"windows": 0, "ok": True, "mismatches": []}
+        if n_windows > 0 and args.config in (2, 5):
+            if my is not None:
+                ivs = [iv for iv in my][-1:]       # the last run of the pass left the last interval resident
+            else:
+                ivs = [(r, 0, ref_lengths[r]) for r in range(len(ref_lengths)) if ref_lengths[r] > 0]
+            if ivs:
+                n, bad = parity_windows(d, path, ivs, n_windows, seed ^ rank, min_bq=self.min_bq, fix_mate=self.fix_mate)
+                par = {"windows": n, "ok": not bad, "mismatches": bad[:4]}
+                ref, a, b = ivs[-1]
+                a2 = a + (b - a) // 3 // 1024 * 1024
+                b2 = min(b, a2 + 1_000_000)
+                md_got, md_want, nbytes = parity_text(d, path, d.ref_names[ref], ref, a2, b2, self.mode_args[1:])
+                par.update({"text_slab": [ref, a2, b2], "text_bytes": nbytes, "text_md5": md_got, "text_ok": md_got == md_want})
+                par["ok"] = par["ok"] and md_got == md_want
+        if n_windows > 0 and args.config in (3, 4) and my is None:
+            # window / region statistics against the oracle's `depth region -L chr:a-b` (a window is the region [k w, (k + 1) w);
+            # the reads come through the BAI, seconds per call).  Config 3 streams the genome in batches and only the last one is
+            # still resident after the timed region: the first and a middle batch are run once more for the check.
+            rng = random.Random(seed ^ 0x33)
+            checked, bad, where = 0, [], []
+            oracle = os.path.join(ROOT, "oracle", "depth_oracle")
+
+            def want_of(r, a, b):
+                out = subprocess.run([oracle, "region", "-L", "%s:%d-%d" % (d.ref_names[r], a + 1, b), path],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode().splitlines()
+                f = out[-1].split("\t")
+                return (int(f[3]), f[4])
+
+            if args.config == 3:
+                batches = [b for b in plan if b is not None]
+                pick = sorted(set([len(batches) - 1, 0, len(batches) // 2])) if batches else [None]
+                per = max(1, -(-n_windows // len(pick)))
+                for bi in reversed(pick):          # the last batch is resident: check it first
+                    if bi is None:
+                        refs_res = range(len(ref_lengths))
+                    else:
+                        lastb = batches[bi]
+                        refs_res = range(lastb[0], lastb[0] + lastb[1])
+                        if bi != len(batches) - 1:
+                            d.run_batch(lastb[0], lastb[1])
+                    cands = [r for r in refs_res if ref_lengths[r] >= 4000]
+                    for j in range(per):
+                        if not cands:
+                            break
+                        r = cands[rng.randrange(len(cands))]
+                        nwin = ref_lengths[r] // 1000
+                        k = nwin - 1 if j == 0 else rng.randrange(1, nwin - 1)       # the last full window of a contig, then random ones
+                        nr, nb, _cov = d.window_stats(r, k, 1)
+                        got = (int(nr[0][0]), "%g" % float(np.float32(nb[0][0]) / np.float32(1000)))
+                        want = want_of(r, k * 1000, (k + 1) * 1000)
+                        checked += 1
+                        where.append([int(bi) if bi is not None else -1, r, k])
+                        if got != want:
+                            bad.append([r, k, list(got), list(want)])
+            else:
+                picks = [regions[0], regions[len(regions) // 2], regions[-1]] + [regions[rng.randrange(len(regions))] for _ in range(max(0, n_windows - 3))]
+                nr, nb, _cov, _seen = d.region_stats(picks)
+                for j, (r, a, b) in enumerate(picks):
+                    got = (int(nr[j][0]), "%g" % float(np.float32(nb[j][0]) / np.float32(b - a)))
+                    want = want_of(r, a, b)
+                    checked += 1
+                    where.append([r, a, b])
+                    if got != want:
+                        bad.append([r, a, b, list(got), list(want)])
+            par = {"windows": checked, "ok": not bad, "mismatches": bad[:4], "checked": where[:32],
+                   "what": "readCount and meanCoverage of sampled %s against `depth_oracle region -L`%s" % (
+                       "windows" if args.config == 3 else "BED regions (first, middle, last of the BED + random ones)",
+                       " (batch index, contig, window; first / middle / last batch of the streamed genome)" if args.config == 3 else "")}
+        return par
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,7 +460,7 @@ def main():
                     help="passes in the timed region (default: ~10 s of device time on configs[1])")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=int(os.environ.get("SBX_BENCH_CONFIG", 2)), help="BASELINE.json config number (2..5)")
-    ap.add_argument("--mode", choices=["auto", "shard", "replicas"], default=os.environ.get("SBX_BENCH_MODE", "auto"))
+    ap.add_argument("--mode", choices=["auto", "shard", "strong", "replicas"], default=os.environ.get("SBX_BENCH_MODE", "auto"))
     ap.add_argument("--length", type=int, default=int(os.environ.get("SBX_BENCH_LEN", CHR1_LEN)),
                     help="contig length of config 2 (default: chr1; smaller values are for development only)")
     ap.add_argument("--scale", type=float, default=float(os.environ.get("SBX_BENCH_SCALE", 1.0)),
@@ -254,6 +471,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=int(os.environ.get("SBX_BENCH_CPU_READS", 3_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="N > 1: skip the strong-scaling / all-reduce side measurements")
     ap.add_argument("--parity-windows", type=int, default=8)
     args = ap.parse_args()
 
@@ -281,14 +499,19 @@ def main():
         ensure_built()
     if dist:
         dist.barrier()
-    import sambamba_amd
-    from sambamba_amd import shard as shardmod
 
-    contigs, coverage, seed, extra, cfg_name = workload(args)
-    key = "%s_%g_%x_%d_%s_%s" % (contigs, coverage, seed, args.level, args.codec, " ".join(extra))
-    path = os.path.join(tmp_dir(), "sbx_bench_%s.bam" % hashlib.sha1(key.encode()).hexdigest()[:12])
+    mode = args.mode
+    if mode == "auto":
+        mode = "shard"
+    if world == 1:
+        mode = "single"
+    # shard: ONE BAM holding one contig of the config's size per rank (configs 2, 5) or the genome (configs 3, 4)
+    copies = world if (mode == "shard" and args.config in (2, 5)) else 1
+    contigs, coverage, seed, extra, cfg_name = workload(args, copies)
+    path = bam_path(contigs, coverage, seed, args.level, args.codec, extra)
     if rank == 0:
         log("built; generating %s" % path)
+        make_room({path}, int(6e9) * copies * (13 if args.config in (3, 4) else 1))
         info = generate(path, contigs, coverage, seed, args.level, args.codec, extra)
         log("BAM ready: %d reads" % int(info["reads"]))
     if dist:
@@ -296,118 +519,20 @@ def main():
     if rank != 0:
         info = json.load(open(path + ".json"))
 
-    sharded = world > 1 and args.mode == "shard"
-    d = sambamba_amd.Depth(path, device=dev_index)
-    SBX = sambamba_amd
-    mode_args, min_bq, fix_mate = ["base"], 0, False
-    regions = None
-    if args.config == 2:
-        d.set_params()             # depth base, default filter, -q 0
-    elif args.config == 3:
-        d.set_params(mode=SBX.SBX_MODE_WINDOW, window=1000)
-        mode_args = ["window", "-w", "1000"]
-    elif args.config == 4:
-        bed = path + ".exome.bed"
-        if rank == 0:
-            exome_bed(bed, d.ref_names, d.ref_lengths, scale=args.scale)
-        if dist:
-            dist.barrier()
-        d.set_params(mode=SBX.SBX_MODE_REGION)
-        regions = shardmod.read_bed_regions(bed, d.ref_names)
-        mode_args = ["region", "-L", bed]
-    elif args.config == 5:
-        min_bq, fix_mate = 20, True
-        d.set_params(min_bq=20, fix_mate_overlaps=True)
-        mode_args = ["base", "-m", "-q", "20"]
-
-    # ---- the work of this rank: one pass = the runs of its share ---------------------------------------------------
-    ref_lengths = d.ref_lengths
-    window_rows = [0]
-
-    def share(sharded_):
-        """(my, plan): `my` = this rank's position slice [(ref, beg, end)] of ONE sharded BAM, or None with `plan` = the
-        batches of the whole BAM."""
-        if sharded_:
-            align = 1000 if args.config == 3 else 1024
-            mine = shardmod.plan_position_shards(ref_lengths, world, align=align)[rank]
-            if regions is not None:
-                mine = shardmod.clip_regions_to_shards(regions, mine)
-            return mine, None
-        if args.config in (3, 4) and regions is None:
-            d.preload()
-            return None, d.plan_batches()
-        if regions is not None:
-            d.set_regions(shardmod.merge_regions(regions))
-            return None, [None]
-        d.preload()                    # compressed BAM resident in HBM before the timed region
-        return None, [None]
-
-    def one_pass(my, plan):
-        """One pass of the hot path over this rank's share; returns the list of per-run statistics."""
-        sts = []
-        if my is not None:
-            if regions is not None:
-                d.set_regions(shardmod.merge_regions(my))
-                sts.append(d.run())
-                if my:
-                    d.region_stats(my)
-            else:
-                for ref, beg, end in my:
-                    sts.append(d.run_interval(ref, beg, end))
-                    if args.config == 3:
-                        n = (min(end, ref_lengths[ref]) // 1000) - beg // 1000
-                        if n > 0:
-                            d.window_stats(ref, beg // 1000, n)
-                            window_rows[0] += n
-            return sts
-        for b in plan:
-            if b is None:
-                sts.append(d.run())
-                if regions is not None:
-                    d.region_stats(regions)
-            else:
-                sts.append(d.run_batch(b[0], b[1]))
-                if args.config == 3:
-                    for r in range(b[0], b[0] + b[1]):
-                        n = ref_lengths[r] // 1000
-                        if n:
-                            d.window_stats(r, 0, n)
-                            window_rows[0] += n
-        return sts
-
     def sync():
         torch.cuda.synchronize(dev)
         if dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(sharded_, warmup, steps):
-        """warmup + `steps` timed passes (barrier + device synchronisation on both sides, MAX over the ranks)."""
-        my, plan = share(sharded_)
-        for _ in range(warmup):
-            one_pass(my, plan)
-        sync()
-        t0 = time.perf_counter()
-        ks = []
-        for _ in range(steps):
-            ks.append(one_pass(my, plan))
-        sync()
-        el = time.perf_counter() - t0
-        lastp = ks[-1]
-        reads = float(sum(s["n_records"] for s in lastp))
-        adm = float(sum(s["n_admitted"] for s in lastp))
-        if dist:
-            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-            r = torch.tensor([reads, adm], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            reads, adm = float(r[0].item()), float(r[1].item())
-        return {"my": my, "plan": plan, "kstats": ks, "elapsed": el, "sum_reads": reads, "sum_adm": adm}
-
+    sharded = mode in ("shard", "strong")
+    job = Job(args, path, info, dev_index, rank, world, dist, seed)
+    d = job.d
+    ref_lengths = job.ref_lengths
+    mode_args = job.mode_args
     log("context open; warmup + timed region: %d steps (%s)" % (args.steps, "one BAM sharded over the ranks" if sharded else
                                                                 "whole BAM per rank"))
-    main_run = timed(sharded, args.warmup, args.steps)
+    main_run = job.timed(sharded, args.warmup, args.steps, sync, red_dev)
     my, plan, kstats, elapsed = main_run["my"], main_run["plan"], main_run["kstats"], main_run["elapsed"]
     sum_reads, sum_adm = main_run["sum_reads"], main_run["sum_adm"]
     log("timed region done: %.1f ms per step; parity" % (elapsed / args.steps * 1e3))
@@ -417,61 +542,7 @@ def main():
     total_admitted = sum_adm * (total_reads / sum_reads) if (sharded and sum_reads) else sum_adm
 
     # ---- parity of THIS run's results at scale (every rank checks its own share) --------------------------------
-    par = {"windows": 0, "ok": True, "mismatches": []}
-    if args.parity_windows > 0 and args.config in (2, 5):
-        if my is not None:
-            ivs = [iv for iv in my]
-        else:
-            ivs = [(r, 0, ref_lengths[r]) for r in range(len(ref_lengths)) if ref_lengths[r] > 0]
-        if ivs:
-            if my is not None:     # the last run of the pass left the last interval resident
-                ivs = [ivs[-1]]
-            n, bad = parity_windows(d, path, ivs, args.parity_windows, seed ^ rank, min_bq=min_bq, fix_mate=fix_mate)
-            par = {"windows": n, "ok": not bad, "mismatches": bad[:4]}
-            ref, a, b = ivs[-1]
-            a2 = a + (b - a) // 3 // 1024 * 1024
-            b2 = min(b, a2 + 1_000_000)
-            md_got, md_want, nbytes = parity_text(d, path, d.ref_names[ref], ref, a2, b2, mode_args[1:])
-            par.update({"text_slab": [ref, a2, b2], "text_bytes": nbytes, "text_md5": md_got, "text_ok": md_got == md_want})
-            par["ok"] = par["ok"] and md_got == md_want
-    if args.parity_windows > 0 and args.config in (3, 4) and my is None:
-        # window / region statistics of the batch that is still resident against the oracle's `depth region -L chr:a-b`
-        # (a window is the region [k w, (k + 1) w); the reads come through the BAI, seconds per call)
-        import numpy as np
-        rng = random.Random(seed ^ 0x33)
-        checked, bad = 0, []
-        if args.config == 3:
-            lastb = plan[-1]
-            refs_res = range(lastb[0], lastb[0] + lastb[1]) if lastb is not None else range(len(ref_lengths))
-            cands = [r for r in refs_res if ref_lengths[r] >= 4000]
-            for _ in range(args.parity_windows):
-                if not cands:
-                    break
-                r = cands[rng.randrange(len(cands))]
-                k = rng.randrange(1, ref_lengths[r] // 1000 - 1)
-                nr, nb, _cov = d.window_stats(r, k, 1)
-                got = (int(nr[0][0]), "%g" % float(np.float32(nb[0][0]) / np.float32(1000)))
-                out = subprocess.run([os.path.join(ROOT, "oracle", "depth_oracle"), "region", "-L", "%s:%d-%d" % (d.ref_names[r], k * 1000 + 1, (k + 1) * 1000), path],
-                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode().splitlines()
-                f = out[-1].split("\t")
-                want = (int(f[3]), f[4])
-                checked += 1
-                if got != want:
-                    bad.append([r, k, list(got), list(want)])
-        else:
-            picks = [regions[rng.randrange(len(regions))] for _ in range(args.parity_windows)]
-            nr, nb, _cov, _seen = d.region_stats(picks)
-            for j, (r, a, b) in enumerate(picks):
-                got = (int(nr[j][0]), "%g" % float(np.float32(nb[j][0]) / np.float32(b - a)))
-                out = subprocess.run([os.path.join(ROOT, "oracle", "depth_oracle"), "region", "-L", "%s:%d-%d" % (d.ref_names[r], a + 1, b), path],
-                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode().splitlines()
-                f = out[-1].split("\t")
-                want = (int(f[3]), f[4])
-                checked += 1
-                if got != want:
-                    bad.append([r, a, b, list(got), list(want)])
-        par = {"windows": checked, "ok": not bad, "mismatches": bad[:4],
-               "what": "readCount and meanCoverage of sampled %s against `depth_oracle region -L`" % ("windows" if args.config == 3 else "BED regions")}
+    par = job.parity(my, plan, args.parity_windows)
     if dist:
         okt = torch.tensor([1.0 if par["ok"] else 0.0, float(par["windows"])], dtype=torch.float64, device=red_dev)
         allok = okt.clone()
@@ -481,24 +552,47 @@ def main():
         par["windows_all_ranks"] = int(okt[1].item())
     parity_ok = par.get("ok_all_ranks", par["ok"])
 
-    # ---- N > 1, default mode: the SAME BAM once more, now sharded over the ranks by position (strong scaling) -------
+    # ---- N > 1, default mode, side measurements -------------------------------------------------------------------
     strong = None
-    if world > 1 and args.mode == "auto" and args.config in (2, 5):
+    allred = None
+    if world > 1 and mode == "shard" and args.config in (2, 5) and not args.no_side_runs:
+        # (a) the config's single contig cut into N position slices: strong scaling
+        contigs1, cov1, seed1, extra1, _ = workload(args, 1)
+        path1 = bam_path(contigs1, cov1, seed1, args.level, args.codec, extra1)
+        if rank == 0:
+            info1 = generate(path1, contigs1, cov1, seed1, args.level, args.codec, extra1)
+        dist.barrier()
+        if rank != 0:
+            info1 = json.load(open(path1 + ".json"))
+        d.close()
+        job1 = Job(args, path1, info1, dev_index, rank, world, dist, seed1)
         s_steps = max(3, args.steps // 4)
-        log("one BAM sharded over %d ranks: %d steps" % (world, s_steps))
-        sh = timed(True, 1, s_steps)
+        log("strong scaling: one contig cut into %d slices, %d steps" % (world, s_steps))
+        sh = job1.timed(True, 1, s_steps, sync, red_dev)
         ok_s = True
         if args.parity_windows > 0 and sh["my"]:
-            n_s, bad_s = parity_windows(d, path, [sh["my"][-1]], max(2, args.parity_windows // 2), seed ^ (rank + 77), min_bq=min_bq, fix_mate=fix_mate)
+            n_s, bad_s = parity_windows(job1.d, path1, [sh["my"][-1]], max(2, args.parity_windows // 2), seed1 ^ (rank + 77),
+                                        min_bq=job1.min_bq, fix_mate=job1.fix_mate)
             ok_s = not bad_s
         okt = torch.tensor([1.0 if ok_s else 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok_s = bool(okt[0].item() >= 1.0)
         strong = {"scaling": "strong", "steps": s_steps, "ms_per_step": round(sh["elapsed"] / s_steps * 1e3, 3),
-                  "value": round(float(info["reads"]) / (sh["elapsed"] / s_steps) / 1e6, 3), "unit": "Mreads/s", "parity_ok": ok_s,
-                  "what": "the same BAM cut into %d position slices (sambamba_amd.shard.plan_position_shards), every rank fetches the reads "
-                          "of its slice through the BAI and clips its contributions to the slice; no data-path collective" % world}
+                  "value": round(float(info1["reads"]) / (sh["elapsed"] / s_steps) / 1e6, 3), "unit": "Mreads/s", "parity_ok": ok_s,
+                  "what": "the config's single-contig BAM cut into %d position slices (sambamba_amd.shard.plan_position_shards), every rank "
+                          "fetches the reads of its slice through the BAI and clips its contributions to the slice; no data-path collective. "
+                          "Bounded below by one residency of the lane-per-block Huffman kernel (DESIGN.md section 7)" % world}
         parity_ok = parity_ok and ok_s
+        # (b) the alternative north_star names: reads partitioned by start position, counters summed with an all-reduce
+        if args.config == 2:
+            try:
+                from sambamba_amd.dist_depth import allreduce_base_counters
+                allred = allreduce_base_counters(job1.d, dist, world, rank, red_dev, check=args.parity_windows > 0, bam=path1)
+                if allred and not allred.get("parity_ok", True):
+                    parity_ok = False
+            except Exception as e:     # a side measurement must not take the headline down
+                allred = {"error": str(e)[:300]}
+        d = job1.d
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -512,19 +606,35 @@ def main():
         unc = sum(s["uncompressed_bytes"] for s in last)
         cnt = sum(s["counter_bytes"] for s in last)
         nrec = sum(s["n_records"] for s in last)
-        # algorithmic bytes per pass of rank 0
-        alg = {"huffman_decode": comp + 0.57 * unc,          # compressed in; literal + match-entry streams out (~0.57 B per output byte)
-               "lz77_resolve": 0.57 * unc + unc,              # token streams in; inflated bytes out
+        tok = sum(s["token_bytes"] for s in last)
+        acc_in = sum(s["accumulate_read_bytes"] for s in last)
+        # ALGORITHMIC bytes per pass of rank 0: what each kernel has to move, measured by the run itself
+        alg = {"huffman_decode": comp + tok,                  # compressed bytes in; literal + match-entry streams out (counted by K1b)
+               "lz77_resolve": tok + unc,                     # token streams in; inflated bytes out
                "record_index": nrec * (36 + 32),              # 36-B fixed part read + 32-B descriptor written per record
-               "decode_accumulate": unc + cnt}               # record bytes read once + 28 B/position/sample written once
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(alg[dom] / (kern[dom] * 1e-3) / 1e9, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+               "decode_accumulate": acc_in + cnt}             # descriptors + CIGAR / packed sequence (+ qualities when -q > 0) of the
+                                                              # admitted records in; counters (+ span counts) out, once
+        pmc = pmc_table() if (args.config == 2 and args.length == CHR1_LEN and world == 1) else {}
+        per_kernel = {}
+        bad_frac = []
+        for k in kern:
+            if kern[k] <= 0:
+                continue
+            gbps = alg[k] / (kern[k] * 1e-3) / 1e9
+            e = {"ms": round(kern[k], 4), "algorithmic_bytes": int(alg[k]), "algorithmic_GBps": round(gbps, 2),
+                 "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 5)}
+            if k in pmc:
+                e["traffic_bytes"] = pmc[k]["traffic"]
+                e["traffic_over_algorithmic"] = round(pmc[k]["traffic"] / max(1.0, alg[k]), 3)
+            if not (0.0 < gbps / HBM_PEAK_GBS <= 1.0):
+                bad_frac.append(k)
+            per_kernel[k] = e
+        roof = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["algorithmic_GBps"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "frac": per_kernel[dom]["frac_of_hbm_peak"],
                 "algorithmic_bytes_per_launch": int(alg[dom]), "kernel_ms": round(kern[dom], 4)}
-        roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
-        if args.config == 2 and args.length == CHR1_LEN and world == 1:
-            roof.update(pmc_traffic(dom))
-        per_kernel = {k: {"ms": round(kern[k], 4), "algorithmic_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 2),
-                          "frac_of_hbm_peak": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in kern if kern[k] > 0}
+        if dom in pmc:
+            roof.update({"traffic": pmc[dom]["traffic"], "traffic_unit": "bytes per launch", "traffic_source": pmc[dom]["source"],
+                         "traffic_over_algorithmic": per_kernel[dom]["traffic_over_algorithmic"]})
         # the fused-path figure of SURVEY.md 8(d): compressed bytes in + counters out over the whole pass
         fused = (comp + cnt) / (sum(kern.values()) * 1e-3) / 1e9 if sum(kern.values()) > 0 else 0.0
         cpu = None
@@ -539,24 +649,28 @@ def main():
                 e2e["vs_cpu_baseline"] = round(e2e["Mreads_per_s"] / cpu["value"], 1)
         what = {2: "depth base", 3: "depth window -w 1000", 4: "depth region -L exome.bed", 5: "depth base --fix-mate-overlaps -q20"}[args.config]
         full = (args.config == 2 and args.length == CHR1_LEN) or (args.config != 2 and args.scale == 1.0)
+        sharding = {"single": "single GPU",
+                    "shard": "ONE BAM (%d contig(s)) sharded over the ranks by reference position (BAI fetch per slice, the slice's BGZF blocks "
+                             "resident in the rank's HBM, contributions clipped to the slice), no data-path collective" % len(ref_lengths),
+                    "strong": "the config's single-contig BAM cut into N position slices (BAI fetch per slice, contributions clipped), "
+                              "no data-path collective",
+                    "replicas": "every GPU runs the full workload (same seeded BAM), no data-path collective"}[mode]
         line = {
             "metric": "depth_%s_Mreads_per_s" % mode_args[0], "value": round(reads_per_s / 1e6, 3), "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if mode == "strong" else "weak", "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
             "config": {"workload": "%s on synthetic %dx coordinate-sorted BAM (%d contig(s), %d Mbp, %d reads of %d bp, BGZF %s level %d, "
                                    "ratio %.2f), compressed bytes resident in HBM" % (
                                        what, int(coverage), len(ref_lengths), sum(ref_lengths) // 1_000_000, int(info["reads"]), read_len,
                                        args.codec, args.level, unc / max(1, comp)),
                        "baseline_config": cfg_name if full else cfg_name + " scaled down (development)",
-                       "sharding": ("one BAM sharded over the ranks by reference position (BAI fetch per slice, contributions clipped "
-                                    "to the slice), no data-path collective" if sharded else
-                                    "every GPU runs the full workload (same seeded BAM), no data-path collective") if world > 1 else "single GPU"},
+                       "sharding": sharding},
             "gbases_per_s": round(total_admitted * read_len / (elapsed / args.steps) / 1e9, 3),
             "reads_total": int(total_reads), "reads_admitted": int(total_admitted),
             "roofline": roof, "kernels": per_kernel,
             "fused_path": {"algorithmic_GBps": round(fused, 1), "frac_of_hbm_peak": round(fused / HBM_PEAK_GBS, 5),
                            "what": "(compressed bytes in + counter bytes out) / sum of the kernel times of a pass, rank 0"},
-            "sharded_one_bam": strong,
+            "strong_one_contig": strong, "allreduce_option": allred,
             "cpu_baseline": cpu, "parity_checked": par, "e2e": e2e,
             "e2e_Mreads_per_s": (e2e or {}).get("Mreads_per_s"),
             "e2e_vs_cpu_baseline": (e2e or {}).get("vs_cpu_baseline"),
@@ -565,11 +679,15 @@ def main():
             "host": {"nproc": os.cpu_count(), "bam_gen_seconds": round(info.get("gen_seconds", 0.0), 1),
                      "bam_gen_phases": info.get("gen_phases"), "h2d_ms": round(max(s.get("ms_h2d", 0.0) for s in last), 1),
                      "runs_per_pass": len(last), "chain_runs": int(sum(s["n_runs"] for s in last)),
-                     "window_rows_per_pass": window_rows[0] // max(1, args.steps + args.warmup)},
+                     "window_rows_per_pass": job.window_rows // max(1, args.steps + args.warmup)},
         }
+        if bad_frac:
+            line["accounting_error"] = "roofline fraction outside (0, 1] for: " + ", ".join(bad_frac)
         log("done")
         print(json.dumps(line))
         sys.stdout.flush()
+        if bad_frac:
+            parity_ok = False
     d.close()
     if dist:
         dist.barrier()
@@ -583,32 +701,32 @@ PMC_KERNELS = {"huffman_decode": ["k_huffman_decode"], "lz77_resolve": ["k_lz77_
                "decode_accumulate": ["k_accumulate16", "k_accumulate"]}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same workload
+def pmc_table():
+    """HBM bytes per launch of every kernel group from the committed PMC passes of this same workload
     (tools/profile_round.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, KiB).
-    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is."""
-    rnd = "round2"
-    path = os.path.join(ROOT, "profiles", rnd, "pmc_fetch_write_chr1_30x.csv")
-    if not os.path.exists(path):
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is.  The file is measured
+    by the builder on the code of the commit named in profiles/<round>/README.md; the driver's run does not re-measure it."""
+    for rnd in ("round3", "round2"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_fetch_write_chr1_30x.csv")
+        if os.path.exists(path):
+            break
+    else:
         return {}
-    fetch = write = 0.0
     best = {}
     with open(path) as fh:
         next(fh)
         for ln in fh:
             k, c, v, _ = ln.strip().split(",")
-            if k in PMC_KERNELS[kernel]:
-                best[(k, c)] = max(best.get((k, c), 0.0), float(v))     # the full-size launch
-    for (k, c), v in best.items():
-        if c == "FETCH_SIZE":
-            fetch += v * 1024
-        else:
-            write += v * 1024
-    if not fetch and not write:
-        return {}
-    return {"traffic": int(2 * fetch + write), "traffic_unit": "bytes per launch",
-            "traffic_source": "profiles/%s/pmc_fetch_write_chr1_30x.csv (rocprofv3 PMC, separate passes; "
-                              "FETCH_SIZE raw %.2f GB doubled, WRITE_SIZE %.2f GB)" % (rnd, fetch / 1e9, write / 1e9)}
+            best[(k, c)] = max(best.get((k, c), 0.0), float(v))     # the full-size launch
+    out = {}
+    for group, kernels in PMC_KERNELS.items():
+        fetch = sum(v for (k, c), v in best.items() if k in kernels and c == "FETCH_SIZE") * 1024
+        write = sum(v for (k, c), v in best.items() if k in kernels and c == "WRITE_SIZE") * 1024
+        if fetch or write:
+            out[group] = {"traffic": int(2 * fetch + write),
+                          "source": "profiles/%s/pmc_fetch_write_chr1_30x.csv (rocprofv3 PMC, separate passes; FETCH_SIZE raw %.2f GB "
+                                    "doubled, WRITE_SIZE %.2f GB)" % (rnd, fetch / 1e9, write / 1e9)}
+    return out
 
 
 if __name__ == "__main__":

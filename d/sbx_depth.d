@@ -62,7 +62,8 @@ extern (C) nothrow @nogc {
         ulong compressed_bytes; ulong uncompressed_bytes; ulong counter_bytes; ulong covered_positions;
         ulong launches_inflate; ulong launches_index; ulong launches_accumulate;
         double ms_huffman; double ms_lz77;
-        ulong n_malformed; ulong n_runs; ulong uploaded_bytes; ulong reserved0;
+        ulong n_malformed; ulong n_runs; ulong uploaded_bytes; ulong accumulate_read_bytes;
+        ulong token_bytes; ulong reserved1; ulong reserved2; ulong reserved3;
     }
 
     size_t sbx_abi_sizeof(const(char)* type_name);

@@ -272,7 +272,10 @@ typedef struct {
     uint64_t n_malformed;         /* records dropped as malformed (always 0 after a successful run: they raise SBX_EFORMAT) */
     uint64_t n_runs;              /* record-chain runs of the device work list (1 for a whole file, one per merged BAI chunk group with -L) */
     uint64_t uploaded_bytes;      /* compressed bytes resident in HBM for this run (the BGZF blocks of the work list only) */
-    uint64_t reserved0;
+    uint64_t accumulate_read_bytes;   /* bytes the accumulate kernel has to read: 32-byte descriptors of the records + CIGAR and packed
+                                         sequence of the admitted ones (+ their base qualities when min_base_quality > 0) */
+    uint64_t token_bytes;             /* bytes of the literal + match-entry streams the Huffman kernel wrote and the LZ77 kernel read */
+    uint64_t reserved1, reserved2, reserved3;
 } sbx_run_stats;
 int sbx_last_run_stats(sbx_ctx*, sbx_run_stats* out);
 

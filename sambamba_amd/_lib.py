@@ -60,7 +60,8 @@ class RunStats(C.Structure):
                 ("compressed_bytes", C.c_uint64), ("uncompressed_bytes", C.c_uint64), ("counter_bytes", C.c_uint64),
                 ("covered_positions", C.c_uint64), ("launches_inflate", C.c_uint64), ("launches_index", C.c_uint64),
                 ("launches_accumulate", C.c_uint64), ("ms_huffman", C.c_double), ("ms_lz77", C.c_double),
-                ("n_malformed", C.c_uint64), ("n_runs", C.c_uint64), ("uploaded_bytes", C.c_uint64), ("reserved0", C.c_uint64)]
+                ("n_malformed", C.c_uint64), ("n_runs", C.c_uint64), ("uploaded_bytes", C.c_uint64), ("accumulate_read_bytes", C.c_uint64),
+                ("token_bytes", C.c_uint64), ("reserved1", C.c_uint64), ("reserved2", C.c_uint64), ("reserved3", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -68,6 +68,7 @@ struct HostResults {
     IndexStats st;
     uint64_t last_state;
     uint32_t max_partners, n_rewalked;
+    unsigned long long tok_bytes;
 };
 
 }  // namespace sbx
@@ -138,6 +139,7 @@ struct sbx_ctx {
     DevBuf<uint32_t> d_rg_off;
     DevBuf<uint16_t> d_rg_sample;
     DevBuf<IndexStats> d_stats;
+    DevBuf<unsigned long long> d_tok;      // token bytes of the last inflate (accounting)
     DevBuf<SortedRegion> d_sel;
     DevBuf<uint32_t> d_sel_first;
     DevBuf<uint32_t> d_fmt_len, d_fmt_soff;
@@ -400,8 +402,10 @@ void inflate_worklist(sbx_ctx* c, hipEvent_t ev_mid) {
     c->d_scratch.ensure(inflate_scratch_bytes(n));
     c->d_lit.ensure(inflate_lit_bytes(w.u_bytes, n));
     c->d_ent.ensure(inflate_ent_words(w.u_bytes, n));
+    c->d_tok.ensure(1);
+    SBX_HIP(hipMemsetAsync(c->d_tok.p, 0, 8, c->stream));
     launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p, c->d_comp_len.p, c->d_isize.p, c->d_out_off.p, c->d_U.p, n, 0, c->d_scratch.p,
-                        c->d_lit.p, c->d_ent.p, c->d_nent.p, c->d_status.p, c->stream, ev_mid);
+                        c->d_lit.p, c->d_ent.p, c->d_nent.p, c->d_status.p, c->stream, ev_mid, c->d_tok.p);
 }
 
 // inflates the first k BGZF blocks of the file into host memory (BAM header at open)
@@ -941,6 +945,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         SBX_HIP(hipMemcpyAsync(R.flags, c->d_flag.p, 16, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipMemcpyAsync(&R.n_active, c->d_n_active.p, 8, hipMemcpyDeviceToHost, s));      // n_active, n_deep
         SBX_HIP(hipMemcpyAsync(&R.st, c->d_stats.p, sizeof(IndexStats), hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(&R.tok_bytes, c->d_tok.p, 8, hipMemcpyDeviceToHost, s));
         if (nb) SBX_HIP(hipMemcpyAsync(&R.last_state, c->d_state.p + (nb - 1), 8, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));                            // ---- host synchronisation 1 of 2 ----
         if (R.flags[1] != 0xFFFFFFFFu) {
@@ -1094,7 +1099,9 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         c->stats.compressed_bytes = cb;
     }
     c->stats.uncompressed_bytes = w.u_bytes;
-    c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4;
+    c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4 + (want_span ? (uint64_t)n_active * T * 4 : 0);
+    c->stats.token_bytes = R.tok_bytes;
+    c->stats.accumulate_read_bytes = 32ull * ist.n_records + ist.adm_seq_bytes + (c->min_bq > 0 || c->fix_mate ? ist.adm_qual_bytes : 0);
     c->stats.covered_positions = (uint64_t)n_active * T;
     c->stats.launches_inflate = 1;
     c->stats.launches_index = 2 + (n_rewalked ? 2 : 0);
@@ -1151,6 +1158,7 @@ static void merge_members(sbx_ctx* c) {
         sum.ms_h2d += a.ms_h2d; sum.ms_huffman += a.ms_huffman; sum.ms_lz77 += a.ms_lz77;
         sum.n_records += a.n_records; sum.n_admitted += a.n_admitted; sum.n_bgzf_blocks += a.n_bgzf_blocks;
         sum.compressed_bytes += a.compressed_bytes; sum.uncompressed_bytes += a.uncompressed_bytes;
+        sum.accumulate_read_bytes += a.accumulate_read_bytes; sum.token_bytes += a.token_bytes;
         sum.launches_inflate += a.launches_inflate; sum.launches_index += a.launches_index; sum.launches_accumulate += a.launches_accumulate;
     }
     SBX_HIP(hipStreamSynchronize(s));

@@ -732,14 +732,14 @@ __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
 constexpr int kDescThreads = 256;
 
 __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
-    __shared__ uint32_t tot[4];          // records, admitted, malformed, unknown read group of this workgroup's blocks
-    if (threadIdx.x < 4) tot[threadIdx.x] = 0;
+    __shared__ uint32_t tot[6];          // records, admitted, malformed, unknown read group of this workgroup's blocks; bytes K3 reads
+    if (threadIdx.x < 6) tot[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = blockIdx.x * (kDescThreads / 64) + (threadIdx.x >> 6);
     // (descriptor array too small: nothing is written, the host enlarges it and launches again)
     const uint32_t count = (b < a.n_blocks && !a.flags[2]) ? a.count[b] : 0u;
-    uint32_t n_adm = 0, n_bad = 0, n_urg = 0;
+    uint32_t n_adm = 0, n_bad = 0, n_urg = 0, b_seq = 0, b_qual = 0;
     if (count) {
         const uint64_t beg = a.out_off[b];
         const uint64_t base = (a.state[b] & kStateMask) - count;
@@ -757,6 +757,7 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
                 a.rec_ref[idx] = R.ref;
                 if (a.name_hash) a.name_hash[idx] = R.hash;
                 n_adm += R.admit ? 1u : 0u;
+                if (R.admit) { b_seq += 4u * R.d.n_cigar + ((R.d.l_seq + 1u) >> 1); b_qual += R.d.l_seq; }
                 n_bad += R.bad ? 1u : 0u;
                 n_urg += R.urg ? 1u : 0u;
             }
@@ -778,12 +779,16 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
             n_adm += __shfl_xor(n_adm, d, 64);
             n_bad += __shfl_xor(n_bad, d, 64);
             n_urg += __shfl_xor(n_urg, d, 64);
+            b_seq += __shfl_xor(b_seq, d, 64);
+            b_qual += __shfl_xor(b_qual, d, 64);
         }
         if (lane == 0) {
             atomicAdd(&tot[0], count);
             if (n_adm) atomicAdd(&tot[1], n_adm);
             if (n_bad) atomicAdd(&tot[2], n_bad);
             if (n_urg) atomicAdd(&tot[3], n_urg);
+            if (b_seq) atomicAdd(&tot[4], b_seq);
+            if (b_qual) atomicAdd(&tot[5], b_qual);
         }
     }
     __syncthreads();
@@ -792,6 +797,8 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
         if (tot[1]) atomicAdd(&a.stats->n_admitted, (unsigned long long)tot[1]);
         if (tot[2]) atomicAdd(&a.stats->n_bad, (unsigned long long)tot[2]);
         if (tot[3]) atomicAdd(&a.stats->n_unknown_rg, (unsigned long long)tot[3]);
+        if (tot[4]) atomicAdd(&a.stats->adm_seq_bytes, (unsigned long long)tot[4]);
+        if (tot[5]) atomicAdd(&a.stats->adm_qual_bytes, (unsigned long long)tot[5]);
     }
 }
 

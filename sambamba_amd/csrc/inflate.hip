@@ -784,7 +784,7 @@ template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
-    uint8_t* out, const uint32_t* __restrict__ status) {
+    uint8_t* out, const uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
@@ -911,6 +911,7 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
         opos += span;
         lpos += lspan;
     }
+    if (tok_bytes && lane == 0) atomicAdd(tok_bytes, (unsigned long long)lpos + 4ull * ne);     // token bytes of this block (accounting)
 }
 
 }  // namespace
@@ -924,7 +925,7 @@ size_t inflate_ent_words(uint64_t total, uint32_t n_blocks) { return (size_t)(en
 void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
                          const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
                          uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
-                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid) {
+                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid, unsigned long long* d_tok_bytes) {
     if (n_blocks == 0) { if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream)); return; }
     {
         dim3 grid((n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
@@ -939,7 +940,7 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
         const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
         hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks,
-                           block0, d_out, d_status);
+                           block0, d_out, d_status, d_tok_bytes);
         SBX_HIP(hipGetLastError());
     }
 }

@@ -87,7 +87,8 @@ size_t inflate_ent_words(uint64_t total_out, uint32_t n_blocks);
 void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
                          const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
                          uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
-                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid = nullptr);
+                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid = nullptr,
+                         unsigned long long* d_tok_bytes = nullptr);     // += literal bytes + 4 x match entries (accounting; may be null)
 const char* inflate_status_string(uint32_t s);
 
 // ---- K2: record index (index.hip) ---------------------------------------------------------
@@ -101,6 +102,8 @@ struct ChainRun {
 
 struct IndexStats {         // device-side accumulators of the describe pass
     unsigned long long n_records, n_admitted, n_bad, n_unknown_rg;
+    // bytes K3 has to read of the admitted records: CIGAR + packed sequence, and their base qualities (read only when -q > 0)
+    unsigned long long adm_seq_bytes, adm_qual_bytes;
 };
 
 struct IndexArgs {

@@ -30,6 +30,11 @@ def test_bench_line(tmp_path, extra):
               "data", "config", "roofline", "cpu_baseline", "parity_checked"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    # the accounting checks itself: every kernel's algorithmic bytes / time stays below the HBM peak (bench.py exits non-zero otherwise)
+    assert "accounting_error" not in d
+    for k, e in d["kernels"].items():
+        assert 0 < e["frac_of_hbm_peak"] <= 1, (k, e)
+    assert d["kernels"]["decode_accumulate"]["algorithmic_bytes"] < d["kernels"]["lz77_resolve"]["algorithmic_bytes"]
     assert d["parity_checked"]["ok"] and d["parity_checked"]["windows"] >= 1
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
     assert d["e2e"]["Mreads_per_s"] > 0

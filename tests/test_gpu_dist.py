@@ -88,15 +88,16 @@ def test_sharded_equals_single_gpu_cli(genome, args, world):
     assert got == want
 
 
-@pytest.mark.parametrize("mode", ["auto", "shard"])
+@pytest.mark.parametrize("mode", ["auto", "strong", "replicas"])
 def test_bench_multi_rank_line(tmp_path, mode):
-    """bench.py as the driver launches it for N > 1 (here: two ranks sharing the box's GPU over gloo, a 3 Mbp contig):
-    one JSON line, parity of the timed results against the oracle on every rank, and -- in the default mode -- the same BAM
-    once more sharded over the ranks."""
+    """bench.py as the driver launches it for N > 1 (here: two ranks sharing the box's GPU over gloo, 3 Mbp contigs):
+    one JSON line, parity of the timed results against the oracle on every rank.  Default mode: ONE BAM with a contig per
+    rank, sharded by position, plus the side measurements (the single contig cut in two; the all-reduce option)."""
     import json
     env = dict(os.environ, SBX_BENCH_BACKEND="gloo", PYTHONPATH=ROOT, TMPDIR=str(tmp_path))
+    port = {"auto": "29871", "strong": "29872", "replicas": "29873"}[mode]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29871" if mode == "auto" else "29872", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--length", "3000000", "--no-cpu-baseline", "--no-e2e", "--parity-windows", "3", "--mode", mode]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-1500:]
@@ -104,9 +105,15 @@ def test_bench_multi_rank_line(tmp_path, mode):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_checked"]["ok"] and d["parity_checked"]["ok_all_ranks"]
+    assert "accounting_error" not in d
     if mode == "auto":
-        assert d["scaling"] == "weak" and d["sharded_one_bam"]["parity_ok"] and d["sharded_one_bam"]["value"] > 0
-        assert d["reads_total"] == 2 * 600000
+        assert d["scaling"] == "weak" and d["reads_total"] == 2 * 600000
+        assert "sharded over the ranks" in d["config"]["sharding"]
+        assert d["strong_one_contig"]["parity_ok"] and d["strong_one_contig"]["value"] > 0
+        ar = d["allreduce_option"]
+        assert ar and "error" not in ar, ar
+        assert ar["parity_ok"] and ar["allreduce_bytes_per_rank"] > 0
+    elif mode == "strong":
+        assert d["scaling"] == "strong" and d["strong_one_contig"] is None and d["reads_total"] == 600000
     else:
-        assert d["scaling"] == "strong" and d["sharded_one_bam"] is None
-        assert d["reads_total"] == 600000
+        assert d["scaling"] == "weak" and d["reads_total"] == 2 * 600000
