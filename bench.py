@@ -586,12 +586,29 @@ def main():
         # (b) the alternative north_star names: reads partitioned by start position, counters summed with an all-reduce
         if args.config == 2:
             try:
+                import numpy as np
                 from sambamba_amd.dist_depth import allreduce_base_counters
-                allred = allreduce_base_counters(job1.d, dist, world, rank, red_dev, check=args.parity_windows > 0, bam=path1)
-                if allred and not allred.get("parity_ok", True):
+                from sambamba_amd.shard import plan_position_shards
+                from tests.util import oracle_base_counters
+                # windows straddling the cuts between the owners: every position there is a sum over two ranks
+                cuts = [iv[0][1] for iv in plan_position_shards(job1.ref_lengths, world, align=1024)[1:] if iv]
+                wins = [(0, max(0, c - 25_000), min(job1.ref_lengths[0], c + 25_000)) for c in cuts[:3]] if args.parity_windows > 0 else []
+                log("all-reduce option: reads partitioned by start position, counters summed over %d ranks" % world)
+                allred = allreduce_base_counters(job1.d, dist, world, rank, red_dev, windows=wins, steps=max(2, min(5, args.steps)))
+                got = allred.pop("windows")
+                ok_a = True
+                if rank == 0:
+                    for (r, a0, b0) in wins:
+                        want = oracle_base_counters(path1, r, a0, b0, n_samples=job1.d.n_samples_eff, ref_name=job1.d.ref_names[r])
+                        ok_a = ok_a and (r, a0, b0) in got and bool(np.array_equal(got[(r, a0, b0)], want))
+                okt = torch.tensor([1.0 if ok_a else 0.0], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                allred["parity_ok"] = bool(okt[0].item() >= 1.0)
+                allred["parity_windows"] = [list(w) for w in wins]
+                if not allred["parity_ok"]:
                     parity_ok = False
             except Exception as e:     # a side measurement must not take the headline down
-                allred = {"error": str(e)[:300]}
+                allred = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         d = job1.d
 
     if rank == 0:

@@ -63,10 +63,14 @@ extern (C) nothrow @nogc {
         ulong launches_inflate; ulong launches_index; ulong launches_accumulate;
         double ms_huffman; double ms_lz77;
         ulong n_malformed; ulong n_runs; ulong uploaded_bytes; ulong accumulate_read_bytes;
-        ulong token_bytes; ulong reserved1; ulong reserved2; ulong reserved3;
+        ulong token_bytes; ulong max_alignment_span; ulong reserved2; ulong reserved3;
     }
 
     size_t sbx_abi_sizeof(const(char)* type_name);
+    int sbx_bgzf_compress(const(ubyte)* input, size_t n, int level, int with_eof, int device, ubyte* output, size_t cap, size_t* out_len,
+                          char* err, size_t errlen);
+    int sbx_write_bam(const(char)* path, const(ubyte)* stream, size_t n, int level, int with_index, int device, char* err, size_t errlen);
+    int sbx_build_index(const(char)* bam_path, const(char)* bai_path, int device, char* err, size_t errlen);
     int sbx_inflate_blocks(const(ubyte)* comp, const(ulong)* comp_off, const(uint)* comp_len, const(uint)* isize,
                            uint n_blocks, ubyte* out_, const(ulong)* out_off, char* err, size_t errlen);
     sbx_ctx* sbx_open(const(char*)* bam_paths, int n_bams, int device, char* err, size_t errlen);
@@ -91,6 +95,8 @@ extern (C) nothrow @nogc {
     int sbx_plan_batches(sbx_ctx*, ulong budget_bytes, sbx_batch* out_batches, size_t cap, size_t* n_out);
     int sbx_run_batch(sbx_ctx*, uint first_ref, uint n_refs);
     int sbx_run_interval(sbx_ctx*, uint ref_id, uint beg, uint end);
+    int sbx_run_interval_owned(sbx_ctx*, uint ref_id, uint beg, uint end);
+    int sbx_depth_base_tile_device(sbx_ctx*, uint ref_id, uint beg, uint end, void* d_counters);
     int sbx_depth_base_tile(sbx_ctx*, uint ref_id, uint beg, uint end, uint* counters, ubyte* covered);
     int sbx_depth_region_stats(sbx_ctx*, const(sbx_region)*, size_t, sbx_region_stats*, uint* cov_counts, ubyte* seen);
     int sbx_depth_region_stats_from(sbx_ctx*, const(sbx_region)*, size_t, const(uint)* min_start, sbx_region_stats*,

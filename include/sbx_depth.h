@@ -140,6 +140,27 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
                        const uint32_t* isize, uint32_t n_blocks, uint8_t* out, const uint64_t* out_off,
                        char* err, size_t errlen);
 
+/* The write side of the same seam: bgzfCompress (BioD/bio/core/bgzf/compress.d:34-103) for a whole buffer at once.  in[0, n) is
+ * cut into 0xFF00-byte pieces (bgzf/constants.d:33), every piece becomes one BGZF block -- 18-byte header with the BC
+ * subfield, raw deflate, CRC32, ISIZE -- compressed on the device (one lane per block; fixed Huffman code + greedy LZ77:
+ * any RFC 1951 stream is valid for every BGZF reader, the reference's included; level 0 = stored blocks, any other level
+ * = the one compressing mode).  with_eof != 0 appends the 28-byte EOF block (constants.d:37-49).  All pointers are host
+ * memory; *out_len receives the size of the stream (also on SBX_ENOMEM, when cap is too small: n + n / 2048 + 64 is
+ * always enough).  device: HIP ordinal or -1. */
+int sbx_bgzf_compress(const uint8_t* in, size_t n, int level, int with_eof, int device, uint8_t* out, size_t cap, size_t* out_len,
+                      char* err, size_t errlen);
+/* BamWriter + BgzfOutputStream (BioD/bio/std/hts/bam/writer.d:67-287, bgzf/outputstream.d): `stream` is the uncompressed BAM
+ * byte stream ("BAM\1", header text, references, records); it is written to `path` as BGZF with the EOF block, and -- with_index
+ * != 0 -- indexed into path + ".bai" (sbx_build_index). */
+int sbx_write_bam(const char* path, const uint8_t* stream, size_t n, int level, int with_index, int device, char* err, size_t errlen);
+/* `sambamba index` (createIndex / IndexBuilder, BioD/bio/std/hts/bam/bai/indexing.d:52-366): the BAI of a coordinate-sorted BAM.
+ * The file goes through the device pipeline once (inflate, record chain, field decode: position, basesCovered(), stored
+ * bin, virtual offsets); chunks per bin, the 16 kbp linear index, the metadata pseudo-bin 37450 and the no-coordinate count
+ * are assembled on the host as IndexBuilder.put / finish do.  Bins are written in ascending id order (the reference's order
+ * is that of a D associative array).  The whole file must fit the device in one pass (SBX_ENOMEM otherwise).
+ * SBX_ENOTSORTED when the reads are not coordinate-sorted. */
+int sbx_build_index(const char* bam_path, const char* bai_path, int device, char* err, size_t errlen);
+
 /* ---- engine seam ------------------------------------------------------------ */
 
 /* new MultiBamReader(filenames) (multireader.d:244) + BamReader header parse (reader.d:101-125).
@@ -220,6 +241,12 @@ int sbx_run_batch(sbx_ctx*, uint32_t first_ref, uint32_t n_refs);
  * the getters answer for positions in [beg, end) only: counters there are complete (every read overlapping
  * the interval was seen), outside they are partial. */
 int sbx_run_interval(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end);
+/* The same fetch, but the run keeps only the reads whose LEFTMOST position lies in [beg, end) and counts every position
+ * they cover, also beyond `end`: reads are partitioned between the intervals instead of clipped to them (what the elements of
+ * pileupChunks are, pileup.d:1011-1015: chunks of READS).  Per-position counters of such runs are partial sums; adding them up
+ * over a set of intervals that tile the contig (an all-reduce across GPUs, see sambamba_amd.dist_depth --reduce allreduce) gives
+ * the counters of the whole.  Only without --fix-mate-overlaps (a pair must be resolved by one owner: SBX_EUNSUPPORTED). */
+int sbx_run_interval_owned(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end);
 
 /* depth base: counters[(pos-beg)*n_samples*7 + s*7 + k] for pos in [beg,end) of ref_id
  * (k = A,C,G,T,other,DEL,REFSKIP; n_samples = 1 when --combined).  Positions no admitted read
@@ -228,6 +255,10 @@ int sbx_run_interval(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end);
  * to tell "column with COV 0" from "no column" when min_base_quality > 0. */
 int sbx_depth_base_tile(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, uint32_t* counters,
                         uint8_t* covered);
+
+/* The same counters copied into DEVICE memory of the context's GPU (d_counters: (end - beg) * n_samples * 7 uint32, e.g. the
+ * storage of a torch tensor handed to an RCCL all-reduce): device-to-device, nothing crosses PCIe. */
+int sbx_depth_base_tile_device(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, void* d_counters);
 
 /* depth region: stats[r*n_samples + s] and cov_counts[(r*n_samples + s)*n_thresholds + t] for the
  * raw (unmerged, input-order) region list given here (PerBedRegionPrinter, depth.d:879-931).
@@ -275,7 +306,8 @@ typedef struct {
     uint64_t accumulate_read_bytes;   /* bytes the accumulate kernel has to read: 32-byte descriptors of the records + CIGAR and packed
                                          sequence of the admitted ones (+ their base qualities when min_base_quality > 0) */
     uint64_t token_bytes;             /* bytes of the literal + match-entry streams the Huffman kernel wrote and the LZ77 kernel read */
-    uint64_t reserved1, reserved2, reserved3;
+    uint64_t max_alignment_span;      /* longest alignment (reference positions) among the admitted records of the run */
+    uint64_t reserved2, reserved3;
 } sbx_run_stats;
 int sbx_last_run_stats(sbx_ctx*, sbx_run_stats* out);
 

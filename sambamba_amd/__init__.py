@@ -7,4 +7,5 @@ for tests and bench.py; there is no Python or CPU implementation of the hot path
 fails loudly when the library has not been built.
 """
 from ._lib import (SbxError, Depth, lib, lib_path, inflate_blocks, compile_filter, regex_search, cli_path,  # noqa: F401
+                   bgzf_compress, write_bam, build_index,
                    SBX_MODE_BASE, SBX_MODE_REGION, SBX_MODE_WINDOW)

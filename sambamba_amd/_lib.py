@@ -61,7 +61,7 @@ class RunStats(C.Structure):
                 ("covered_positions", C.c_uint64), ("launches_inflate", C.c_uint64), ("launches_index", C.c_uint64),
                 ("launches_accumulate", C.c_uint64), ("ms_huffman", C.c_double), ("ms_lz77", C.c_double),
                 ("n_malformed", C.c_uint64), ("n_runs", C.c_uint64), ("uploaded_bytes", C.c_uint64), ("accumulate_read_bytes", C.c_uint64),
-                ("token_bytes", C.c_uint64), ("reserved1", C.c_uint64), ("reserved2", C.c_uint64), ("reserved3", C.c_uint64)]
+                ("token_bytes", C.c_uint64), ("max_alignment_span", C.c_uint64), ("reserved2", C.c_uint64), ("reserved3", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -77,7 +77,7 @@ class Batch(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_char), C.c_size_t)
 
 EXPORTS = [
-    "sbx_abi_sizeof", "sbx_run_interval", "sbx_parse_regions", "sbx_parsed_regions", "sbx_parsed_region_line", "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
+    "sbx_abi_sizeof", "sbx_bgzf_compress", "sbx_write_bam", "sbx_build_index", "sbx_run_interval", "sbx_run_interval_owned", "sbx_depth_base_tile_device", "sbx_parse_regions", "sbx_parsed_regions", "sbx_parsed_region_line", "sbx_inflate_blocks", "sbx_open", "sbx_close", "sbx_last_error", "sbx_header", "sbx_ref_name", "sbx_ref_length",
     "sbx_ref_id", "sbx_sample_name", "sbx_header_text", "sbx_compile_filter", "sbx_set_filter", "sbx_regex_search", "sbx_set_params",
     "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_region_stats_from",
     "sbx_depth_window_stats",
@@ -142,6 +142,11 @@ def lib():
     L.sbx_next_active_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, u64p, u64p]
     L.sbx_preload.argtypes = [C.c_void_p]
     L.sbx_run_interval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.sbx_bgzf_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.sbx_write_bam.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.sbx_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.sbx_run_interval_owned.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.sbx_depth_base_tile_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sbx_parse_regions.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.sbx_parsed_regions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.sbx_parsed_region_line.argtypes = [C.c_void_p, C.c_size_t]
@@ -176,6 +181,39 @@ def inflate_blocks(comp, comp_off, comp_len, isize, out_off, out_size):
     if rc != 0:
         raise SbxError(rc, err.value.decode())
     return out
+
+
+def bgzf_compress(data, level=6, with_eof=True, device=-1):
+    """sbx_bgzf_compress: the BGZF stream (bytes) of `data`, compressed on the device."""
+    L = lib()
+    src = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    cap = len(src) + len(src) // 2048 + 64 + 28 + 31
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    rc = L.sbx_bgzf_compress(src.ctypes.data if len(src) else None, len(src), int(level), int(with_eof), device, out.ctypes.data, cap, C.byref(n), err, 512)
+    if rc != 0:
+        raise SbxError(rc, err.value.decode())
+    return out[:n.value].tobytes()
+
+
+def write_bam(path, stream, level=6, with_index=True, device=-1):
+    """sbx_write_bam: the uncompressed BAM byte stream `stream` as a BGZF file (+ .bai)."""
+    L = lib()
+    src = np.frombuffer(bytes(stream), dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    rc = L.sbx_write_bam(path.encode(), src.ctypes.data, len(src), int(level), int(with_index), device, err, 512)
+    if rc != 0:
+        raise SbxError(rc, err.value.decode())
+
+
+def build_index(bam_path, bai_path=None, device=-1):
+    """sbx_build_index (`sambamba index`): writes bai_path (default: bam_path + ".bai")."""
+    L = lib()
+    err = C.create_string_buffer(512)
+    rc = L.sbx_build_index(bam_path.encode(), (bai_path or bam_path + ".bai").encode(), device, err, 512)
+    if rc != 0:
+        raise SbxError(rc, err.value.decode())
 
 
 def regex_search(pattern, text, options=""):
@@ -308,6 +346,25 @@ class Depth:
         st = RunStats()
         self._check(self._L.sbx_last_run_stats(self._ctx, C.byref(st)))
         return st.as_dict()
+
+    def run_interval_owned(self, ref_id, beg, end):
+        """sbx_run_interval_owned: only the reads whose leftmost position lies in [beg, end), counted over all they cover."""
+        self._check(self._L.sbx_run_interval_owned(self._ctx, int(ref_id), int(beg), int(end)))
+        st = RunStats()
+        self._check(self._L.sbx_last_run_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def base_counters_to_device(self, ref_id, beg, end, device_ptr):
+        """sbx_depth_base_tile_device: counters of [beg, end) into device memory ((end - beg) * S * 7 uint32 at device_ptr)."""
+        self._check(self._L.sbx_depth_base_tile_device(self._ctx, int(ref_id), int(beg), int(end), C.c_void_p(int(device_ptr))))
+
+    def measure_base_rows(self, ref_id, beg, end, min_cov=1.0, max_cov=float("inf"), annotate=False):
+        """Bytes of the text of [beg, end) (the device's measuring pass alone; nothing is copied)."""
+        need = C.c_size_t(0)
+        rc = self._L.sbx_format_base_rows(self._ctx, ref_id, beg, end, float(min_cov), float(max_cov), int(annotate), None, 0, C.byref(need))
+        if rc != 0 and rc != ENOMEM:
+            self._check(rc)
+        return int(need.value)
 
     def format_base_rows(self, ref_id, beg, end, min_cov=1.0, max_cov=float("inf"), annotate=False):
         """Text of `depth base` for [beg, end) of ref_id, formatted on the device (bytes)."""

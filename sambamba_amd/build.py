@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsbx_depth.so")
 CLI = os.path.join(CSRC, "sbx-depth")
-SOURCES = ["inflate.hip", "index.hip", "depth.hip", "reduce.hip", "mates.hip", "format.hip", "engine.cpp"]
+SOURCES = ["inflate.hip", "index.hip", "depth.hip", "reduce.hip", "mates.hip", "format.hip", "deflate.hip", "engine.cpp"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "sbx_depth.h")]
 
 

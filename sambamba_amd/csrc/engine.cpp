@@ -14,7 +14,9 @@
 #include <memory>
 #include <thread>
 
+#include "bai_writer.hpp"
 #include "common.hpp"
+#include "deflate_core.hpp"
 #include "host_io.hpp"
 #include "kernels.hpp"
 
@@ -96,6 +98,10 @@ struct sbx_ctx {
     std::vector<uint32_t> thresholds;
     sbx_filter filter;
     std::vector<sbx_region> regions;
+    bool index_mode = false;        // sbx_build_index: every record is described, no index / sort order / read group is required, no K3
+    // read ownership of the next run (sbx_run_interval_owned): own_ref >= 0
+    int32_t own_ref = -1;
+    uint32_t own_beg = 0, own_end = 0;
 
     // compressed input on the device: the whole file (sbx_preload) or the blocks of the current work list
     bool preloaded = false;
@@ -849,8 +855,10 @@ static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool r
 
 // The whole device pipeline for the reads selected by `sel` (restricted == false: every read of the file).
 static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
-    if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
-    if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
+    if (!c->index_mode) {
+        if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
+        if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
+    }
     SBX_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->have_run = false;
@@ -883,6 +891,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     RefTable refs{};
     RgTable rg{};
     upload_static(c, sel, restricted, T, &nt, &refs, &rg);
+    if (c->index_mode) rg.lookup = 0;
 
     c->d_entry.ensure(nb + 1);
     c->d_exit.ensure(nb + 1);
@@ -938,6 +947,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         a.desc = c->d_desc.p; a.rec_ref = c->d_rec_ref.p; a.name_hash = c->fix_mate ? c->d_name_hash.p : nullptr;
         a.desc_cap = c->desc_cap;
         a.tile_lo = c->d_tile_lo.p; a.tile_hi = c->d_tile_hi.p; a.stats = c->d_stats.p; a.flags = c->d_flag.p;
+        a.own_ref = c->own_ref; a.own_beg = c->own_beg; a.own_end = c->own_end;
         launch_index_blocks(a, s);
         launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, deep_thr, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
         if (attempt == 0) t2.stop(s);
@@ -1010,6 +1020,14 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     if (ist.n_records != n_records)
         throw Error(SBX_EFORMAT, "internal error: record chain (" + std::to_string(n_records) + ") and describe pass (" +
                                      std::to_string(ist.n_records) + ") disagree on the number of records");
+    if (c->index_mode) {              // the descriptors are the result
+        c->primary_records = n_records;
+        c->stats.n_records = ist.n_records;
+        c->stats.n_bgzf_blocks = nb;
+        c->stats.ms_inflate = t1.ms();
+        c->stats.ms_index = t2.ms();
+        return;
+    }
     if (ist.n_unknown_rg)
         throw Error(SBX_ERG, "error in read: read group is not present in the header (" + std::to_string(ist.n_unknown_rg) + " reads)");
     if (ist.n_bad)
@@ -1101,6 +1119,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     c->stats.uncompressed_bytes = w.u_bytes;
     c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4 + (want_span ? (uint64_t)n_active * T * 4 : 0);
     c->stats.token_bytes = R.tok_bytes;
+    c->stats.max_alignment_span = ist.max_span;
     c->stats.accumulate_read_bytes = 32ull * ist.n_records + ist.adm_seq_bytes + (c->min_bq > 0 || c->fix_mate ? ist.adm_qual_bytes : 0);
     c->stats.covered_positions = (uint64_t)n_active * T;
     c->stats.launches_inflate = 1;
@@ -1159,6 +1178,7 @@ static void merge_members(sbx_ctx* c) {
         sum.n_records += a.n_records; sum.n_admitted += a.n_admitted; sum.n_bgzf_blocks += a.n_bgzf_blocks;
         sum.compressed_bytes += a.compressed_bytes; sum.uncompressed_bytes += a.uncompressed_bytes;
         sum.accumulate_read_bytes += a.accumulate_read_bytes; sum.token_bytes += a.token_bytes;
+        sum.max_alignment_span = std::max(sum.max_alignment_span, a.max_alignment_span);
         sum.launches_inflate += a.launches_inflate; sum.launches_index += a.launches_index; sum.launches_accumulate += a.launches_accumulate;
     }
     SBX_HIP(hipStreamSynchronize(s));
@@ -1279,6 +1299,188 @@ int sbx_run_interval(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end) {
                 if (g.ref_id == ref_id && g.start < end && g.end > beg) sel.push_back({ref_id, std::max(g.start, beg), std::min(g.end, end)});
         run_files(c, sel, true);
     });
+}
+
+int sbx_run_interval_owned(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end) {
+    return guarded(c, [&] {
+        if (!c) throw Error(SBX_EINVAL, "null context");
+        if (ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
+        if (!(beg < end)) throw Error(SBX_EINVAL, "empty interval");
+        if (c->fix_mate) throw Error(SBX_EUNSUPPORTED, "sbx_run_interval_owned: --fix-mate-overlaps needs both mates of a pair in one run");
+        std::vector<sbx_region> sel;
+        if (c->regions.empty()) sel.push_back({ref_id, beg, end});
+        else
+            for (auto& g : c->regions)
+                if (g.ref_id == ref_id && g.start < end && g.end > beg) sel.push_back({ref_id, std::max(g.start, beg), std::min(g.end, end)});
+        struct Own {      // the restriction lasts for this run only
+            std::vector<sbx_ctx*> f;
+            ~Own() { for (sbx_ctx* m : f) m->own_ref = -1; }
+        } own{files_of(c)};
+        for (sbx_ctx* m : own.f) { m->own_ref = (int32_t)ref_id; m->own_beg = beg; m->own_end = end; }
+        run_files(c, sel, true);
+    });
+}
+
+// ---- the write side: BGZF compression, BAM files, BAI ---------------------------------------------------------------
+extern "C++" {
+namespace {
+const uint8_t kEofBlock[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// compresses in[0, n) piece by piece on the device; sink(data, len) receives consecutive pieces of the BGZF stream
+template <class Sink>
+void bgzf_compress_stream(const uint8_t* in, size_t n, int level, Sink&& sink) {
+    hipStream_t s = nullptr;
+    SBX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } guard{s};
+    const size_t piece_blocks = 32768;
+    const size_t n_blocks_total = (n + kBgzfPayload - 1) / kBgzfPayload;
+    const uint32_t cap_blocks = (uint32_t)std::min<size_t>(piece_blocks, std::max<size_t>(1, n_blocks_total));
+    DevBuf<uint8_t> d_in((size_t)cap_blocks * kBgzfPayload + 64), d_slots((size_t)cap_blocks * kBgzfSlot), d_out((size_t)cap_blocks * kBgzfSlot);
+    DevBuf<uint16_t> d_tab(deflate_table_entries(cap_blocks));
+    DevBuf<uint32_t> d_len(cap_blocks + 1);
+    DevBuf<uint64_t> d_off((size_t)cap_blocks + 2);
+    std::vector<uint8_t> host;
+    for (size_t done = 0; done < n;) {
+        const size_t bytes = std::min<size_t>(n - done, (size_t)cap_blocks * kBgzfPayload);
+        const uint32_t nb = (uint32_t)((bytes + kBgzfPayload - 1) / kBgzfPayload);
+        SBX_HIP(hipMemcpyAsync(d_in.p, in + done, bytes, hipMemcpyHostToDevice, s));
+        launch_bgzf_deflate(d_in.p, bytes, nb, level, d_slots.p, d_tab.p, d_len.p, s);
+        launch_count_scan(d_len.p, nb, d_off.p, nullptr, 0, s);
+        launch_pack_blocks(d_slots.p, d_len.p, d_off.p, nb, d_out.p, s);
+        uint64_t total = 0;
+        SBX_HIP(hipMemcpyAsync(&total, d_off.p + nb, 8, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+        host.resize((size_t)total);
+        SBX_HIP(hipMemcpy(host.data(), d_out.p, (size_t)total, hipMemcpyDeviceToHost));
+        sink(host.data(), (size_t)total);
+        done += bytes;
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+int sbx_bgzf_compress(const uint8_t* in, size_t n, int level, int with_eof, int device, uint8_t* out, size_t cap, size_t* out_len,
+                      char* err, size_t errlen) {
+    try {
+        if ((!in && n) || !out_len) throw Error(SBX_EINVAL, "null argument");
+        require_device(device);
+        size_t pos = 0;
+        bgzf_compress_stream(in, n, level, [&](const uint8_t* p, size_t k) {
+            if (pos + k > cap || !out) { pos += k; return; }
+            memcpy(out + pos, p, k);
+            pos += k;
+        });
+        if (with_eof) {
+            if (out && pos + 28 <= cap) memcpy(out + pos, kEofBlock, 28);
+            pos += 28;
+        }
+        *out_len = pos;
+        if (pos > cap || !out) throw Error(SBX_ENOMEM, "output buffer too small for the BGZF stream");
+        return SBX_OK;
+    } catch (const Error& e) {
+        set_err(err, errlen, e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, e.what());
+        return SBX_EINVAL;
+    }
+}
+
+int sbx_build_index(const char* bam_path, const char* bai_path, int device, char* err, size_t errlen) {
+    sbx_ctx* c = nullptr;
+    try {
+        if (!bam_path || !bai_path) throw Error(SBX_EINVAL, "null argument");
+        const char* one[1] = {bam_path};
+        char e2[512] = {0};
+        c = sbx_open(one, 1, device, e2, sizeof e2);
+        if (!c) throw Error(SBX_EIO, e2);
+        c->index_mode = true;
+        memset(&c->filter, 0, sizeof c->filter);         // no filter: every record is described
+        c->mode = SBX_MODE_BASE;
+        c->fix_mate = false;
+        // one pass over the whole file (files whose working set exceeds the device are rejected by the allocation: SBX_ENOMEM)
+        run_impl(c, {}, false);
+        const uint64_t nrec = c->primary_records;
+        hipStream_t s = c->stream;
+        DevBuf<uint16_t> d_bins((size_t)nrec + 1);
+        launch_gather_bins(c->U(), c->d_desc.p, nrec, d_bins.p, s);
+        std::vector<RecDesc> desc((size_t)nrec);
+        std::vector<int32_t> ref((size_t)nrec);
+        std::vector<uint16_t> bins((size_t)nrec);
+        SBX_HIP(hipStreamSynchronize(s));
+        if (nrec) {
+            SBX_HIP(hipMemcpy(desc.data(), c->d_desc.p, (size_t)nrec * sizeof(RecDesc), hipMemcpyDeviceToHost));
+            SBX_HIP(hipMemcpy(ref.data(), c->d_rec_ref.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
+            SBX_HIP(hipMemcpy(bins.data(), d_bins.p, (size_t)nrec * 2, hipMemcpyDeviceToHost));
+        }
+        // virtual offset of a position of the inflated stream: the block that holds the byte, or -- at a block boundary and at
+        // the end of the stream -- the block that starts there (BgzfInputStream.readBlock sets up the next block as soon as
+        // the current one is exhausted, inputstream.d:497-530)
+        const BlockTable& bt = c->blocks;
+        const size_t nbk = bt.size();
+        const uint64_t file_end_coff = nbk ? bt.coffset[nbk - 1] + (bt.comp_off[nbk - 1] - bt.coffset[nbk - 1]) + bt.comp_len[nbk - 1] + 8 : 0;
+        size_t bi = 0;
+        auto voff = [&](uint64_t u) -> uint64_t {        // u is non-decreasing over the calls
+            while (bi < nbk && bt.out_off[bi + 1] <= u) ++bi;
+            if (bi >= nbk) return file_end_coff << 16;
+            return (bt.coffset[bi] << 16) | (u - bt.out_off[bi]);
+        };
+        BaiBuilder bb((int)c->hdr.refs.size());
+        const uint64_t total = bt.out_off.back();
+        uint64_t vo = nrec ? voff(desc[0].rec_off) : 0;
+        for (uint64_t i = 0; i < nrec; ++i) {
+            const uint64_t next_u = i + 1 < nrec ? desc[(size_t)i + 1].rec_off : total;
+            const uint64_t ve = voff(next_u);
+            BaiRecord r;
+            r.ref_id = ref[(size_t)i];
+            r.position = desc[(size_t)i].pos;
+            r.end_position = desc[(size_t)i].end;
+            r.bin = bins[(size_t)i];
+            r.is_unmapped = (desc[(size_t)i].flag & 0x4) != 0;
+            r.start_vo = vo;
+            r.end_vo = ve;
+            bb.put(r);
+            vo = ve;
+        }
+        const std::vector<uint8_t>& bytes = bb.finish();
+        FILE* f = fopen(bai_path, "wb");
+        if (!f) throw Error(SBX_EIO, std::string("cannot write ") + bai_path);
+        const bool ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+        if (fclose(f) != 0 || !ok) throw Error(SBX_EIO, std::string("error writing ") + bai_path);
+        sbx_close(c);
+        return SBX_OK;
+    } catch (const Error& e) {
+        set_err(err, errlen, e.what());
+        if (c) sbx_close(c);
+        return e.code;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, e.what());
+        if (c) sbx_close(c);
+        return SBX_EINVAL;
+    }
+}
+
+int sbx_write_bam(const char* path, const uint8_t* stream, size_t n, int level, int with_index, int device, char* err, size_t errlen) {
+    try {
+        if (!path || (!stream && n)) throw Error(SBX_EINVAL, "null argument");
+        require_device(device);
+        FILE* f = fopen(path, "wb");
+        if (!f) throw Error(SBX_EIO, std::string("cannot write ") + path);
+        bool ok = true;
+        try {
+            bgzf_compress_stream(stream, n, level, [&](const uint8_t* p, size_t k) { ok = ok && fwrite(p, 1, k, f) == k; });
+        } catch (...) { fclose(f); throw; }
+        ok = ok && fwrite(kEofBlock, 1, 28, f) == 28;
+        if (fclose(f) != 0 || !ok) throw Error(SBX_EIO, std::string("error writing ") + path);
+    } catch (const Error& e) {
+        set_err(err, errlen, e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, e.what());
+        return SBX_EINVAL;
+    }
+    if (with_index) return sbx_build_index(path, (std::string(path) + ".bai").c_str(), device, err, errlen);
+    return SBX_OK;
 }
 
 int sbx_last_run_stats(sbx_ctx* c, sbx_run_stats* out) {
@@ -1552,6 +1754,34 @@ int sbx_depth_window_stats(sbx_ctx* c, uint32_t ref_id, uint64_t first_win, uint
         range_stats(c, ranges, true, (uint32_t)w, wb, nw, stats, cov_counts, nullptr);
     });
 }
+int sbx_depth_base_tile_device(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, void* d_out) {
+    return guarded(c, [&] {
+        if (!c || (!d_out && end > beg)) throw Error(SBX_EINVAL, "null argument");
+        if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
+        if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
+        SBX_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        const uint32_t T = c->tile_pos, S = c->n_samples_eff;
+        const size_t row = (size_t)S * SBX_NCOUNTERS;
+        const uint32_t t_first = c->h_tile_base[ref_id], t_end = c->h_tile_base[ref_id + 1];
+        uint32_t* out = (uint32_t*)d_out;
+        if (end > beg) SBX_HIP(hipMemsetAsync(out, 0, (size_t)(end - beg) * row * 4, s));
+        for (uint64_t p = beg; p < end;) {
+            const uint32_t t = t_first + (uint32_t)(p / T);
+            const uint64_t tile_start = (uint64_t)(t - t_first) * T;
+            if (t >= t_end || c->h_slot_of[t] == 0xFFFFFFFFu) { p = std::min<uint64_t>(end, tile_start + T); continue; }
+            uint32_t t2 = t + 1;       // consecutive active tiles occupy consecutive slots: one copy per run of them
+            while (t2 < t_end && (uint64_t)(t2 - t_first) * T < end && c->h_slot_of[t2] == c->h_slot_of[t] + (t2 - t)) ++t2;
+            const uint64_t stop = std::min<uint64_t>(end, (uint64_t)(t2 - t_first) * T);
+            const size_t slot = c->h_slot_of[t];
+            SBX_HIP(hipMemcpyAsync(out + (size_t)(p - beg) * row, c->d_counters.p + slot * T * row + (size_t)(p - tile_start) * row,
+                                   (size_t)(stop - p) * row * 4, hipMemcpyDeviceToDevice, s));
+            p = stop;
+        }
+        SBX_HIP(hipStreamSynchronize(s));
+    });
+}
+
 // K6: the text of `depth base` for [beg, end) of ref_id, formatted on the device (format.hip).
 // FormatArgs of a `depth base` run for rows of ref_id (the names blob travels on the stream first); beg / end are set by the caller
 static FormatArgs format_args(sbx_ctx* c, uint32_t ref_id, double min_cov, double max_cov, int annotate, hipStream_t s) {

@@ -573,6 +573,9 @@ __device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexAr
         while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((int64_t)a.refs.sel[m].end > (int64_t)pos) hi = m; else lo = m + 1; }
         if (lo >= a.refs.sel_first[ref + 1] || (int64_t)a.refs.sel[lo].start >= (int64_t)d.end) { admit = false; d.kind = 0; d.end = d.pos; }
     }
+    if (admit && a.own_ref >= 0 && (ref != a.own_ref || (uint32_t)pos < a.own_beg || (uint32_t)pos >= a.own_end)) {
+        admit = false; d.kind = 0; d.end = d.pos;       // owned by another shard (reads partitioned by start position)
+    }
     // RG -> sample.  The reference builds a CustomBamRead -- and throws on a read group that is not in the header -- for
     // every read it iterates over, filtered or not (depth.d:240-250,1211-1214); with -L those are the reads the index
     // fetch returns, which the admitted ones stand for here.
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
     const uint32_t b = blockIdx.x * (kDescThreads / 64) + (threadIdx.x >> 6);
     // (descriptor array too small: nothing is written, the host enlarges it and launches again)
     const uint32_t count = (b < a.n_blocks && !a.flags[2]) ? a.count[b] : 0u;
-    uint32_t n_adm = 0, n_bad = 0, n_urg = 0, b_seq = 0, b_qual = 0;
+    uint32_t n_adm = 0, n_bad = 0, n_urg = 0, b_seq = 0, b_qual = 0, m_span = 0;
     if (count) {
         const uint64_t beg = a.out_off[b];
         const uint64_t base = (a.state[b] & kStateMask) - count;
@@ -757,7 +760,11 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
                 a.rec_ref[idx] = R.ref;
                 if (a.name_hash) a.name_hash[idx] = R.hash;
                 n_adm += R.admit ? 1u : 0u;
-                if (R.admit) { b_seq += 4u * R.d.n_cigar + ((R.d.l_seq + 1u) >> 1); b_qual += R.d.l_seq; }
+                if (R.admit) {
+                    b_seq += 4u * R.d.n_cigar + ((R.d.l_seq + 1u) >> 1); b_qual += R.d.l_seq;
+                    const uint32_t sp = (uint32_t)(R.d.end - R.d.pos);
+                    m_span = sp > m_span ? sp : m_span;
+                }
                 n_bad += R.bad ? 1u : 0u;
                 n_urg += R.urg ? 1u : 0u;
             }
@@ -781,6 +788,8 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
             n_urg += __shfl_xor(n_urg, d, 64);
             b_seq += __shfl_xor(b_seq, d, 64);
             b_qual += __shfl_xor(b_qual, d, 64);
+            const uint32_t o = __shfl_xor(m_span, d, 64);
+            m_span = o > m_span ? o : m_span;
         }
         if (lane == 0) {
             atomicAdd(&tot[0], count);
@@ -789,6 +798,7 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
             if (n_urg) atomicAdd(&tot[3], n_urg);
             if (b_seq) atomicAdd(&tot[4], b_seq);
             if (b_qual) atomicAdd(&tot[5], b_qual);
+            if (m_span) atomicMax(&a.stats->max_span, m_span);
         }
     }
     __syncthreads();

@@ -36,6 +36,8 @@
 // Roofline: K1a is bound by the instruction issue of the serial decode chain, K1b by VALU issue;
 // neither is HBM-bandwidth bound and their GB/s are reported separately from the HBM-bound
 // accumulate kernel.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -434,6 +436,9 @@ struct Emitter {
     }
 };
 
+// kTrim (variant 1): one input refill per loop iteration covers both literal/length slots (2 x 15 bits <= the 32 a refill
+// guarantees) instead of one per slot; the output position is not counted per literal but derived (literals + match bytes).
+template <bool kTrim>
 __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
     const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint32_t in_bits = comp_len[b] * 8u;
     const uint32_t osize = isize[b];
     const uint64_t oo = out_off[b];
-    uint32_t opos = 0;
+    uint32_t opos = 0;          // (!kTrim) output position; kTrim: bytes produced by matches and stored blocks only
     uint32_t err = INF_OK;
 
     Emitter em;   // (lanes past the last block stay inactive and never emit)
@@ -489,8 +494,8 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             br.refill();
             uint32_t nlen = br.take(16);
             if ((len ^ 0xFFFFu) != nlen) { err = INF_BAD_STORED; active = false; }
-            else if (opos + len > osize) { err = INF_OUTPUT_OVERRUN; active = false; }
-            else { stored_left = len; opos += len; }
+            else if ((kTrim ? opos + em.n_lit : opos) + len > osize) { err = INF_OUTPUT_OVERRUN; active = false; }
+            else { stored_left = len; if (!kTrim) opos += len; }
         }
         while (__any(stored_left != 0)) {
             if (stored_left) {
@@ -614,10 +619,12 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             em.flush();                 // one ring load and the token stores parked by the previous iteration
             uint32_t msym = 0;          // pending length symbol (257..285) of this lane, 0 = none
             uint32_t bad = INF_OK;
+            static_assert(kLitPerIter * 15 <= 32, "one refill must cover the literal/length slots of an iteration");
+            if (kTrim && sym_loop) br.refill();
 #pragma unroll
             for (int r = 0; r < kLitPerIter; ++r) {
                 if (sym_loop && msym == 0 && bad == INF_OK) {
-                    br.refill();
+                    if (!kTrim) br.refill();
                     const uint32_t v = __brev((uint32_t)br.buf) >> 17;
                     int len;
                     uint32_t delta;
@@ -628,14 +635,15 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                     const uint32_t sym = (uint32_t)lds[kLitSymOff + idx] | (((uint32_t)lds[kLitHiOff + (idx >> 3)] >> (idx & 7)) & 1u) << 8;
                     br.drop(lc);
                     const bool ok = len <= 15 && idx0 <= 287u && sym <= 285u;
-                    if (ok && sym < 256u) { ++opos; em.literal(sym); }     // (overrun: checked once per iteration below)
+                    if (ok && sym < 256u) { if (!kTrim) ++opos; em.literal(sym); }     // (overrun: checked once per iteration below)
                     sym_loop = !(ok && sym == 256u);
                     msym = ok && sym > 256u ? sym : 0u;
                     bad = ok ? INF_OK : INF_BAD_SYMBOL;
                 }
             }
             em.park_lits();
-            if (opos > osize && bad == INF_OK) { bad = INF_OUTPUT_OVERRUN; msym = 0; }
+            const uint32_t opos_now = kTrim ? opos + em.n_lit : opos;
+            if (opos_now > osize && bad == INF_OK) { bad = INF_OUTPUT_OVERRUN; msym = 0; }
             if (msym != 0) {
                 // One refill covers the whole match: <= 5 length-extra + 15 code + 13 distance-extra bits.
                 br.refill();
@@ -657,8 +665,8 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                 const uint32_t de = dsym < 4u ? 0u : ((dsym >> 1) - 1u) & 15u;
                 const uint32_t db = dsym < 4u ? dsym + 1u : ((2u + (dsym & 1u)) << de) + 1u;
                 const uint32_t dist = db + br.take((int)de);
-                const bool code_ok = dl <= 15 && didx0 < 30u && dsym <= 29u && dist <= opos;
-                const bool fits = opos + mlen <= osize;
+                const bool code_ok = dl <= 15 && didx0 < 30u && dsym <= 29u && dist <= opos_now;
+                const bool fits = opos_now + mlen <= osize;
                 if (code_ok && fits) { opos += mlen; em.match(mlen, dist); }
                 bad = !code_ok ? (uint32_t)INF_BAD_DISTANCE : !fits ? (uint32_t)INF_OUTPUT_OVERRUN : bad;
             }
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         if (active && last) active = false;
     }
     em.finish();
-    if (err == INF_OK && opos != osize) err = INF_SIZE_MISMATCH;
+    if (err == INF_OK && (kTrim ? opos + em.n_lit : opos) != osize) err = INF_SIZE_MISMATCH;
     if (err == INF_OK && br.consumed() > in_bits) err = INF_INPUT_OVERRUN;
     if (live) {
         status[b] = err;
@@ -930,8 +938,13 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
     {
         dim3 grid((n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
         size_t lds = (size_t)kInfThreads * kLaneLds;
-        hipLaunchKernelGGL(k_huffman_decode, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off,
-                           n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status);
+        static const int variant = [] { const char* e = getenv("SBX_K1A_VARIANT"); return e ? atoi(e) : 1; }();
+        if (variant == 0)
+            hipLaunchKernelGGL(k_huffman_decode<false>, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off,
+                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status);
+        else
+            hipLaunchKernelGGL(k_huffman_decode<true>, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off,
+                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status);
         SBX_HIP(hipGetLastError());
     }
     if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream));

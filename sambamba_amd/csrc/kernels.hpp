@@ -104,6 +104,7 @@ struct IndexStats {         // device-side accumulators of the describe pass
     unsigned long long n_records, n_admitted, n_bad, n_unknown_rg;
     // bytes K3 has to read of the admitted records: CIGAR + packed sequence, and their base qualities (read only when -q > 0)
     unsigned long long adm_seq_bytes, adm_qual_bytes;
+    unsigned int max_span, pad_;            // longest alignment (reference positions) among the admitted records
 };
 
 struct IndexArgs {
@@ -132,6 +133,11 @@ struct IndexArgs {
     uint32_t* tile_lo;
     uint32_t* tile_hi;
     IndexStats* stats;
+    // read ownership (sbx_run_interval_owned): own_ref >= 0 admits only records whose leftmost position lies in
+    // [own_beg, own_end) of that contig -- reads are then partitioned, not clipped, and per-position sums over the
+    // owners' runs equal the whole
+    int32_t own_ref;
+    uint32_t own_beg, own_end;
     uint32_t* flags;                // [0] lowest block with an inconsistent chain (0xFFFFFFFF: none), [1] lowest block whose
                                     // inflate failed, [2] != 0: desc_cap was too small (nothing useful was written)
 };
@@ -210,6 +216,14 @@ void launch_count_reads_mates(const uint8_t* d_U, const RecDesc* d_desc, uint64_
 // multi-BAM: add the tile slots of one file's run into the merged tile set
 void launch_merge_tiles(const uint32_t* d_src, const uint32_t* d_src_active, uint32_t n_src_active, const uint32_t* d_dst_slot_of,
                         uint32_t per_tile, uint32_t* d_dst, hipStream_t stream);
+
+// ---- BGZF writer (deflate.hip): one lane per <= 0xFF00-byte block -> 64 KiB slots -> packed stream; record bins for the BAI
+size_t deflate_table_entries(uint32_t n_blocks);
+void launch_bgzf_deflate(const uint8_t* d_in, uint64_t n_bytes, uint32_t n_blocks, int level, uint8_t* d_slots, uint16_t* d_tables,
+                         uint32_t* d_block_len, hipStream_t stream);
+void launch_pack_blocks(const uint8_t* d_slots, const uint32_t* d_block_len, const uint64_t* d_offset, uint32_t n_blocks, uint8_t* d_out,
+                        hipStream_t stream);
+void launch_gather_bins(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, uint16_t* d_bins, hipStream_t stream);
 
 // K6 format_base_rows (format.hip): text of `depth base` for positions [beg, end) of one contig
 struct FormatArgs {

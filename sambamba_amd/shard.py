@@ -178,32 +178,79 @@ def gather_region_stats(local_rows, dist=None):
     return sorted(merged, key=lambda r: r[0])
 
 
-def send_text_to_rank0(chunks, dist, write):
-    """Concatenate the ranks' text in rank order on rank 0: rank r sends its byte chunks point to point (RCCL send/recv on
-    GPUs), rank 0 hands every chunk to `write` -- per-position text never visits a third rank."""
+def text_group(dist):
+    """The process group finished text travels through: host memory.  With RCCL as the job's backend a second, gloo group
+    is created for it -- text is produced in pinned host buffers and consumed by a host writer, sending it through HBM
+    and xGMI would only add two copies (call on every rank, once)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    if dist.get_backend() == "gloo":
+        return dist.group.WORLD
+    return dist.new_group(backend="gloo")
+
+
+def exclusive_offset(nbytes, dist=None):
+    """(sum of `nbytes` over the lower ranks, sum over all ranks): where this rank's byte range starts in a shared output."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        for c in chunks:
-            write(c)
-        return
+        return 0, int(nbytes)
     dev = _dev(dist)
-    rank, world = dist.get_rank(), dist.get_world_size()
-    if rank == 0:
-        for c in chunks:
-            write(c)
-        for src in range(1, world):
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = torch.tensor([int(nbytes)], dtype=torch.int64, device=dev)
+    parts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    sizes = [int(x.item()) for x in parts]
+    return sum(sizes[:rank]), sum(sizes)
+
+
+class TextFunnel:
+    """Rank-ordered concatenation of the ranks' text on rank 0, streamed: a rank calls write(chunk) as its pieces are
+    produced (bounded memory: one piece in flight) and end() when it is done; rank 0 first drains its own writes straight
+    to `sink`, then receives rank 1's pieces, rank 2's, ...  Point to point through host memory (`group`: gloo)."""
+
+    def __init__(self, dist, group, sink):
+        self.dist, self.group, self.sink = dist, group, sink
+        self.solo = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+        self.rank = 0 if self.solo else dist.get_rank()
+
+    def begin(self):
+        pass
+
+    def write(self, chunk):
+        import torch
+        if self.solo or self.rank == 0:
+            self.sink(chunk)
+            return
+        if not len(chunk):
+            return
+        self.dist.send(torch.tensor([len(chunk)], dtype=torch.int64), dst=0, group=self.group)
+        self.dist.send(torch.frombuffer(bytearray(chunk), dtype=torch.uint8), dst=0, group=self.group)
+
+    def end(self):
+        import torch
+        if self.solo:
+            return
+        if self.rank != 0:
+            self.dist.send(torch.tensor([-1], dtype=torch.int64), dst=0, group=self.group)
+            return
+        for src in range(1, self.dist.get_world_size()):
             while True:
-                n = torch.zeros(1, dtype=torch.int64, device=dev)
-                dist.recv(n, src=src)
+                n = torch.zeros(1, dtype=torch.int64)
+                self.dist.recv(n, src=src, group=self.group)
                 n = int(n.item())
                 if n < 0:
                     break
-                buf = torch.empty(max(1, n), dtype=torch.uint8, device=dev)
-                dist.recv(buf, src=src)
-                write(bytes(buf[:n].cpu().numpy().tobytes()))
-    else:
-        for c in chunks:
-            dist.send(torch.tensor([len(c)], dtype=torch.int64, device=dev), dst=0)
-            t = torch.frombuffer(bytearray(c if len(c) else b"\0"), dtype=torch.uint8).to(dev)
-            dist.send(t, dst=0)
-        dist.send(torch.tensor([-1], dtype=torch.int64, device=dev), dst=0)
+                buf = torch.empty(n, dtype=torch.uint8)
+                self.dist.recv(buf, src=src, group=self.group)
+                self.sink(buf.numpy().tobytes())
+
+
+def send_text_to_rank0(chunks, dist, write, group=None):
+    """Concatenate the ranks' text in rank order on rank 0 (TextFunnel over a list of chunks)."""
+    if group is None:
+        group = text_group(dist)
+    f = TextFunnel(dist, group, write)
+    f.begin()
+    for c in chunks:
+        f.write(c)
+    f.end()

@@ -117,3 +117,113 @@ def test_bench_multi_rank_line(tmp_path, mode):
         assert d["scaling"] == "strong" and d["strong_one_contig"] is None and d["reads_total"] == 600000
     else:
         assert d["scaling"] == "weak" and d["reads_total"] == 2 * 600000
+
+
+# ---- round 3: per-rank output ranges, the all-reduce form, RCCL at world size 1, data-driven mate slack ------------------
+def run_dist_to_file(args, world, port, out_path, env_extra=None):
+    env = dict(os.environ, SBX_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "sambamba_amd.dist_depth"] + args + ["-o", out_path]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    return open(out_path, "rb").read()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("args", [["base"], ["base", "-c", "0"], ["base", "-m", "-q", "20", "-a"]])
+def test_every_rank_writes_its_own_byte_range(genome, one_contig, tmp_path, args, world):
+    """`base -o`: no text funnel -- each rank pwrites at the offset the exclusive scan of the measured sizes gives it, in pieces
+    (SBX_STREAM_PIECE makes the pieces small enough that every rank writes several)."""
+    for k, bam in enumerate((genome[0], one_contig)):
+        want = run_cli(args + [bam])
+        got = run_dist_to_file([args[0], bam] + args[1:], world, 29900 + 10 * world + k + 3 * len(args), str(tmp_path / ("o%d.txt" % k)),
+                               {"SBX_STREAM_PIECE": "20000"})
+        assert got == want, (args, k)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allreduce_form_prints_the_same_text(genome, one_contig, tmp_path, world):
+    """`base --reduce allreduce`: reads partitioned by start position, per-position counters summed by an all-reduce."""
+    for k, bam in enumerate((one_contig, genome[0])):
+        want = run_cli(["base", bam])
+        got = run_dist_to_file(["base", bam, "--reduce", "allreduce"], world, 29940 + 10 * world + k, str(tmp_path / ("a%d.txt" % k)))
+        assert got == want, k
+
+
+def test_rccl_backend_at_world_size_one(one_contig, tmp_path):
+    """The `nccl` (RCCL) branch of the driver on the box's one GPU: process group, all_reduce of flags, the all-reduce of the
+    counter tensors on the device -- world size 1, so that the code path at least runs on hardware."""
+    env = dict(os.environ, SBX_BENCH_BACKEND="nccl", SBX_DIST_FORCE_GROUP="1", PYTHONPATH=ROOT, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29983")
+    for args, ref in ((["window", "-w", "1000", "-T", "10"], None), (["base", "--reduce", "allreduce"], ["base"])):
+        out = str(tmp_path / "n.txt")
+        r = subprocess.run([sys.executable, "-m", "sambamba_amd.dist_depth", args[0], one_contig] + args[1:] + ["-o", out],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        assert open(out, "rb").read() == run_cli((ref or args) + [one_contig])
+
+
+def test_owned_runs_add_up_to_the_whole(one_contig):
+    """sbx_run_interval_owned: the reads are partitioned by start position, so the counters of the owners' runs add up to the
+    counters of the whole run, position by position (also across the cuts, where both owners contribute)."""
+    import numpy as np
+    import sambamba_amd
+    with sambamba_amd.Depth(one_contig) as d:
+        d.set_params()
+        d.run()
+        L = d.ref_lengths[0]
+        whole = d.base_counters(0, 0, L)
+        total = np.zeros_like(whole)
+        cuts = [0, 50176, 50176 + 1024, 131072, L]
+        n_owned = 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            st = d.run_interval_owned(0, a, b)
+            n_owned += st["n_admitted"]
+            total += d.base_counters(0, 0, L)
+        assert np.array_equal(total, whole)
+        d.run()
+        assert n_owned == d.run()["n_admitted"]
+
+
+def test_region_starting_beyond_its_contig_keeps_its_row(genome, tmp_path):
+    """A BED region that starts at or beyond the end of its contig is owned by the rank holding the contig's last position
+    (the single-GPU CLI prints a zero row for it)."""
+    bam, _ = genome
+    bed = str(tmp_path / "beyond.bed")
+    with open(bed, "w") as fh:
+        fh.write("c1\t100\t9000\nc2\t30000\t30500\nc3\t69990\t70100\nc5\t60000\t60010\nc1\t89999\t95000\n")
+    want = run_cli(["region", "-L", bed, bam])
+    for world in (2, 3):
+        got = run_sharded(["region", bam, "-L", bed], world, 29960 + world)
+        assert got == want
+
+
+def test_mate_slack_follows_the_longest_alignment(tmp_path):
+    """window -m across a cut with spliced reads: a read's mate ends tens of kilobases before the slice (an N operation
+    longer than one linear-index window); the left margin of the fetch grows to the longest alignment of the run."""
+    from tests import bamgen as bg
+    import random
+    rng = random.Random(5)
+    L = 400000
+    recs = []
+    def seq(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    k = 0
+    for pos in range(1000, L - 80000, 1500):
+        k += 1
+        # a spliced read (60M <skip>N 60M) and its mate: the mate overlaps the FIRST exon (so that, right of a cut inside the
+        # skip, the spliced read is `past` only if the mate -- which ends far left of the cut -- is in the run) or the second
+        skip = rng.choice([200, 30000, 52000])
+        s1, s2 = seq(120), seq(100)
+        recs.append((pos, bg.make_record(0, pos, "60M%dN60M" % skip, s1, 30, name="p%d" % k, flag=99)))
+        at = pos + 20 if k % 2 else pos + 60 + skip + 20
+        recs.append((at, bg.make_record(0, at, "100M", s2, 31, name="p%d" % k, flag=147)))
+    recs.sort(key=lambda x: x[0])
+    bam = str(tmp_path / "spliced.bam")
+    bg.write_bam(bam, [("chrS", L)], [r[1] for r in recs])
+    args = ["window", "-w", "1000", "-m", "-T", "1"]
+    want = run_cli(args + [bam])
+    for world in (2, 3):
+        got = run_sharded([args[0], bam] + args[1:], world, 29970 + world)
+        assert got == want
