@@ -70,7 +70,7 @@ struct HostResults {
     IndexStats st;
     uint64_t last_state;
     uint32_t max_partners, n_rewalked;
-    unsigned long long tok_bytes;
+    unsigned long long tok_bytes[64];
 };
 
 }  // namespace sbx
@@ -408,8 +408,8 @@ void inflate_worklist(sbx_ctx* c, hipEvent_t ev_mid) {
     c->d_scratch.ensure(inflate_scratch_bytes(n));
     c->d_lit.ensure(inflate_lit_bytes(w.u_bytes, n));
     c->d_ent.ensure(inflate_ent_words(w.u_bytes, n));
-    c->d_tok.ensure(1);
-    SBX_HIP(hipMemsetAsync(c->d_tok.p, 0, 8, c->stream));
+    c->d_tok.ensure(64);
+    SBX_HIP(hipMemsetAsync(c->d_tok.p, 0, 64 * 8, c->stream));
     launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p, c->d_comp_len.p, c->d_isize.p, c->d_out_off.p, c->d_U.p, n, 0, c->d_scratch.p,
                         c->d_lit.p, c->d_ent.p, c->d_nent.p, c->d_status.p, c->stream, ev_mid, c->d_tok.p);
 }
@@ -955,7 +955,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         SBX_HIP(hipMemcpyAsync(R.flags, c->d_flag.p, 16, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipMemcpyAsync(&R.n_active, c->d_n_active.p, 8, hipMemcpyDeviceToHost, s));      // n_active, n_deep
         SBX_HIP(hipMemcpyAsync(&R.st, c->d_stats.p, sizeof(IndexStats), hipMemcpyDeviceToHost, s));
-        SBX_HIP(hipMemcpyAsync(&R.tok_bytes, c->d_tok.p, 8, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(R.tok_bytes, c->d_tok.p, 64 * 8, hipMemcpyDeviceToHost, s));
         if (nb) SBX_HIP(hipMemcpyAsync(&R.last_state, c->d_state.p + (nb - 1), 8, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));                            // ---- host synchronisation 1 of 2 ----
         if (R.flags[1] != 0xFFFFFFFFu) {
@@ -1118,7 +1118,8 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     }
     c->stats.uncompressed_bytes = w.u_bytes;
     c->stats.counter_bytes = (uint64_t)n_active * per_tile * 4 + (want_span ? (uint64_t)n_active * T * 4 : 0);
-    c->stats.token_bytes = R.tok_bytes;
+    c->stats.token_bytes = 0;
+    for (int k = 0; k < 64; ++k) c->stats.token_bytes += R.tok_bytes[k];
     c->stats.max_alignment_span = ist.max_span;
     c->stats.accumulate_read_bytes = 32ull * ist.n_records + ist.adm_seq_bytes + (c->min_bq > 0 || c->fix_mate ? ist.adm_qual_bytes : 0);
     c->stats.covered_positions = (uint64_t)n_active * T;

@@ -919,7 +919,8 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
         opos += span;
         lpos += lspan;
     }
-    if (tok_bytes && lane == 0) atomicAdd(tok_bytes, (unsigned long long)lpos + 4ull * ne);     // token bytes of this block (accounting)
+    // token bytes of this block (accounting): 64 accumulators, so that 200,000 waves do not queue up on one address
+    if (tok_bytes && lane == 0) atomicAdd(tok_bytes + (b & 63u), (unsigned long long)lpos + 4ull * ne);
 }
 
 }  // namespace

@@ -88,7 +88,7 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
                          const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
                          uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
                          uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid = nullptr,
-                         unsigned long long* d_tok_bytes = nullptr);     // += literal bytes + 4 x match entries (accounting; may be null)
+                         unsigned long long* d_tok_bytes = nullptr);     // [64] += literal bytes + 4 x match entries (accounting; may be null)
 const char* inflate_status_string(uint32_t s);
 
 // ---- K2: record index (index.hip) ---------------------------------------------------------

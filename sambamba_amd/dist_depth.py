@@ -202,7 +202,7 @@ def allreduce_base_counters(d, dist, world, rank, red_dev, windows=(), steps=3, 
     """bench.py's `allreduce_option`: the resident BAM of `d` (configs[1]: one contig) with the reads partitioned between the
     ranks by start position and the per-position counters summed by an all-reduce.  Returns timings, the bytes every rank
     puts through the collective and, for each (ref, beg, end) of `windows`, the reduced counters (numpy) for the caller to
-    compare with the oracle."""
+    compare with an independent result."""
     import time
     import torch
     ref_lengths = d.ref_lengths
