@@ -289,6 +289,8 @@ class Job:
                 dist.barrier()
             d.set_params(mode=SBX.SBX_MODE_REGION)
             self.regions = shardmod.read_bed_regions(bed, d.ref_names)
+            import numpy as np
+            self.regions_arr = np.ascontiguousarray(np.asarray(self.regions, dtype=np.uint32).reshape(-1, 3))
             self.mode_args = ["region", "-L", bed]
         elif args.config == 5:
             self.min_bq, self.fix_mate = 20, True
@@ -339,7 +341,7 @@ class Job:
             if b is None:
                 sts.append(d.run())
                 if regions is not None:
-                    d.region_stats(regions)
+                    d.region_stats(self.regions_arr)
             else:
                 sts.append(d.run_batch(b[0], b[1]))
                 if args.config == 3:

@@ -95,6 +95,7 @@ extern (C) nothrow @nogc {
     int sbx_plan_batches(sbx_ctx*, ulong budget_bytes, sbx_batch* out_batches, size_t cap, size_t* n_out);
     int sbx_run_batch(sbx_ctx*, uint first_ref, uint n_refs);
     int sbx_run_interval(sbx_ctx*, uint ref_id, uint beg, uint end);
+    int sbx_prefetch_interval(sbx_ctx*, uint ref_id, uint beg, uint end);
     int sbx_run_interval_owned(sbx_ctx*, uint ref_id, uint beg, uint end);
     int sbx_depth_base_tile_device(sbx_ctx*, uint ref_id, uint beg, uint end, void* d_counters);
     int sbx_depth_base_tile(sbx_ctx*, uint ref_id, uint beg, uint end, uint* counters, ubyte* covered);

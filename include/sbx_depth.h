@@ -241,6 +241,12 @@ int sbx_run_batch(sbx_ctx*, uint32_t first_ref, uint32_t n_refs);
  * the getters answer for positions in [beg, end) only: counters there are complete (every read overlapping
  * the interval was seen), outside they are partial. */
 int sbx_run_interval(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end);
+/* Upload stage of the next sbx_run_interval(ref_id, beg, end) on its own: the BGZF blocks of the interval's work list are read from
+ * the file and copied to the device (pinned staging, the context's copy stream); the results of the previous run stay valid and
+ * may be read meanwhile -- by sbx_stream_base_rows / sbx_depth_* on ANOTHER host thread (the one exception to "one context, one
+ * thread at a time").  A following sbx_run_interval with the same arguments finds the blocks resident and starts with the
+ * kernels.  Lets a caller overlap file -> device, the kernels and device -> text of consecutive slices (cli.cpp does). */
+int sbx_prefetch_interval(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end);
 /* The same fetch, but the run keeps only the reads whose LEFTMOST position lies in [beg, end) and counts every position
  * they cover, also beyond `end`: reads are partitioned between the intervals instead of clipped to them (what the elements of
  * pileupChunks are, pileup.d:1011-1015: chunks of READS).  Per-position counters of such runs are partial sums; adding them up

@@ -9,7 +9,10 @@
 //   sbx-depth window -w size [--overlap n] [-T thr]... [common options] in.bam
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 #include <ctime>
 #include <cstdlib>
 #include <cstring>
@@ -240,6 +243,22 @@ public:
                 else range((uint32_t)r, b, e);
                 from = e;
             }
+        }
+    }
+    // rows of [beg, end) of contig r from context `c` (a slice of the pipelined run: min_cov > 0, no -L)
+    void run_slice(sbx_ctx* c, uint32_t r, uint64_t beg, uint64_t end) {
+        uint64_t from = beg;
+        for (;;) {
+            uint64_t b, e;
+            check(c, sbx_next_active_range(c, r, from, &b, &e));
+            if (b == ~0ULL || b >= end) break;
+            b = std::max(b, from);
+            e = std::min(e, end);
+            out_.flush();
+            check(c, sbx_stream_base_rows(c, r, (uint32_t)b, (uint32_t)e, o_.min_cov, o_.max_cov, o_.annotate ? 1 : 0,
+                                          [](void* u, const char* d, size_t n) -> int { return fwrite(d, 1, n, (FILE*)u) == n ? 0 : 1; },
+                                          out_.fp));
+            from = e;
         }
     }
     void run_device_empty(int r) {
@@ -810,6 +829,89 @@ int depth_main(int argc, char** argv) {
         if (n_batches) check(ctx, sbx_plan_batches(ctx, budget, plan.data(), plan.size(), &n_batches));
         BasePrinter bp(ctx, o, out, samples);
         if (o.mode == "base" && o.has_regions) bp.set_bed(merged);
+        // ---- `depth base` without -L and with -c > 0: the text is a pure function of the position, so the genome is cut into
+        // slices that flow through three overlapping stages -- file -> device (sbx_prefetch_interval), the kernels
+        // (sbx_run_interval), device -> text (sbx_stream_base_rows) -- on two contexts that alternate.  PCIe is full duplex:
+        // the upload of slice k + 1 and the text of slice k - 1 travel while slice k is computed.
+        if (o.mode == "base" && !o.has_regions && o.min_cov > 0 && bp.device_format_applies() && paths.size() == 1 &&
+            !getenv("SBX_NO_PIPELINE") && (hi.compressed_bytes >= (256u << 20) || getenv("SBX_FORCE_PIPELINE"))) {
+            struct Slice { uint32_t ref; uint64_t beg, end, print_end; };
+            std::vector<Slice> sl;
+            {
+                uint64_t total = 0;
+                for (int r = 0; r < hi.n_ref; ++r) total += (uint64_t)std::max<int64_t>(0, sbx_ref_length(ctx, r));
+                uint64_t want = std::max<uint64_t>(total / 8, 16u << 20);
+                if (const char* e = getenv("SBX_SLICE_POSITIONS")) want = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
+                want = (want + 1023) / 1024 * 1024;
+                for (int r = 0; r < hi.n_ref; ++r) {
+                    const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(ctx, r));
+                    if (!len) continue;
+                    const uint64_t n = (len + want - 1) / want, step = ((len + n - 1) / n + 1023) / 1024 * 1024;
+                    for (uint64_t b = 0; b < len; b += step) {
+                        const uint64_t e = std::min(len, b + step);
+                        sl.push_back({(uint32_t)r, b, e, e == len ? 0xFFFFFFFFull : e});      // columns of alignments hanging over the contig end
+                    }
+                }
+            }
+            sbx_ctx* cx[2] = {ctx, nullptr};
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<int> uploaded(sl.size(), 0), computed(sl.size(), 0), printed(sl.size(), 0);
+            std::string failure;
+            bool opened2 = false;
+            auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> g(mu); if (failure.empty()) failure = m; cv.notify_all(); };
+            auto wait_for = [&](auto&& pred) { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return !failure.empty() || pred(); }); return failure.empty(); };
+            auto mark = [&](std::vector<int>& v, size_t k) { std::lock_guard<std::mutex> g(mu); v[k] = 1; cv.notify_all(); };
+            std::thread opener([&] {       // the second context opens while the first slice is on its way
+                char e2[512] = {0};
+                sbx_ctx* c2 = sl.size() > 1 ? sbx_open(paths.data(), (int)paths.size(), -1, e2, sizeof e2) : nullptr;
+                if (sl.size() > 1 && !c2) { fail(e2); return; }
+                if (c2 && (sbx_set_filter(c2, &filt) != SBX_OK ||
+                           sbx_set_params(c2, mode_id, (uint8_t)o.min_bq, o.fix_mate, o.combined, (uint32_t)o.window, (uint32_t)o.overlap,
+                                          o.thresholds.data(), (int)o.thresholds.size()) != SBX_OK)) { fail(sbx_last_error(c2)); sbx_close(c2); return; }
+                std::lock_guard<std::mutex> g(mu);
+                cx[1] = c2;
+                opened2 = true;
+                cv.notify_all();
+            });
+            std::thread uploader([&] {
+                for (size_t k = 0; k < sl.size(); ++k) {
+                    if (!wait_for([&] { return (k & 1) == 0 || opened2; })) return;
+                    if (k >= 2 && !wait_for([&] { return computed[k - 2] != 0; })) return;       // the context's compressed bytes are free again
+                    sbx_ctx* c = cx[k & 1];
+                    if (sbx_prefetch_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end) != SBX_OK) { fail(sbx_last_error(c)); return; }
+                    mark(uploaded, k);
+                }
+            });
+            std::thread computer([&] {
+                for (size_t k = 0; k < sl.size(); ++k) {
+                    if (!wait_for([&] { return uploaded[k] != 0 && (k < 2 || printed[k - 2] != 0); })) return;
+                    sbx_ctx* c = cx[k & 1];
+                    if (sbx_run_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end) != SBX_OK) { fail(sbx_last_error(c)); return; }
+                    mark(computed, k);
+                }
+            });
+            std::string print_failure;
+            const double t0 = now();
+            for (size_t k = 0; k < sl.size(); ++k) {
+                if (!wait_for([&] { return computed[k] != 0; })) break;
+                try { bp.run_slice(cx[k & 1], sl[k].ref, sl[k].beg, sl[k].print_end); }
+                catch (const Fail& f) { fail(f.msg); break; }
+                mark(printed, k);
+            }
+            opener.join(); uploader.join(); computer.join();
+            if (!failure.empty()) { if (cx[1]) sbx_close(cx[1]); throw Fail{failure}; }
+            out.flush();
+            if (out.fp != stdout) fclose(out.fp);
+            if (timing) fprintf(stderr, "[sbx-depth] open %.3f s, %zu slices through upload / kernels / text in %.3f s, total %.3f s since main\n",
+                                t_open - t_start, sl.size(), now() - t0, now() - t_start);
+            // the process ends here: device memory, mappings and streams go with it (an orderly sbx_close of two contexts
+            // frees tens of gigabytes buffer by buffer and costs 0.1 s that no caller is waiting for)
+            if (!getenv("SBX_ORDERLY_EXIT")) { fflush(nullptr); _exit(0); }
+            if (cx[1]) sbx_close(cx[1]);
+            sbx_close(ctx);
+            return 0;
+        }
         WindowPrinter wp{ctx, o, out, samples, false, 0, 0, -1, 0, {}, {}, {}};
         RegionPrinter rp{ctx, o, out, samples, raw, raw_lines, {}, {}, {}};
         for (auto& b : plan) {
