@@ -67,7 +67,7 @@ struct WorkList {
 struct HostResults {
     uint32_t flags[4];
     uint32_t n_active, n_deep;
-    IndexStats st;
+    IndexStats st[kIndexStatSlots];
     uint64_t last_state;
     uint32_t max_partners, n_rewalked;
     unsigned long long tok_bytes[64];
@@ -930,7 +930,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     c->d_active.ensure((size_t)nt + 1);
     c->d_slot_of.ensure((size_t)nt + 1);
     c->d_n_active.ensure(4);
-    c->d_stats.ensure(1);
+    c->d_stats.ensure(kIndexStatSlots);
     // descriptor capacity: sized for records of >= 160 bytes on average; K2 reports an overflow and the pass is repeated
     // with the exact number (short-read fixtures, amplicon data with tiny records)
     uint64_t want_cap = std::max<uint64_t>(c->desc_cap, w.u_bytes / 160 + 4096);
@@ -957,7 +957,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         if (c->fix_mate) c->d_name_hash.ensure((size_t)c->desc_cap + 64);
         SBX_HIP(hipMemsetAsync(c->d_tile_lo.p, 0xFF, (size_t)nt * 4, s));
         SBX_HIP(hipMemsetAsync(c->d_tile_hi.p, 0, (size_t)nt * 4, s));
-        SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats), s));
+        SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats) * kIndexStatSlots, s));
         SBX_HIP(hipMemsetAsync(c->d_state.p, 0, ((size_t)nb + 1) * 8, s));
         SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 8, s));           // [0] first inconsistent block, [1] first failed inflate
         SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 24, s));         // [2] overflow, [3] ticket, [4] rewalked, [5] max partners
@@ -981,7 +981,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         R.last_state = 0;
         SBX_HIP(hipMemcpyAsync(R.flags, c->d_flag.p, 16, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipMemcpyAsync(&R.n_active, c->d_n_active.p, 8, hipMemcpyDeviceToHost, s));      // n_active, n_deep
-        SBX_HIP(hipMemcpyAsync(&R.st, c->d_stats.p, sizeof(IndexStats), hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(R.st, c->d_stats.p, sizeof(IndexStats) * kIndexStatSlots, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipMemcpyAsync(R.tok_bytes, c->d_tok.p, 64 * 8, hipMemcpyDeviceToHost, s));
         if (nb) SBX_HIP(hipMemcpyAsync(&R.last_state, c->d_state.p + (nb - 1), 8, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));                            // ---- host synchronisation 1 of 2 ----
@@ -1042,7 +1042,13 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         if (R.flags[2]) { want_cap = n_records + 1024; continue; }
         break;
     }
-    const IndexStats ist = R.st;
+    IndexStats ist{};
+    for (uint32_t k = 0; k < kIndexStatSlots; ++k) {
+        const IndexStats& x = R.st[k];
+        ist.n_records += x.n_records; ist.n_admitted += x.n_admitted; ist.n_bad += x.n_bad; ist.n_unknown_rg += x.n_unknown_rg;
+        ist.adm_seq_bytes += x.adm_seq_bytes; ist.adm_qual_bytes += x.adm_qual_bytes;
+        ist.max_span = std::max(ist.max_span, x.max_span);
+    }
     const uint32_t n_active = R.n_active;
     if (ist.n_records != n_records)
         throw Error(SBX_EFORMAT, "internal error: record chain (" + std::to_string(n_records) + ") and describe pass (" +

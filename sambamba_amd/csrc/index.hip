@@ -735,8 +735,8 @@ __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
 constexpr int kDescThreads = 256;
 
 __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
-    __shared__ uint32_t tot[6];          // records, admitted, malformed, unknown read group of this workgroup's blocks; bytes K3 reads
-    if (threadIdx.x < 6) tot[threadIdx.x] = 0;
+    __shared__ uint32_t tot[7];          // records, admitted, malformed, unknown read group of this workgroup's blocks; bytes K3 reads; longest span
+    if (threadIdx.x < 7) tot[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = blockIdx.x * (kDescThreads / 64) + (threadIdx.x >> 6);
@@ -798,17 +798,20 @@ __global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
             if (n_urg) atomicAdd(&tot[3], n_urg);
             if (b_seq) atomicAdd(&tot[4], b_seq);
             if (b_qual) atomicAdd(&tot[5], b_qual);
-            if (m_span) atomicMax(&a.stats->max_span, m_span);
+            if (m_span) atomicMax(&tot[6], m_span);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (tot[0]) atomicAdd(&a.stats->n_records, (unsigned long long)tot[0]);
-        if (tot[1]) atomicAdd(&a.stats->n_admitted, (unsigned long long)tot[1]);
-        if (tot[2]) atomicAdd(&a.stats->n_bad, (unsigned long long)tot[2]);
-        if (tot[3]) atomicAdd(&a.stats->n_unknown_rg, (unsigned long long)tot[3]);
-        if (tot[4]) atomicAdd(&a.stats->adm_seq_bytes, (unsigned long long)tot[4]);
-        if (tot[5]) atomicAdd(&a.stats->adm_qual_bytes, (unsigned long long)tot[5]);
+        // kIndexStatSlots accumulators (the host adds them up): tens of thousands of workgroups do not queue up on one cache line
+        IndexStats* st = a.stats + (blockIdx.x & (kIndexStatSlots - 1));
+        if (tot[0]) atomicAdd(&st->n_records, (unsigned long long)tot[0]);
+        if (tot[1]) atomicAdd(&st->n_admitted, (unsigned long long)tot[1]);
+        if (tot[2]) atomicAdd(&st->n_bad, (unsigned long long)tot[2]);
+        if (tot[3]) atomicAdd(&st->n_unknown_rg, (unsigned long long)tot[3]);
+        if (tot[4]) atomicAdd(&st->adm_seq_bytes, (unsigned long long)tot[4]);
+        if (tot[5]) atomicAdd(&st->adm_qual_bytes, (unsigned long long)tot[5]);
+        if (tot[6]) atomicMax(&st->max_span, tot[6]);
     }
 }
 

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
     const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
     uint8_t* __restrict__ lit_stream, uint32_t* __restrict__ ent_stream, uint32_t* __restrict__ n_entries,
-    uint8_t* __restrict__ lens_scratch, uint32_t* __restrict__ status) {
+    uint8_t* __restrict__ lens_scratch, uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // Lanes past the last block shadow block n_blocks-1 but stay inactive: every lane of the wave
     // must take part in the wave-synchronous input service.
@@ -681,6 +681,12 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         status[b] = err;
         n_entries[b] = em.n_ent;
     }
+    if (tok_bytes) {
+        // bytes of the two token streams (accounting): one atomic per wave into one of 64 accumulators
+        unsigned long long t = live ? (unsigned long long)em.n_lit + 4ull * em.n_ent : 0ull;
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (threadIdx.x == 0) atomicAdd(tok_bytes + (blockIdx.x & 63u), t);
+    }
 }
 
 // ---- K1b -----------------------------------------------------------------------------------------
@@ -792,7 +798,7 @@ template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
-    uint8_t* out, const uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes) {
+    uint8_t* out, const uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
@@ -919,8 +925,6 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
         opos += span;
         lpos += lspan;
     }
-    // token bytes of this block (accounting): 64 accumulators, so that 200,000 waves do not queue up on one address
-    if (tok_bytes && lane == 0) atomicAdd(tok_bytes + (b & 63u), (unsigned long long)lpos + 4ull * ne);
 }
 
 }  // namespace
@@ -942,10 +946,10 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         static const int variant = [] { const char* e = getenv("SBX_K1A_VARIANT"); return e ? atoi(e) : 1; }();
         if (variant == 0)
             hipLaunchKernelGGL(k_huffman_decode<false>, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off,
-                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status);
+                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes);
         else
             hipLaunchKernelGGL(k_huffman_decode<true>, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off,
-                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status);
+                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes);
         SBX_HIP(hipGetLastError());
     }
     if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream));
@@ -954,7 +958,7 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
         const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
         hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks,
-                           block0, d_out, d_status, d_tok_bytes);
+                           block0, d_out, d_status);
         SBX_HIP(hipGetLastError());
     }
 }

@@ -100,6 +100,7 @@ struct ChainRun {
     uint32_t blk_first, blk_last;      // inclusive
 };
 
+constexpr uint32_t kIndexStatSlots = 64;     // IndexArgs.stats points at this many accumulators (power of two); the host adds them up
 struct IndexStats {         // device-side accumulators of the describe pass
     unsigned long long n_records, n_admitted, n_bad, n_unknown_rg;
     // bytes K3 has to read of the admitted records: CIGAR + packed sequence, and their base qualities (read only when -q > 0)

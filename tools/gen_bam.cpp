@@ -409,7 +409,20 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (P.out.empty()) { fprintf(stderr, "usage: gen_bam --out x.bam [--contigs n:len,n:len] [--coverage 30] ...\n"); return 2; }
-    if (P.threads <= 0) P.threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (P.threads <= 0) {
+        // the CPUs this process may actually use: a container's cgroup quota is often far below the CPUs it can see (16 of 256 on
+        // the GPU boxes), and hundreds of compressing threads on 16 CPUs of quota mostly wait for each other
+        P.threads = (int)std::max(1u, std::thread::hardware_concurrency());
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long long quota = atoll(q);
+                if (quota > 0) P.threads = (int)std::max<long long>(1, std::min<long long>(P.threads, (quota + period - 1) / period + 2));
+            }
+            fclose(f);
+        }
+    }
     init_luts();
     {
         size_t p = 0;
