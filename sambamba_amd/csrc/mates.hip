@@ -25,6 +25,8 @@
 // region / window mode, whose closed form (reduce.hip) is derived for pairs.  Ties are resolved as in the oracle: the
 // record later in the file wins (column order; parity unpinned).  Names are compared byte for byte after the hashes
 // match (depth.d:352-353).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -243,13 +245,38 @@ __device__ MultiPlan plan_multi(const RecDesc* __restrict__ desc, uint32_t ia, c
     return P;
 }
 
+// ---- fast path of k_accumulate_mates: a single-run read and its (at most one) single-run mate ----------------------------
+// The per-position path below evaluates two CIGAR cursors per position and lane: ten times the work of the plain tile
+// kernel per read (config 5: 116 of 246 ms).  For a read A whose alignment is one run of M/=/X and whose partner B (if it
+// has one) is of the same kind -- every ordinary pair of a paired-end library -- the cursors are arithmetic: A's base at
+// position p is query offset q_start + p - pos, and the reference's rule (depth.d:391-399, ties to the record later in the
+// file) is a comparison of two quality bytes.  Every lane takes an ALIGNED block of 16 tile positions of one read: 12 bytes of
+// packed sequence, 16 quality bytes of A and the 16 quality bytes of B at the same positions, loaded as dwords; reads are
+// packed into lanes by a prefix sum of their block counts (as in k_accumulate16b).  A read is eligible iff eligible_fast();
+// the per-position path skips exactly those.
+#define SBX_M_LUT_OFF_ENTRY(n) (((n) == 1 || (n) == 2 ? 0u : (n) == 4 || (n) == 8 ? 1u : 2u) << (2 * (n)))
+#define kMLutOff (SBX_M_LUT_OFF_ENTRY(0) | SBX_M_LUT_OFF_ENTRY(1) | SBX_M_LUT_OFF_ENTRY(2) | SBX_M_LUT_OFF_ENTRY(3) | SBX_M_LUT_OFF_ENTRY(4) | \
+                  SBX_M_LUT_OFF_ENTRY(5) | SBX_M_LUT_OFF_ENTRY(6) | SBX_M_LUT_OFF_ENTRY(7) | SBX_M_LUT_OFF_ENTRY(8) | SBX_M_LUT_OFF_ENTRY(9) | \
+                  SBX_M_LUT_OFF_ENTRY(10) | SBX_M_LUT_OFF_ENTRY(11) | SBX_M_LUT_OFF_ENTRY(12) | SBX_M_LUT_OFF_ENTRY(13) | SBX_M_LUT_OFF_ENTRY(14) | \
+                  SBX_M_LUT_OFF_ENTRY(15))
+#define kMLutHalf ((1u << 4) | (1u << 16))
+constexpr uint32_t kMateMapBytes = 704;      // 64 reads x 11 blocks
+
+__device__ __forceinline__ bool single_run_ok(const RecDesc& d) {      // one run of aligned bases that lies inside the sequence
+    return d.kind == 1 && (uint64_t)d.q_start + (uint64_t)(d.end - d.pos) <= (uint64_t)d.l_seq;
+}
+__device__ __forceinline__ bool eligible_fast(const RecDesc& a, uint32_t np, bool has_mate, const RecDesc& b) {
+    return np <= 1u && single_run_ok(a) && (!has_mate || single_run_ok(b));
+}
+__device__ __forceinline__ uint32_t nibble_swap_m(uint32_t x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
+
 template <bool kSpan>
 __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ mate,
     const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active,
     const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S, uint32_t min_bq,
     const uint32_t* __restrict__ ext, const uint32_t* __restrict__ n_partners, uint32_t* __restrict__ too_many,
-    uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out) {
+    uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out, int fast_path) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t s7 = S * 7;
     const uint32_t sub_dw = (T / 4) * s7 + 8;
@@ -265,6 +292,111 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T), te = ts + (int32_t)T;
     const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
     __syncthreads();
+    if (fast_path) {
+        // ---- phase 1: eligible reads, 16 aligned positions per lane ------------------------------------------------------
+        const uint32_t wlane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        uint8_t* map = (uint8_t*)(lds + 4 * sub_dw + (kSpan ? T : 0u)) + wave * kMateMapBytes;
+        for (uint32_t c0 = r_lo + wave * 64u; c0 < r_hi; c0 += (kMateThreads / 64) * 64u) {
+            const uint32_t ri = c0 + wlane;
+            RecDesc a, b;
+            a.kind = 0; a.pos = 0; a.end = 0; a.rec_off = 0; a.l_seq = 0; a.n_cigar = 0; a.l_name = 0; a.q_start = 0; a.sample = 0; a.mapq = 0;
+            b = a;
+            uint32_t mi = 0xFFFFFFFFu, np = 0;
+            if (ri < r_hi) {
+                a = desc[ri];
+                if (a.kind != 0 && a.pos < te && a.end > ts) {
+                    np = ext ? n_partners[ri] : 0u;
+                    mi = mate[ri];
+                    if (mi != 0xFFFFFFFFu) b = desc[mi];
+                }
+            }
+            const bool has_mate = mi != 0xFFFFFFFFu;
+            const bool el = a.kind != 0 && a.pos < te && a.end > ts && eligible_fast(a, np, has_mate, b);
+            // clipped run of A: tile offsets [t0, t0 + n), first base = query offset q0
+            const int32_t i0 = ts > a.pos ? ts - a.pos : 0;
+            const int32_t i1 = a.end - a.pos < te - a.pos ? a.end - a.pos : te - a.pos;
+            const uint32_t n_run = el && i1 > i0 ? (uint32_t)(i1 - i0) : 0u;
+            const uint32_t t0 = (uint32_t)(a.pos + i0 - ts);
+            const uint32_t nblk_all = n_run ? ((t0 + n_run - 1u) >> 4) - (t0 >> 4) + 1u : 0u;
+            // (runs of more than eleven blocks -- long reads -- would overflow the map: they stay on the per-position path; the
+            //  test below is repeated there)
+            const uint32_t nblk = nblk_all <= 11u ? nblk_all : 0u;
+            const uint32_t q0 = (uint32_t)a.q_start + (uint32_t)i0;
+            const uint64_t a_seq = a.rec_off + 36u + a.l_name + 4u * (uint32_t)a.n_cigar;
+            const uint64_t a_nib = a_seq + (q0 >> 1);                                   // byte of the run's first base
+            const uint64_t a_qual = a_seq + ((a.l_seq + 1u) >> 1) + q0;                 // quality of the run's first base
+            // B's quality byte at tile offset x: b_q0 + x (only meaningful inside the overlap [ob0, ob1))
+            const uint64_t b_q0 = b.rec_off + 36u + b.l_name + 4u * (uint32_t)b.n_cigar + ((b.l_seq + 1u) >> 1) + b.q_start + (uint64_t)(int64_t)(ts - b.pos);
+            int32_t ob0 = 0, ob1 = 0;
+            if (has_mate) { ob0 = (b.pos > ts ? b.pos : ts) - ts; ob1 = (b.end < te ? b.end : te) - ts; if (ob1 < ob0) ob1 = ob0; }
+            const uint32_t tie = has_mate && !(ri < mi) ? 1u : 0u;                     // ties go to the record later in the file
+            uint32_t incl = nblk;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const uint32_t o = __shfl_up(incl, dlt, 64);
+                if ((int)wlane >= dlt) incl += o;
+            }
+            const uint32_t start = incl - nblk;
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            const uint32_t p0w = (uint32_t)a_nib, p1w = (uint32_t)(a_nib >> 32) | (start << 16) | ((q0 & 1u) << 31);
+            const uint32_t p2w = t0 | (n_run << 16);
+            const uint32_t p3w = (uint32_t)a_qual, p4w = (uint32_t)(a_qual >> 32) | (tie << 16) | ((S > 1 ? (uint32_t)a.sample : 0u) << 17);
+            const uint32_t p5w = (uint32_t)b_q0, p6w = (uint32_t)(b_q0 >> 32);
+            const uint32_t p7w = (uint32_t)ob0 | ((uint32_t)ob1 << 16);
+            for (uint32_t j = 0; j < 11u; ++j)
+                if (j < nblk) map[start + j] = (uint8_t)wlane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
+                const uint32_t g = g0 + wlane;
+                const bool on = g < total;
+                const uint32_t r = on ? (uint32_t)map[g] : 0u;
+                const uint32_t w0 = __shfl(p0w, r, 64), w1 = __shfl(p1w, r, 64), w2 = __shfl(p2w, r, 64), w3 = __shfl(p3w, r, 64);
+                const uint32_t w4 = __shfl(p4w, r, 64), w5 = __shfl(p5w, r, 64), w6 = __shfl(p6w, r, 64), w7 = __shfl(p7w, r, 64);
+                if (!on) continue;
+                const uint32_t rt0 = w2 & 0xFFFFu, rn = w2 >> 16;
+                const uint32_t j = g - ((w1 >> 16) & 0x7FFFu);
+                const uint32_t pb = ((rt0 >> 4) + j) << 4;
+                const uint32_t k0 = pb < rt0 ? rt0 - pb : 0u;
+                const uint32_t k1 = rt0 + rn - pb < 16u ? rt0 + rn - pb : 16u;
+                const uint32_t vm = ((1u << k1) - 1u) & ~((1u << k0) - 1u);
+                // overlap with the mate inside this block
+                const int32_t o0 = (int32_t)(w7 & 0xFFFFu) - (int32_t)pb, o1 = (int32_t)(w7 >> 16) - (int32_t)pb;
+                const uint32_t ok0 = o0 < 0 ? 0u : o0 > 16 ? 16u : (uint32_t)o0, ok1 = o1 < 0 ? 0u : o1 > 16 ? 16u : (uint32_t)o1;
+                const uint32_t ovm = ok1 > ok0 ? ((1u << ok1) - 1u) & ~((1u << ok0) - 1u) : 0u;
+                // sequence nibbles of positions pb .. pb + 15 (stream order), as k_accumulate16b
+                const int32_t d0 = (int32_t)pb - (int32_t)rt0;                                   // >= -15
+                const int32_t qi = (int32_t)(w1 >> 31) + d0;
+                const uint8_t* sp = U + (((uint64_t)(w1 & 0xFFFFu) << 32) | w0) + (qi >> 1);
+                const uint32_t y0 = nibble_swap_m(ld32m(sp)), y1 = nibble_swap_m(ld32m(sp + 4)), y2 = nibble_swap_m(ld32m(sp + 8));
+                const uint32_t nsh = ((uint32_t)qi & 1u) * 4u;
+                const uint32_t b_lo = __builtin_amdgcn_alignbit(y1, y0, nsh), b_hi = __builtin_amdgcn_alignbit(y2, y1, nsh);
+                // qualities of A and of B at the same 16 positions
+                const uint8_t* qa_p = U + (((uint64_t)(w4 & 0xFFFFu) << 32) | w3) + d0;
+                const uint8_t* qb_p = U + (((uint64_t)w6 << 32) | w5) + pb;
+                uint32_t QA[4], QB[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { QA[x] = ld32m(qa_p + 4 * x); QB[x] = ovm ? ld32m(qb_p + 4 * x) : 0u; }
+                const uint32_t tie_r = (w4 >> 16) & 1u, smp = w4 >> 17;
+                uint32_t* cbase = cnt + __umul24(pb >> 2, s7) + __umul24(smp, 7u);
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k) {
+                    const uint32_t wv = k < 8 ? b_lo : b_hi, sh = 4u * (k & 7u);
+                    const uint32_t nib2 = sh ? (wv >> (sh - 1u)) & 0x1Eu : (wv << 1) & 0x1Eu;
+                    const uint32_t code = (((kMLutOff >> nib2) & 3u) << 1) | ((kMLutHalf >> nib2) & 1u);      // A 0 C 1 G 2 T 3 other 4
+                    const uint32_t qa = (QA[k >> 2] >> (8u * (k & 3u))) & 0xFFu, qb = (QB[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
+                    const uint32_t win = (qb - qa - tie_r) >> 31;            // 1: A is the better mate here (qa + tie > qb)
+                    const uint32_t low = (qa - min_bq) >> 31;                 // 1: below the base-quality threshold
+                    const uint32_t v = (vm >> k) & 1u, ov = (ovm >> k) & 1u;
+                    const uint32_t inc = v & (low ^ 1u) & ((ov ^ 1u) | win);
+                    // dword of position pb + k: (k & 3) * sub_dw + ((pb >> 2) + (k >> 2)) * s7
+                    atomicAdd(cbase + (k & 3u) * sub_dw + (k >> 2) * s7 + code, inc);
+                    if (kSpan) atomicAdd(&spn[pb + k], v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     // One record per QUARTER wave and iteration, every lane one reference position of it per pass: a 150-base read
     // fills 16 lanes ten times over (94 % of the lanes busy, 78 % with 64 lanes per read), and the chain of dependent
     // loads a record needs -- descriptor -> mate index -> mate's descriptor -> both reads' bytes -- is in flight for
@@ -276,6 +408,18 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
         const uint32_t sample = S > 1 ? a.sample : 0u;
         const int32_t p0 = a.pos > ts ? a.pos : ts, p1 = a.end < te ? a.end : te;
         const uint32_t np = ext ? n_partners[ri] : 0u;
+        if (fast_path && np <= 1u && single_run_ok(a)) {
+            // handled by phase 1?  (the same test, with the same inputs)
+            const uint32_t mi_f = mate[ri];
+            RecDesc bf;
+            bf.kind = 0; bf.pos = 0; bf.end = 0; bf.l_seq = 0; bf.q_start = 0;
+            if (mi_f != 0xFFFFFFFFu) bf = desc[mi_f];
+            const int32_t fi0 = ts > a.pos ? ts - a.pos : 0;
+            const int32_t fi1 = a.end - a.pos < te - a.pos ? a.end - a.pos : te - a.pos;
+            const uint32_t ft0 = (uint32_t)(a.pos + fi0 - ts), fn = fi1 > fi0 ? (uint32_t)(fi1 - fi0) : 0u;
+            const uint32_t fblk = fn ? ((ft0 + fn - 1u) >> 4) - (ft0 >> 4) + 1u : 0u;
+            if (eligible_fast(a, np, mi_f != 0xFFFFFFFFu, bf) && fblk <= 11u) continue;
+        }
         if (np >= 2u) {
             // ---- two or three same-name partners: pairing and status per interval of constant company ----------------
             const MultiPlan P = plan_multi(desc, ri, a, ext, np);
@@ -447,15 +591,17 @@ void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const ui
                              int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, const uint32_t* d_ext,
                              const uint32_t* d_n_partners, uint32_t* d_too_many, uint32_t* d_counters, uint32_t* d_span, hipStream_t stream) {
     if (!n_active) return;
-    size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0);
+    static const int fast = [] { const char* e = getenv("SBX_K7_VARIANT"); return e ? atoi(e) : 1; }();
+    size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0) +
+                 (fast ? (size_t)(kMateThreads / 64) * kMateMapBytes : 0);
     if (d_span) {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate_mates<true>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,
-                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_ext, d_n_partners, d_too_many, d_counters, d_span);
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_ext, d_n_partners, d_too_many, d_counters, d_span, fast);
     } else {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate_mates<false>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,
-                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_ext, d_n_partners, d_too_many, d_counters, d_span);
+                           d_tile_hi, d_active, d_tile_base, n_ref, tile_pos, n_samples, min_bq, d_ext, d_n_partners, d_too_many, d_counters, d_span, fast);
     }
     SBX_HIP(hipGetLastError());
 }
