@@ -840,7 +840,10 @@ int depth_main(int argc, char** argv) {
             {
                 uint64_t total = 0;
                 for (int r = 0; r < hi.n_ref; ++r) total += (uint64_t)std::max<int64_t>(0, sbx_ref_length(ctx, r));
-                uint64_t want = std::max<uint64_t>(total / 8, 16u << 20);
+                // four slices of a chromosome-sized job: each slice still fills the device once (the lane-per-block Huffman kernel takes
+                // one residency, ~16 ms, however few blocks it gets), and the text of the whole job -- what the pipeline is
+                // bound by -- starts to flow after a quarter of the upload
+                uint64_t want = std::max<uint64_t>(total / 4, 16u << 20);
                 if (const char* e = getenv("SBX_SLICE_POSITIONS")) want = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
                 want = (want + 1023) / 1024 * 1024;
                 for (int r = 0; r < hi.n_ref; ++r) {
@@ -859,12 +862,16 @@ int depth_main(int argc, char** argv) {
             std::vector<int> uploaded(sl.size(), 0), computed(sl.size(), 0), printed(sl.size(), 0);
             std::string failure;
             bool opened2 = false;
+            double busy_up = 0, busy_run = 0, busy_print = 0, t_open2 = 0;       // seconds every stage was working (SBX_TIMING)
+            std::vector<double> done_at(sl.size(), 0);
             auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> g(mu); if (failure.empty()) failure = m; cv.notify_all(); };
             auto wait_for = [&](auto&& pred) { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return !failure.empty() || pred(); }); return failure.empty(); };
             auto mark = [&](std::vector<int>& v, size_t k) { std::lock_guard<std::mutex> g(mu); v[k] = 1; cv.notify_all(); };
             std::thread opener([&] {       // the second context opens while the first slice is on its way
                 char e2[512] = {0};
+                const double to = now();
                 sbx_ctx* c2 = sl.size() > 1 ? sbx_open(paths.data(), (int)paths.size(), -1, e2, sizeof e2) : nullptr;
+                t_open2 = now() - to;
                 if (sl.size() > 1 && !c2) { fail(e2); return; }
                 if (c2 && (sbx_set_filter(c2, &filt) != SBX_OK ||
                            sbx_set_params(c2, mode_id, (uint8_t)o.min_bq, o.fix_mate, o.combined, (uint32_t)o.window, (uint32_t)o.overlap,
@@ -879,7 +886,9 @@ int depth_main(int argc, char** argv) {
                     if (!wait_for([&] { return (k & 1) == 0 || opened2; })) return;
                     if (k >= 2 && !wait_for([&] { return computed[k - 2] != 0; })) return;       // the context's compressed bytes are free again
                     sbx_ctx* c = cx[k & 1];
+                    const double tu = now();
                     if (sbx_prefetch_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end) != SBX_OK) { fail(sbx_last_error(c)); return; }
+                    busy_up += now() - tu;
                     mark(uploaded, k);
                 }
             });
@@ -887,7 +896,9 @@ int depth_main(int argc, char** argv) {
                 for (size_t k = 0; k < sl.size(); ++k) {
                     if (!wait_for([&] { return uploaded[k] != 0 && (k < 2 || printed[k - 2] != 0); })) return;
                     sbx_ctx* c = cx[k & 1];
+                    const double tr = now();
                     if (sbx_run_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end) != SBX_OK) { fail(sbx_last_error(c)); return; }
+                    busy_run += now() - tr;
                     mark(computed, k);
                 }
             });
@@ -895,16 +906,25 @@ int depth_main(int argc, char** argv) {
             const double t0 = now();
             for (size_t k = 0; k < sl.size(); ++k) {
                 if (!wait_for([&] { return computed[k] != 0; })) break;
+                const double tp = now();
                 try { bp.run_slice(cx[k & 1], sl[k].ref, sl[k].beg, sl[k].print_end); }
                 catch (const Fail& f) { fail(f.msg); break; }
+                busy_print += now() - tp;
+                done_at[k] = now() - t0;
                 mark(printed, k);
             }
             opener.join(); uploader.join(); computer.join();
             if (!failure.empty()) { if (cx[1]) sbx_close(cx[1]); throw Fail{failure}; }
             out.flush();
             if (out.fp != stdout) fclose(out.fp);
-            if (timing) fprintf(stderr, "[sbx-depth] open %.3f s, %zu slices through upload / kernels / text in %.3f s, total %.3f s since main\n",
-                                t_open - t_start, sl.size(), now() - t0, now() - t_start);
+            if (timing) {
+                fprintf(stderr, "[sbx-depth] open %.3f s, %zu slices through upload / kernels / text in %.3f s (stages busy: upload %.3f, kernels %.3f, text %.3f; "
+                                "second context opened in %.3f s), total %.3f s since main\n",
+                        t_open - t_start, sl.size(), now() - t0, busy_up, busy_run, busy_print, t_open2, now() - t_start);
+                std::string tl;
+                for (double x : done_at) { char b[32]; snprintf(b, sizeof b, " %.3f", x); tl += b; }
+                fprintf(stderr, "[sbx-depth] slices printed at%s s\n", tl.c_str());
+            }
             // the process ends here: device memory, mappings and streams go with it (an orderly sbx_close of two contexts
             // frees tens of gigabytes buffer by buffer and costs 0.1 s that no caller is waiting for)
             if (!getenv("SBX_ORDERLY_EXIT")) { fflush(nullptr); _exit(0); }
@@ -939,6 +959,7 @@ int depth_main(int argc, char** argv) {
         out.flush();
         if (out.fp != stdout) fclose(out.fp);
         const double t_out = now();
+        if (!getenv("SBX_ORDERLY_EXIT") && !timing) { fflush(nullptr); _exit(0); }      // (see the pipelined path: nobody waits for the frees)
         sbx_close(ctx);
         if (timing)
             fprintf(stderr, "[sbx-depth] open %.3f s, run %.3f s, print %.3f s, finish %.3f s, close %.3f s, total %.3f s since main\n", t_open - t_start,

@@ -33,6 +33,8 @@ struct Error : std::runtime_error {
 inline double& alloc_seconds() { static double s = 0; return s; }
 inline double wall_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
+inline double& devbuf_slack_pct() { static double p = 0.0; return p; }      // see DevBuf::ensure
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -61,8 +63,10 @@ struct DevBuf {
             }
         }
     }
-    // grow-only (keeps the allocation when it is already large enough)
-    void ensure(size_t count) { if (count > n) alloc(count); }
+    // grow-only (keeps the allocation when it is already large enough).  A buffer that has to grow takes `slack_pct` percent
+    // more than asked for: consecutive runs of similar size (the slices of a pipelined job, the batches of a genome) then
+    // keep their allocations -- hipFree synchronises the whole device, which stalls every other stream.
+    void ensure(size_t count) { if (count > n) alloc(count + (size_t)((double)count * devbuf_slack_pct() / 100.0)); }
     void release() {
         if (p) { const double t0 = wall_now(); (void)hipFree(p); alloc_seconds() += wall_now() - t0; }
         p = nullptr; n = 0;

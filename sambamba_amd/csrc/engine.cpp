@@ -934,6 +934,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     // descriptor capacity: sized for records of >= 160 bytes on average; K2 reports an overflow and the pass is repeated
     // with the exact number (short-read fixtures, amplicon data with tiny records)
     uint64_t want_cap = std::max<uint64_t>(c->desc_cap, w.u_bytes / 160 + 4096);
+    if (want_cap > c->desc_cap) want_cap += (uint64_t)((double)want_cap * devbuf_slack_pct() / 100.0);
     const bool dbg = getenv("SBX_DEBUG") != nullptr;
     const char* force = getenv("SBX_FORCE_REPAIR");   // debug hook (tests/test_gpu_repair.py)
     // tiles with this many records or more keep 32-bit LDS counters in K3 (debug hook: a small value sends ordinary tiles
@@ -1341,6 +1342,7 @@ int sbx_prefetch_interval(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t en
         if (ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
         if (!(beg < end)) throw Error(SBX_EINVAL, "empty interval");
         if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
+        if (devbuf_slack_pct() < 8.0) devbuf_slack_pct() = 8.0;       // slices of similar size follow: no buffer should have to grow twice
         std::vector<sbx_region> sel;
         if (c->regions.empty()) sel.push_back({ref_id, beg, end});
         else
@@ -1949,7 +1951,8 @@ int sbx_stream_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end
         SBX_HIP(hipSetDevice(c->device));
         hipStream_t s = c->stream;
         FormatArgs a = format_args(c, ref_id, min_cov, max_cov, annotate, s);
-        uint64_t piece = 4u << 20;                // positions per piece (~110 MB of text at one sample, 30x)
+        uint64_t piece = 2u << 20;                // positions per piece (~55 MB of text at one sample, 30x: the two pinned buffers
+                                                  // of a context are allocated on first use, 15 ms each at this size)
         if (const char* e = getenv("SBX_STREAM_PIECE")) { const long v = atol(e); if (v >= 256) piece = (uint64_t)v; }      // (tests)
         for (int i = 0; i < 2; ++i) {
             if (!c->text_ev_fmt[i]) SBX_HIP(hipEventCreateWithFlags(&c->text_ev_fmt[i], hipEventDisableTiming));

@@ -695,36 +695,51 @@ __global__ __launch_bounds__(kWalkThreads) void k_rewalk_mismatched(IndexArgs a,
 // state[b] = 2 << 62 | records in blocks 0..b (the engine reads the last one); flags[0] = lowest inconsistent block,
 // flags[2] != 0: the descriptor array is too small for the total
 __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
-    // 1024 blocks per step, coalesced: inclusive scan inside the wave by shuffles, wave totals through LDS
-    __shared__ uint64_t wtot[kScanThreads / 64];
+    // 4 x 1024 blocks per step, coalesced; the loads of all four sub-steps are issued before the first scan, so that the single
+    // workgroup pays one memory round trip per 4096 blocks (it is the serial link between the walk and the describe launches);
+    // inclusive scan inside the wave by shuffles, wave totals through LDS
+    constexpr int kSub = 4;
+    __shared__ uint64_t wtot[kSub][kScanThreads / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6, n = a.n_blocks;
     uint64_t run = 0;                    // records in the blocks before this step (workgroup-uniform)
     uint32_t first_bad = 0xFFFFFFFFu;
-    for (uint32_t i0 = 0; i0 < n; i0 += kScanThreads) {
-        const uint32_t i = i0 + t;
-        uint64_t v = 0;
-        if (i < n) {
-            v = a.count[i];
-            const ChainRun r = a.runs[a.run_of[i]];
-            if (i != r.blk_first && a.exit_[i - 1] != a.entry[i] && first_bad == 0xFFFFFFFFu) first_bad = i;
-        }
-        uint64_t incl = v;
+    for (uint32_t i0 = 0; i0 < n; i0 += kSub * kScanThreads) {
+        uint64_t v[kSub], incl[kSub];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t o = (uint64_t)__shfl_up((unsigned long long)incl, d, 64);
-            if ((int)lane >= d) incl += o;
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+            v[u] = 0;
+            if (i < n) {
+                v[u] = a.count[i];
+                const ChainRun r = a.runs[a.run_of[i]];
+                if (i != r.blk_first && a.exit_[i - 1] != a.entry[i] && first_bad == 0xFFFFFFFFu) first_bad = i;
+            }
         }
-        if (lane == 63) wtot[wv] = incl;
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            uint64_t x = v[u];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint64_t o = (uint64_t)__shfl_up((unsigned long long)x, d, 64);
+                if ((int)lane >= d) x += o;
+            }
+            incl[u] = x;
+            if (lane == 63) wtot[u][wv] = x;
+        }
         __syncthreads();
-        uint64_t before = 0, all = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
-            const uint64_t x = wtot[w];
-            before += w < wv ? x : 0;
-            all += x;
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+            uint64_t before = 0, all = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+                const uint64_t x = wtot[u][w];
+                before += w < wv ? x : 0;
+                all += x;
+            }
+            if (i < n) a.state[i] = (2ull << 62) | (run + before + incl[u]);
+            run += all;
         }
-        if (i < n) a.state[i] = (2ull << 62) | (run + before + incl);
-        run += all;
         __syncthreads();
     }
     if (first_bad != 0xFFFFFFFFu) atomicMin(a.flags + 0, first_bad);
@@ -734,7 +749,7 @@ __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
 // ---- 3. describe: one wave per block, one lane per record ---------------------------------------------------
 constexpr int kDescThreads = 256;
 
-__global__ __launch_bounds__(kDescThreads) void k_describe_blocks(IndexArgs a) {
+__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks(IndexArgs a) {
     __shared__ uint32_t tot[7];          // records, admitted, malformed, unknown read group of this workgroup's blocks; bytes K3 reads; longest span
     if (threadIdx.x < 7) tot[threadIdx.x] = 0;
     __syncthreads();
@@ -820,38 +835,53 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* _
                                                                 const uint32_t* __restrict__ tile_hi, uint32_t n_tiles, uint32_t deep_thr,
                                                                 uint32_t* __restrict__ active, uint32_t* __restrict__ slot_of,
                                                                 uint32_t* __restrict__ n_active) {
-    // 1024 tiles per step, coalesced: rank inside the wave by ballot, wave totals through LDS
-    __shared__ uint32_t wtot[kScanThreads / 64];
+    // 4 x 1024 tiles per step, coalesced, the loads of the four sub-steps in flight together: rank inside the wave by ballot,
+    // wave totals through LDS
+    constexpr int kSub = 4;
+    __shared__ uint32_t wtot[kSub][kScanThreads / 64];
     __shared__ uint32_t deep_total;
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     if (t == 0) deep_total = 0;
     uint32_t n_deep = 0;                 // this thread's tiles with >= 2^16 records (K3 keeps 32-bit counters for them)
     uint32_t run = 0;                    // active tiles before this step (workgroup-uniform)
-    for (uint32_t i0 = 0; i0 < n_tiles; i0 += kScanThreads) {
-        const uint32_t i = i0 + t;
-        const uint32_t lo_i = i < n_tiles ? tile_lo[i] : 0u, hi_i = i < n_tiles ? tile_hi[i] : 0u;
-        const bool on = hi_i > lo_i;
-        n_deep += on && hi_i - lo_i >= deep_thr ? 1u : 0u;
-        const uint64_t m = __ballot(on);
-        if (lane == 0) wtot[wv] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = 0, all = 0;
+    for (uint32_t i0 = 0; i0 < n_tiles; i0 += kSub * kScanThreads) {
+        uint32_t lo_i[kSub], hi_i[kSub];
 #pragma unroll
-        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
-            const uint32_t v = wtot[w];
-            before += w < wv ? v : 0u;
-            all += v;
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+            lo_i[u] = i < n_tiles ? tile_lo[i] : 0u;
+            hi_i[u] = i < n_tiles ? tile_hi[i] : 0u;
         }
-        if (i < n_tiles) {
-            if (on) {
-                const uint32_t slot = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                active[slot] = i;
-                slot_of[i] = slot;
-            } else {
-                slot_of[i] = 0xFFFFFFFFu;
+        uint64_t m[kSub];
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            const bool on = hi_i[u] > lo_i[u];
+            n_deep += on && hi_i[u] - lo_i[u] >= deep_thr ? 1u : 0u;
+            m[u] = __ballot(on);
+            if (lane == 0) wtot[u][wv] = (uint32_t)__popcll(m[u]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+                const uint32_t x = wtot[u][w];
+                before += w < wv ? x : 0u;
+                all += x;
             }
+            if (i < n_tiles) {
+                if (hi_i[u] > lo_i[u]) {
+                    const uint32_t slot = run + before + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
+                    active[slot] = i;
+                    slot_of[i] = slot;
+                } else {
+                    slot_of[i] = 0xFFFFFFFFu;
+                }
+            }
+            run += all;
         }
-        run += all;
         __syncthreads();
     }
     if (n_deep) atomicAdd(&deep_total, n_deep);
