@@ -959,7 +959,13 @@ int depth_main(int argc, char** argv) {
         out.flush();
         if (out.fp != stdout) fclose(out.fp);
         const double t_out = now();
-        if (!getenv("SBX_ORDERLY_EXIT") && !timing) { fflush(nullptr); _exit(0); }      // (see the pipelined path: nobody waits for the frees)
+        if (!getenv("SBX_ORDERLY_EXIT")) {      // (see the pipelined path: nobody waits for the frees)
+            if (timing)
+                fprintf(stderr, "[sbx-depth] open %.3f s, run %.3f s, print %.3f s, finish %.3f s, total %.3f s since main (exit without freeing)\n",
+                        t_open - t_start, t_run, t_print, t_out - t_open - t_run - t_print, now() - t_start);
+            fflush(nullptr);
+            _exit(0);
+        }
         sbx_close(ctx);
         if (timing)
             fprintf(stderr, "[sbx-depth] open %.3f s, run %.3f s, print %.3f s, finish %.3f s, close %.3f s, total %.3f s since main\n", t_open - t_start,
