@@ -33,6 +33,9 @@ enum SBX_FILTER_REGEXES = 2;
 enum SBX_REGEX_STATES = 64;
 enum SBX_REGEX_CLASSES = 8;
 
+/// The writer handed to sbx_stream_base_rows: C linkage, but neither nothrow nor @nogc -- the D side writes to a File.
+alias sbx_write_fn = extern (C) int function(void* user, const(char)* data, size_t n);
+
 extern (C) nothrow @nogc {
     struct sbx_ctx;
     struct sbx_region { uint ref_id; uint start; uint end; }
@@ -105,7 +108,6 @@ extern (C) nothrow @nogc {
     int sbx_depth_window_stats(sbx_ctx*, uint ref_id, ulong first_win, ulong n_win, sbx_region_stats*, uint* cov_counts);
     int sbx_format_base_rows(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
                              char* out_buf, size_t cap, size_t* out_len);
-    alias sbx_write_fn = int function(void* user, const(char)* data, size_t n);
     int sbx_stream_base_rows(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
                              sbx_write_fn write, void* user);
     int sbx_last_run_stats(sbx_ctx*, sbx_run_stats*);
@@ -151,17 +153,76 @@ private void printRegionRow(File output, ref const SbxDepthOptions o, string pre
     output.write('\n');
 }
 
+/// The writer of base rows: the File the caller opened for -o / stdout.
+extern (C) int sbxFileSink(void* user, const(char)* data, size_t n) {
+    try { (cast(File*) user).rawWrite(data[0 .. n]); return 0; } catch (Exception) { return 1; }
+}
+
+/// Position of the first pileup column of contigs [r0, r1) of the resident run (cli.cpp first_column): exact, from the
+/// `covered` bytes of sbx_depth_base_tile -- sbx_next_active_range alone is tile granular.
+private bool firstColumn(sbx_ctx* ctx, uint r0, uint r1, out uint fref, out ulong fpos) {
+    uint T, S;
+    sbxEnforce(ctx, sbx_tile_info(ctx, &T, &S));
+    foreach (r; r0 .. r1) {
+        ulong from = 0, b, e;
+        for (;;) {
+            sbxEnforce(ctx, sbx_next_active_range(ctx, r, from, &b, &e));
+            if (b == ulong.max) break;
+            for (ulong p = b; p < e; p += 65536) {
+                const ulong q = min(e, p + 65536);
+                auto cnt = new uint[cast(size_t)(q - p) * S * SBX_NCOUNTERS];
+                auto cov = new ubyte[cast(size_t)(q - p)];
+                sbxEnforce(ctx, sbx_depth_base_tile(ctx, r, cast(uint) p, cast(uint) q, cnt.ptr, cov.ptr));
+                foreach (x; 0 .. cov.length) if (cov[x]) { fref = r; fpos = p + x; return true; }
+            }
+            from = e;
+        }
+    }
+    return false;
+}
+
+/// Position of the last pileup column of contig r, which has one (cli.cpp WindowPrinter.last_column).
+private ulong lastColumn(sbx_ctx* ctx, uint r) {
+    uint T, S;
+    sbxEnforce(ctx, sbx_tile_info(ctx, &T, &S));
+    ulong from = 0, lb = 0, le = 0, b, e;
+    for (;;) {
+        sbxEnforce(ctx, sbx_next_active_range(ctx, r, from, &b, &e));
+        if (b == ulong.max) break;
+        lb = b; le = e; from = e;
+    }
+    for (ulong q = le; q > lb;) {
+        const ulong p = q > lb + 65536 ? q - 65536 : lb;
+        auto cnt = new uint[cast(size_t)(q - p) * S * SBX_NCOUNTERS];
+        auto cov = new ubyte[cast(size_t)(q - p)];
+        sbxEnforce(ctx, sbx_depth_base_tile(ctx, r, cast(uint) p, cast(uint) q, cnt.ptr, cov.ptr));
+        for (ulong x = q; x > p; --x) if (cov[cast(size_t)(x - 1 - p)]) return x - 1;
+        q = p;
+    }
+    return 0;
+}
+
 /**
  * Replacement of depth.d:1163-1234 ("new MultiBamReader ... printer.close()").  depth_main keeps its option
  * parsing and its BED parsing (parseBed / parseRegion need the reference dictionary: use sbxOpen first and
  * sbx_ref_id / sbx_ref_length in place of bam.hasReference / bam[name]) and calls this with the opened context.
  * The header lines (`REF\tPOS...` / `# chrom\t...`) are printed by the caller exactly as printer.init() does.
  *
- * Text rules are the reference's: base rows come formatted from the device (K6 reproduces writeColumn /
- * writeEmptyColumns byte for byte), region and window rows are printed here with printRegionStats' rules.
- * Two stateful corners stay with the reference's own CPU code path (return false -> the caller runs the old
- * body of depth_main): `base -L` together with `-c 0`, and `window --overlap > 0`; sambamba_amd/csrc/cli.cpp
- * shows how to drive the same ABI for them.
+ * Text rules are the reference's, and the same as sambamba_amd/csrc/cli.cpp applies (the compiled host that the test-suite
+ * compares with the reference's goldens and with the oracle):
+ *   base    rows come formatted from the device (K6 reproduces writeColumn / writeEmptyColumns byte for byte).  With -c 0 a
+ *           contig WITHOUT pileup columns is zero-filled only before the first and after the last contig that has some
+ *           (push() fills from the previous column's contig straight to the current one, depth.d:574-583; close() fills what
+ *           follows the last column, depth.d:593-606); columns of alignments hanging over a contig end are printed too.
+ *   region  printRegionStats' rules; rows only if some column fell inside some region (lazily created samples, B-12).
+ *   window  (overlap 0) nothing before the first pileup column of the run -- the exact column, not its tile --; a contig
+ *           with columns prints every window finished by its columns or by its length (alignments hanging over the end finish
+ *           windows beyond it); read-less contigs between two contigs with columns print length / w all-zero windows; the
+ *           FIRST read-less contig after the last contig with columns continues that contig's window coordinates and its
+ *           first row shows what the unfinished window held (close() does not reset the ring, depth.d:1070-1076).
+ * Stateful corners that stay with the reference's own CPU code path (return false -> the caller runs the old body of
+ * depth_main; cli.cpp shows how to drive the same ABI for them): `base -L` together with `-c 0`, `window --overlap > 0`,
+ * and `base -c 0` when alignments hang over a contig end (host-side column rows).
  */
 bool sbxDepthRun(sbx_ctx* ctx, ref const SbxDepthOptions o, File output) {
     if (o.mode == SBX_MODE_BASE && o.merged_bed.length && o.min_cov <= 0) return false;
@@ -186,6 +247,7 @@ bool sbxDepthRun(sbx_ctx* ctx, ref const SbxDepthOptions o, File output) {
     foreach (s; 0 .. hi.n_samples) samples ~= fromStringz(sbx_sample_name(ctx, s)).idup;
     const uint S = o.combined ? 1 : cast(uint) samples.length;
     const size_t n_thr = max(1, o.cov_thresholds.length);
+    const ulong w = o.window_size;
 
     // the device takes the file in batches of contigs sized to its free memory (one batch unless whole-genome sized)
     size_t n_batches;
@@ -197,37 +259,94 @@ bool sbxDepthRun(sbx_ctx* ctx, ref const SbxDepthOptions o, File output) {
     auto r_st = new sbx_region_stats[o.raw_bed.length * S];
     auto r_cov = new uint[o.raw_bed.length * S * n_thr];
     auto r_seen = new ubyte[o.raw_bed.length];
-    bool seen_columns = false;       // window mode: nothing is printed before the first pileup column (SURVEY App. B-12)
+
+    // base -c 0: contigs without columns seen since the last contig that had some (cli.cpp BasePrinter.pending_empty_)
+    bool base_seen_columns = false;
+    uint[] base_pending_empty;
+    // window mode (cli.cpp WindowPrinter): first column of the run, the last contig with columns, what its unfinished window holds
+    bool have_first = false;
+    uint fref = 0;
+    ulong fpos = 0;
+    int last_cols_ref = -1;
+    ulong last_nl = 0;
+    sbx_region_stats[] stale_st;
+    uint[] stale_cov;
+    uint[] win_pending_empty;
+
+    void emitBase(uint r, ulong p, ulong q, double min_cov) {
+        if (q <= p) return;
+        sbxEnforce(ctx, sbx_stream_base_rows(ctx, r, cast(uint) p, cast(uint) q, min_cov, o.max_cov, o.annotate ? 1 : 0,
+                                             &sbxFileSink, &output));
+    }
+    void windowRows(string name, ulong start, const(sbx_region_stats)[] st, const(uint)[] cov) {
+        const prefix = name ~ "\t" ~ start.to!string ~ "\t" ~ (start + w).to!string ~ "\t";
+        foreach (s; 0 .. S) {
+            sbx_region_stats z;
+            auto zc = new uint[n_thr];
+            printRegionRow(output, o, prefix, cast(uint) w, st.length ? st[s] : z, cov.length ? cov[s * n_thr .. (s + 1) * n_thr] : zc, samples[s]);
+        }
+    }
+    void zeroWindows(uint r) {                                                           // printEmptyWindows, depth.d:1039-1044
+        const ulong cnt = cast(ulong) max(0L, sbx_ref_length(ctx, cast(int) r)) / w;
+        const name = fromStringz(sbx_ref_name(ctx, cast(int) r)).idup;
+        foreach (k; 0 .. cnt) windowRows(name, k * w, null, null);
+    }
+    // statistics of windows [k0, k1) of contig r as [k][S] / [k][S][n_thr]: the engine's window statistics for windows inside the
+    // contig, region statistics for windows that end beyond it
+    void windowStats(uint r, ulong k0, ulong k1, ref sbx_region_stats[] st, ref uint[] cov) {
+        const size_t n = cast(size_t)(k1 - k0);
+        st = new sbx_region_stats[n * S];
+        cov = new uint[n * S * n_thr];
+        if (!n) return;
+        const ulong len = cast(ulong) max(0L, sbx_ref_length(ctx, cast(int) r));
+        if (k1 * w <= len) { sbxEnforce(ctx, sbx_depth_window_stats(ctx, r, k0, k1 - k0, st.ptr, cov.ptr)); return; }
+        auto reg = new sbx_region[n];
+        foreach (i; 0 .. n) reg[i] = sbx_region(r, cast(uint)((k0 + i) * w), cast(uint)((k0 + i) * w + w));
+        auto seen = new ubyte[n];
+        auto cov1 = new uint[n * S * n_thr];
+        sbxEnforce(ctx, sbx_depth_region_stats(ctx, reg.ptr, n, st.ptr, cov1.ptr, seen.ptr));
+        foreach (i; 0 .. n * S) foreach (t; 0 .. o.cov_thresholds.length) cov[i * n_thr + t] = cov1[i * o.cov_thresholds.length + t];
+    }
 
     foreach (b; plan) {
         if (plan.length == 1) sbxEnforce(ctx, sbx_run(ctx));
         else sbxEnforce(ctx, sbx_run_batch(ctx, b.first_ref, b.n_refs));
-        foreach (r; b.first_ref .. b.first_ref + b.n_refs) {
+        const uint r0 = b.first_ref, r1 = b.first_ref + b.n_refs;
+        if (o.mode == SBX_MODE_WINDOW && !have_first) {
+            if (!firstColumn(ctx, r0, r1, fref, fpos)) continue;                          // no column yet: windows so far print nothing
+            have_first = true;
+        }
+        foreach (r; r0 .. r1) {
             const name = fromStringz(sbx_ref_name(ctx, cast(int) r)).idup;
             const ulong len = cast(ulong) max(0L, sbx_ref_length(ctx, cast(int) r));
             stderr.writeln("Processing reference #", r + 1, " (", name, ")");           // depth.d:1225-1229
+            ulong act_b, act_e;
+            sbxEnforce(ctx, sbx_next_active_range(ctx, r, 0, &act_b, &act_e));
+            const bool has_columns = act_b != ulong.max;
             final switch (o.mode) {
             case SBX_MODE_BASE:
-                // rows of [p, q) formatted on the device; with -c > 0 only active stretches can hold rows
-                // (sbx_stream_base_rows hands the text over piece by piece from pinned buffers while the device formats
-                // and copies the next piece; sbx_format_base_rows into a caller buffer is the synchronous form)
-                void emit(ulong p, ulong q) {
-                    static extern (C) int sink(void* user, const(char)* data, size_t n) {
-                        try { (cast(File*) user).rawWrite(data[0 .. n]); return 0; } catch (Exception) { return 1; }
-                    }
-                    sbxEnforce(ctx, sbx_stream_base_rows(ctx, r, cast(uint) p, cast(uint) q, o.min_cov, o.max_cov, o.annotate ? 1 : 0,
-                                                         &sink, &output));
-                }
                 if (o.merged_bed.length) {
-                    foreach (g; o.merged_bed) if (g.ref_id == r) emit(g.start, g.end);     // outputRequired, depth.d:558-565
+                    foreach (g; o.merged_bed) if (g.ref_id == r) emitBase(r, g.start, g.end, o.min_cov);     // outputRequired, depth.d:558-565
                 } else if (o.min_cov <= 0) {
-                    emit(0, len);          // (contigs without columns between two with columns: see cli.cpp BasePrinter)
+                    if (!has_columns) {
+                        if (!base_seen_columns) emitBase(r, 0, len, o.min_cov);            // before the first contig with columns: zero rows
+                        else base_pending_empty ~= r;                                      // decided when the next contig with columns / the end comes
+                        break;
+                    }
+                    base_seen_columns = true;
+                    base_pending_empty.length = 0;                                         // skipped: push() jumps to the current contig
+                    // columns beyond the contig end (alignments hanging over it) are column rows, not zero rows: cli.cpp prints
+                    // them on the host; here the job goes back to the reference's own code path
+                    ulong ob, oe;
+                    sbxEnforce(ctx, sbx_next_active_range(ctx, r, len, &ob, &oe));
+                    if (ob != ulong.max) return false;
+                    emitBase(r, 0, len, o.min_cov);
                 } else {
                     ulong from = 0, rb, re;
                     for (;;) {
                         sbxEnforce(ctx, sbx_next_active_range(ctx, r, from, &rb, &re));
                         if (rb == ulong.max) break;
-                        emit(rb, min(re, len + 1024));
+                        emitBase(r, max(rb, from), re, o.min_cov);                         // (tiles beyond `len`: the contig's spare tile)
                         from = re;
                     }
                 }
@@ -251,27 +370,48 @@ bool sbxDepthRun(sbx_ctx* ctx, ref const SbxDepthOptions o, File output) {
                 }
                 break;
             case SBX_MODE_WINDOW:
-                const ulong n_win = len / o.window_size;            // only full windows are printed (depth.d:1057,1071)
-                ulong first_col, fc_end;
-                sbxEnforce(ctx, sbx_next_active_range(ctx, r, 0, &first_col, &fc_end));
-                if (first_col == ulong.max && !seen_columns) break;  // lazily created `samples`: nothing before the first column
-                ulong k0 = 0;
-                if (!seen_columns) { k0 = first_col / o.window_size; seen_columns = true; }   // (exact first column: cli.cpp first_column)
-                enum ulong CHW = 1u << 20;
-                for (ulong k = k0; k < n_win; k += CHW) {
-                    const ulong n = min(CHW, n_win - k);
-                    auto st = new sbx_region_stats[cast(size_t) n * S];
-                    auto cv = new uint[cast(size_t) n * S * n_thr];
-                    sbxEnforce(ctx, sbx_depth_window_stats(ctx, r, k, n, st.ptr, cv.ptr));
-                    foreach (i; 0 .. n) foreach (s; 0 .. S) {
-                        const beg = (k + i) * o.window_size;
-                        printRegionRow(output, o, name ~ "\t" ~ beg.to!string ~ "\t" ~ (beg + o.window_size).to!string ~ "\t",
-                                       o.window_size, st[cast(size_t)(i * S + s)],
-                                       cv[cast(size_t)((i * S + s) * o.cov_thresholds.length) .. $], samples[s]);
+                if (r < fref) break;                                                       // before the first column of the run: nothing
+                if (!has_columns) { win_pending_empty ~= r; break; }
+                foreach (e; win_pending_empty) zeroWindows(e);                             // read-less contigs between two with columns
+                win_pending_empty.length = 0;
+                // windows finished by the contig's columns or by its length; alignments hanging over the end finish windows beyond it
+                const ulong lastcol = lastColumn(ctx, r);
+                const ulong nw = max(len >= w ? (len - w) / w + 1 : 0, lastcol >= w ? (lastcol - w) / w + 1 : 0);
+                enum ulong CHW = 1u << 18;
+                for (ulong k0 = 0; k0 < nw; k0 += CHW) {
+                    const ulong k1 = min(nw, k0 + CHW);
+                    sbx_region_stats[] st;
+                    uint[] cv;
+                    windowStats(r, k0, k1, st, cv);
+                    foreach (k; k0 .. k1) {
+                        if (r == fref && k * w + w <= fpos) continue;                      // finished before the first column of the run
+                        const size_t i = cast(size_t)(k - k0);
+                        windowRows(name, k * w, st[i * S .. (i + 1) * S], cv[i * S * n_thr .. (i + 1) * S * n_thr]);
                     }
                 }
+                last_cols_ref = cast(int) r;
+                last_nl = nw;
+                windowStats(r, nw, nw + 1, stale_st, stale_cov);                           // what the ring (one slot at overlap 0) still holds
                 break;
             }
+        }
+    }
+    if (o.mode == SBX_MODE_BASE && !o.merged_bed.length && o.min_cov <= 0)
+        foreach (r; base_pending_empty)                                                   // close(): everything after the last column
+            emitBase(r, 0, cast(ulong) max(0L, sbx_ref_length(ctx, cast(int) r)), o.min_cov);
+    if (o.mode == SBX_MODE_WINDOW && have_first) {
+        bool first = true;
+        foreach (e; win_pending_empty) {
+            if (first && last_cols_ref >= 0) {
+                // close() does not reset the ring: this contig continues the previous one's window coordinates
+                const ulong cnt = cast(ulong) max(0L, sbx_ref_length(ctx, cast(int) e)) / w;
+                const name = fromStringz(sbx_ref_name(ctx, cast(int) e)).idup;
+                foreach (i; 0 .. cnt) {
+                    if (i < 1) windowRows(name, (last_nl + i) * w, stale_st[0 .. S], stale_cov[0 .. S * n_thr]);
+                    else windowRows(name, (last_nl + i) * w, null, null);
+                }
+            } else zeroWindows(e);
+            first = false;
         }
     }
     if (o.mode == SBX_MODE_REGION) {

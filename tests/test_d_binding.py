@@ -118,3 +118,27 @@ def test_d_declares_every_function_of_the_header():
 def test_d_glue_is_code_not_a_comment():
     text = _d_source()
     assert re.search(r"\bbool\s+sbxDepthRun\s*\(", text) and "sbx_stream_base_rows(ctx" in text and "sbx_depth_window_stats(ctx" in text
+
+
+def test_d_glue_covers_or_refuses_every_stateful_corner_of_the_compiled_host():
+    """d/sbx_depth.d cannot be compiled here; what can be checked is that, for every order-dependent rule cli.cpp implements
+    (and the GPU tests pin against the oracle), the D glue either carries the same rule or hands the job back to the
+    reference's CPU path (`return false`) -- never prints something else."""
+    d = open(os.path.join(ROOT, "d", "sbx_depth.d")).read()
+    cli = open(os.path.join(ROOT, "sambamba_amd", "csrc", "cli.cpp")).read()
+    body = d[d.index("bool sbxDepthRun("):]
+    # refusals
+    assert "o.mode == SBX_MODE_BASE && o.merged_bed.length && o.min_cov <= 0) return false" in body      # base -L with -c 0
+    assert "o.mode == SBX_MODE_WINDOW && o.overlap != 0) return false" in body                            # window --overlap
+    assert "if (ob != ulong.max) return false;" in body                                                   # base -c 0 with over-hanging alignments
+    # rules carried over (each named after the cli.cpp member that implements it)
+    for cli_name, d_name in (("first_column(", "firstColumn("), ("last_column(", "lastColumn("), ("pending_empty_", "base_pending_empty"),
+                             ("pending_empty", "win_pending_empty"), ("stale_st", "stale_st"), ("zero_windows(", "zeroWindows("),
+                             ("last_nl", "last_nl")):
+        assert cli_name in cli and d_name in body or d_name in d, (cli_name, d_name)
+    assert "k * w + w <= fpos" in body                  # windows finished before the first column of the run print nothing
+    assert "lastcol >= w ? (lastcol - w) / w + 1 : 0" in body      # windows finished by over-hanging columns
+    # the writer callback is declared outside the nothrow @nogc block (its D implementation writes to a File)
+    head = d[:d.index("extern (C) nothrow @nogc {")]
+    assert "alias sbx_write_fn = extern (C) int function" in head
+    assert "extern (C) int sbxFileSink" in d and "&sbxFileSink" in body
