@@ -794,18 +794,36 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
     }
 }
 
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
+// kOwn32 (variant 1): what the token statistics of BAM streams say a batch spends its instructions on (tools/token_stats.cpp):
+// 99.5 % of the near matches longer than 16 bytes are at most 32 bytes long, and so are most far ones -- they no longer go
+// through the cooperative copy loop (three readlanes per task, two dwords per lane, 3 to 19 of 64 lanes busy) but are copied
+// by their own lane with a second 16-byte step; and a short self-overlapping match (a run, a dinucleotide repeat: 0.8 per
+// batch, 84 % with a period of at most 8) is no longer expanded byte by byte but with four byte permutes of the period
+// (v_perm_b32, selectors per period from a 128-byte table in LDS).
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32>
+__device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
     uint8_t* out, const uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
+    if (kOwn32) {
+        uint32_t* tab = (uint32_t*)(smem + (kResThreads / 64) * (kHist + 1024u + kSpanMax + 16u));
+        if (threadIdx.x < 32u) {
+            const uint32_t d = (threadIdx.x >> 2) + 1u, j = threadIdx.x & 3u;
+            uint32_t v = 0;
+            for (uint32_t i = 0; i < 4; ++i) v |= ((4u * j + i) % d) << (8u * i);
+            tab[threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
     if (b >= n_blocks) return;
     if (status[b] != INF_OK) return;
     constexpr uint32_t kCap = kHist + 1024u + kSpanMax, kWaveLds = kCap + 16u;
     uint8_t* buf = smem + wv * kWaveLds;
+    // byte selectors of a period: sel[d - 1][j] = the four bytes ((4 j + i) mod d), i = 0..3 -- output dword j of a match of period d
+    const uint32_t* per_sel = (const uint32_t*)(smem + (kResThreads / 64) * kWaveLds);
     const uint64_t oo = out_off[b];
     const uint8_t* lit = lit_stream + lit_off(oo, block0 + b);
     const uint32_t* ent = ent_stream + ent_off(oo, block0 + b);
@@ -845,14 +863,19 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
         const bool far = len != 0 && src < base;             // (dist <= dst for every entry K1a emitted)
         // ---- phase A: everything that comes from global memory, all loads before the first store ---------
         {
-            const uint32_t n_l = lr <= 16 ? lr : 0u, n_f = far && len <= 16 ? len : 0u;
-            Short16 rl, rf;
+            constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;       // bytes a lane copies itself
+            const uint32_t n_l = lr <= kOwn ? (lr < 16u ? lr : 16u) : 0u, n_f = far && len <= kOwn ? (len < 16u ? len : 16u) : 0u;
+            const uint32_t n_l2 = kOwn32 && lr > 16u && lr <= 32u ? lr - 16u : 0u, n_f2 = kOwn32 && far && len > 16u && len <= 32u ? len - 16u : 0u;
+            Short16 rl, rf, rl2, rf2;
             rl.load(lit + el, n_l);
             rf.load(o + src, n_f);
+            const bool second = kOwn32 && __any(n_l2 | n_f2);
+            if (second) { rl2.load(lit + el + 16, n_l2); rf2.load(o + src + 16, n_f2); }
             rl.store(buf + (eo - base), n_l);
             rf.store(buf + (dst - base), n_f);
-            coop_copy(__ballot(lr > 16), lit, el, buf, eo - base, lr, lane);
-            coop_copy(__ballot(far && len > 16), o, src, buf, dst - base, len, lane);
+            if (second) { rl2.store(buf + (eo - base) + 16, n_l2); rf2.store(buf + (dst - base) + 16, n_f2); }
+            coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
+            coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
         }
         // ---- phase B: near matches, LDS -> LDS --------------------------------------------------------------
         // A match may start once everything below its source end is final.  Matches start in entry order,
@@ -872,17 +895,45 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
             pending = pending && !ready;
             const bool plain = ready && dist >= len;
             {
-                const uint32_t n_s = plain && len <= 16 ? len : 0u;
-                Short16 rs;
+                constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;
+                const uint32_t n_s = plain && len <= kOwn ? (len < 16u ? len : 16u) : 0u;
+                const uint32_t n_s2 = kOwn32 && plain && len > 16u && len <= 32u ? len - 16u : 0u;
+                Short16 rs, rs2;
                 rs.load(buf + srco, n_s);
+                const bool second = kOwn32 && __any(n_s2);
+                if (second) rs2.load(buf + srco + 16, n_s2);       // (source and destination of a plain match do not overlap)
                 rs.store(buf + dsto, n_s);
+                if (second) rs2.store(buf + dsto + 16, n_s2);
+                coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
-            coop_copy(__ballot(plain && len > 16), buf, srco, buf, dsto, len, lane);
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
             // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
             // 1, 2, 4 ... periods copied from the match's own output.
             const bool per = ready && dist < len;
-            if (per && len <= 16) {
+            const bool per_perm = kOwn32 && per && len <= 16 && dist <= 8;
+            if (kOwn32 && __any(per_perm)) {
+                // output byte k = period[k mod dist]: the period sits in the first (<= 8) bytes at src, output dword j is one byte
+                // permute of them; the tail dword (offset len - 4) is cut out of two neighbours
+                Short16 ws;
+                uint32_t n_p = 0;
+                if (per_perm) {
+                    const uint32_t x0 = ldu32(buf + srco), x1 = ldu32(buf + srco + 4);
+                    const u32x4 sel = *(const u32x4*)(per_sel + 4u * (dist - 1u));
+                    const uint32_t y0 = __builtin_amdgcn_perm(x1, x0, sel.x), y1 = __builtin_amdgcn_perm(x1, x0, sel.y);
+                    const uint32_t y2 = __builtin_amdgcn_perm(x1, x0, sel.z), y3 = __builtin_amdgcn_perm(x1, x0, sel.w);
+                    n_p = len;
+                    const uint32_t to = len >= 4u ? len - 4u : 0u, tj = to >> 2, tsh = to & 3u;
+                    const uint32_t ta = tj == 0u ? y0 : tj == 1u ? y1 : tj == 2u ? y2 : y3;
+                    const uint32_t tb = tj == 0u ? y1 : tj == 1u ? y2 : y3;          // (tj == 3 only with tsh == 0)
+                    const uint32_t tail = __builtin_amdgcn_alignbyte(tb, ta, tsh);
+                    ws.w[0] = y0;                              // (Short16::store: dword k goes to offset 4 k when it fits, else to len - 4)
+                    ws.w[1] = 8u <= len ? y1 : tail;
+                    ws.w[2] = 12u <= len ? y2 : tail;
+                    ws.w[3] = 16u <= len ? y3 : tail;
+                }
+                ws.store(buf + dsto, n_p);
+            }
+            if (per && len <= 16 && !per_perm) {
                 uint32_t lo = 0, hi = 0, m = 0;      // 16 bytes in two 64-bit halves would need 4 regs; len <= 16
                 uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -927,6 +978,26 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve(
     }
 }
 
+
+#define SBX_LZ77_ARGS const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries, \
+                      const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0, uint8_t* out, \
+                      const uint32_t* __restrict__ status
+#define SBX_LZ77_PASS lit_stream, ent_stream, n_entries, out_off, isize, n_blocks, block0, out, status
+// the same body at different register budgets (waves per SIMD): the variant with the 32-byte own-lane copies needs 77 VGPRs
+// left alone (6 waves), 72 with 4 spilled dwords (7 waves), 64 with 15 (8 waves); which one wins is a measurement
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) void k_lz77_resolve(SBX_LZ77_ARGS) { lz77_resolve_body<kHist, kSpanMax, false>(SBX_LZ77_PASS); }
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) void k_lz77_resolve_o32(SBX_LZ77_ARGS) { lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS); }
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lz77_resolve_o32w7(SBX_LZ77_ARGS) {
+    lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS);
+}
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_o32w8(SBX_LZ77_ARGS) {
+    lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS);
+}
+
 }  // namespace
 
 size_t inflate_scratch_bytes(uint32_t n_blocks) { return (size_t)n_blocks * kLensScratch; }
@@ -957,8 +1028,19 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         const uint32_t per = kResThreads / 64;
         dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
         const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
-        hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks,
-                           block0, d_out, d_status);
+        static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 1; }();
+        if (variant == 0)
+            hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize,
+                               n_blocks, block0, d_out, d_status);
+        else if (variant == 2)
+            hipLaunchKernelGGL((k_lz77_resolve_o32w7<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
+                               d_isize, n_blocks, block0, d_out, d_status);
+        else if (variant == 3)
+            hipLaunchKernelGGL((k_lz77_resolve_o32w8<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
+                               d_isize, n_blocks, block0, d_out, d_status);
+        else
+            hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
+                               d_isize, n_blocks, block0, d_out, d_status);
         SBX_HIP(hipGetLastError());
     }
 }

@@ -133,6 +133,12 @@ int main(int argc, char** argv) {
     uint64_t blocks = 0, entries = 0, out_bytes = 0, lit_bytes = 0, matches = 0, nearm = 0, farm = 0, batches = 0;
     uint64_t rounds_a = 0, rounds_b = 0, near_len = 0, far_len = 0, far_short = 0;
     uint64_t hist_a[40] = {0}, hist_b[40] = {0};
+    // which paths of k_lz77_resolve a batch executes (a wave pays for a path when ANY of its lanes takes it)
+    uint64_t pa_lit_long = 0, pa_far_long = 0, pa_lit_long_tasks = 0, pa_far_long_tasks = 0;
+    uint64_t rb_plain_short = 0, rb_plain_long = 0, rb_plain_long_tasks = 0, rb_per_short = 0, rb_per_long_tasks = 0;
+    uint64_t rb_per_short_d124 = 0, per_short_n = 0, per_short_d1 = 0, per_short_d124 = 0, per_short_d8 = 0, rb_per_short_gt8 = 0;
+    uint64_t plain_long_hist[4] = {0, 0, 0, 0};      // 17-32, 33-64, 65-128, 129+
+    uint64_t rb_plain_gt32 = 0;
     size_t off = 0;
     while (off + 18 <= file.size() && blocks < max_blocks + 1) {
         const uint8_t* p = file.data() + off;
@@ -152,7 +158,7 @@ int main(int argc, char** argv) {
             if (e1 == e0) { span = ent[e1].lit_run + ent[e1].len; ++e1; }
             if (opos - base + kSpan > kHist + 1024 + kSpan) base = (opos - kHist) & ~15u;
             // entries of the batch: dst / src ranges
-            struct M { uint32_t dst, src, shi, len; bool near_; };
+            struct M { uint32_t dst, src, shi, len; bool near_; uint32_t dist; };
             std::vector<M> ms;
             uint32_t o = opos;
             for (size_t e = e0; e < e1; ++e) {
@@ -161,11 +167,17 @@ int main(int argc, char** argv) {
                 if (ent[e].len) {
                     uint32_t dst = o, src = o - ent[e].dist;
                     bool nr = src >= base;
-                    ms.push_back({dst, src, src + std::min(ent[e].len, ent[e].dist), ent[e].len, nr});
+                    ms.push_back({dst, src, src + std::min(ent[e].len, ent[e].dist), ent[e].len, nr, ent[e].dist});
                     ++matches;
                     if (nr) { ++nearm; near_len += ent[e].len; } else { ++farm; far_len += ent[e].len; if (ent[e].len <= 16) ++far_short; }
                 }
                 o += ent[e].len;
+            }
+            {   // phase A: long literal runs / long far matches go through the cooperative copy loop (four tasks per iteration)
+                uint32_t ll = 0, fl = 0;
+                for (size_t e = e0; e < e1; ++e) if (ent[e].lit_run > 16) ++ll;
+                for (auto& m : ms) if (!m.near_ && m.len > 16) ++fl;
+                pa_lit_long += ll != 0; pa_far_long += fl != 0; pa_lit_long_tasks += ll; pa_far_long_tasks += fl;
             }
             // (a) frontier rule
             {
@@ -176,7 +188,27 @@ int main(int argc, char** argv) {
                 while (np) {
                     uint32_t F = 0;
                     for (size_t i = 0; i < ms.size(); ++i) if (pend[i]) { F = ms[i].dst; break; }
-                    for (size_t i = 0; i < ms.size(); ++i) if (pend[i] && ms[i].shi <= F) { pend[i] = 0; --np; }
+                    bool ps = false, pl = false, qs = false, qs_other = false, qs_gt8 = false, pl32 = false;
+                    for (size_t i = 0; i < ms.size(); ++i) if (pend[i] && ms[i].shi <= F) {
+                        pend[i] = 0; --np;
+                        const bool per = ms[i].dist < ms[i].len;
+                        if (!per) {
+                            if (ms[i].len <= 16) ps = true;
+                            else {
+                                pl = true; ++rb_plain_long_tasks;
+                                plain_long_hist[ms[i].len <= 32 ? 0 : ms[i].len <= 64 ? 1 : ms[i].len <= 128 ? 2 : 3]++;
+                                if (ms[i].len > 32) pl32 = true;
+                            }
+                        }
+                        else if (ms[i].len <= 16) {
+                            qs = true; ++per_short_n;
+                            if (ms[i].dist == 1) ++per_short_d1;
+                            if (ms[i].dist == 1 || ms[i].dist == 2 || ms[i].dist == 4) ++per_short_d124; else qs_other = true;
+                            if (ms[i].dist <= 8) ++per_short_d8; else qs_gt8 = true;
+                        } else ++rb_per_long_tasks;
+                    }
+                    rb_plain_short += ps; rb_plain_long += pl; rb_per_short += qs; rb_per_short_d124 += qs && !qs_other;
+                    rb_per_short_gt8 += qs_gt8; rb_plain_gt32 += pl32;
                     ++r;
                 }
                 rounds_a += r;
@@ -217,6 +249,19 @@ int main(int argc, char** argv) {
            (double)out_bytes / batches, (double)near_len / std::max<uint64_t>(1, nearm), (double)far_len / std::max<uint64_t>(1, farm),
            100.0 * far_short / std::max<uint64_t>(1, farm));
     printf("dependency rounds per batch: frontier rule %.2f, exact rule %.2f\n", (double)rounds_a / batches, (double)rounds_b / batches);
+    printf("phase A per batch: long literal runs in %.2f of the batches (%.2f tasks), long far matches in %.2f (%.2f tasks)\n",
+           (double)pa_lit_long / batches, (double)pa_lit_long_tasks / batches, (double)pa_far_long / batches, (double)pa_far_long_tasks / batches);
+    printf("phase B per batch (frontier rounds that execute a path): plain short %.2f, plain long %.2f (%.2f tasks), periodic short %.2f "
+           "(of which only dist 1/2/4: %.2f), periodic long tasks %.2f\n", (double)rb_plain_short / batches, (double)rb_plain_long / batches,
+           (double)rb_plain_long_tasks / batches, (double)rb_per_short / batches, (double)rb_per_short_d124 / batches, (double)rb_per_long_tasks / batches);
+    printf("periodic short matches: %.2f per batch, dist 1: %.1f %%, dist 1/2/4: %.1f %%\n", (double)per_short_n / batches,
+           100.0 * per_short_d1 / std::max<uint64_t>(1, per_short_n), 100.0 * per_short_d124 / std::max<uint64_t>(1, per_short_n));
+    printf("periodic short with dist <= 8: %.1f %%; rounds per batch that still hold one with dist > 8: %.3f\n",
+           100.0 * per_short_d8 / std::max<uint64_t>(1, per_short_n), (double)rb_per_short_gt8 / batches);
+    printf("plain long near matches by length: 17-32 %.1f %%, 33-64 %.1f %%, 65-128 %.1f %%, 129+ %.1f %%; rounds per batch with one > 32: %.2f\n",
+           100.0 * plain_long_hist[0] / std::max<uint64_t>(1, rb_plain_long_tasks), 100.0 * plain_long_hist[1] / std::max<uint64_t>(1, rb_plain_long_tasks),
+           100.0 * plain_long_hist[2] / std::max<uint64_t>(1, rb_plain_long_tasks), 100.0 * plain_long_hist[3] / std::max<uint64_t>(1, rb_plain_long_tasks),
+           (double)rb_plain_gt32 / batches);
     printf("rounds histogram (frontier | exact):\n");
     for (int r = 0; r < 16; ++r) printf("  %2d  %6.2f %%  %6.2f %%\n", r, 100.0 * hist_a[r] / batches, 100.0 * hist_b[r] / batches);
     return 0;
