@@ -331,6 +331,28 @@ struct LibDeflate {
 static LibDeflate g_ld;
 static bool g_use_libdeflate = false;
 
+// Optional device backend: the product's BGZF writer (libsbx_depth.so: sbx_bgzf_compress, one lane per block on the GPU), bound
+// through dlopen so that this harness tool does not link the product.  A whole wave of the stream is compressed per call.
+struct DeviceCodec {
+    int (*compress)(const uint8_t*, size_t, int, int, int, uint8_t*, size_t, size_t*, char*, size_t) = nullptr;
+    bool ok = false;
+    void open(const char* argv0) {
+        std::string dir = argv0;
+        size_t k = dir.rfind('/');
+        dir = k == std::string::npos ? "." : dir.substr(0, k);
+        const std::string cands[3] = {dir + "/../sambamba_amd/csrc/libsbx_depth.so", "sambamba_amd/csrc/libsbx_depth.so", "libsbx_depth.so"};
+        for (auto& c : cands) {
+            void* h = dlopen(c.c_str(), RTLD_NOW);
+            if (!h) continue;
+            compress = (decltype(compress))dlsym(h, "sbx_bgzf_compress");
+            ok = compress != nullptr;
+            if (ok) return;
+        }
+    }
+};
+static DeviceCodec g_dev;
+static bool g_use_device = false;
+
 static void bgzf_compress(const uint8_t* src, uint32_t n, int level, std::vector<uint8_t>& dst) {
     dst.resize(18 + compressBound(n) + 8 + 64);
     if (g_use_libdeflate) {
@@ -405,7 +427,16 @@ int main(int argc, char** argv) {
         else if (a == "--samples") P.n_samples = atoi(val().c_str());
         else if (a == "--tie-free-overlaps") P.tie_free_overlaps = true;
         else if (a == "--segment") P.segment = atoll(val().c_str());
-        else if (a == "--codec") { std::string c = val(); g_use_libdeflate = (c == "libdeflate"); if (g_use_libdeflate && !g_ld.ok) { fprintf(stderr, "libdeflate.so.0 not available, using zlib\n"); g_use_libdeflate = false; } }
+        else if (a == "--codec") {
+            std::string c = val();
+            g_use_libdeflate = (c == "libdeflate");
+            if (g_use_libdeflate && !g_ld.ok) { fprintf(stderr, "libdeflate.so.0 not available, using zlib\n"); g_use_libdeflate = false; }
+            if (c == "device") {
+                g_dev.open(argv[0]);
+                if (!g_dev.ok) { fprintf(stderr, "libsbx_depth.so (sbx_bgzf_compress) not found\n"); return 1; }
+                g_use_device = true;
+            }
+        }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (P.out.empty()) { fprintf(stderr, "usage: gen_bam --out x.bam [--contigs n:len,n:len] [--coverage 30] ...\n"); return 2; }
@@ -539,7 +570,26 @@ int main(int argc, char** argv) {
         bool last = t1i >= tasks.size();
         size_t nblk = last ? (size_t)((total_len + BLK - 1) / BLK) : (size_t)(total_len / BLK);
         if (cb.size() < nblk) cb.resize(nblk);
-        {
+        if (g_use_device && nblk) {
+            // the whole wave through the product's writer: one contiguous buffer in, BGZF blocks out (cut apart by their BSIZE)
+            const uint64_t bytes = std::min<uint64_t>(total_len, (uint64_t)nblk * BLK);
+            std::vector<uint8_t> flat((size_t)bytes), comp((size_t)bytes + (size_t)bytes / 2048 + 4096 + 64 * nblk);
+            copy_range(0, bytes, flat.data());
+            size_t clen = 0;
+            char err[256] = {0};
+            if (g_dev.compress(flat.data(), flat.size(), P.level, 0, -1, comp.data(), comp.size(), &clen, err, sizeof err) != 0) {
+                fprintf(stderr, "sbx_bgzf_compress: %s\n", err);
+                return 1;
+            }
+            size_t o = 0;
+            for (size_t b = 0; b < nblk; ++b) {
+                if (o + 18 > clen) { fprintf(stderr, "device writer returned too few blocks\n"); return 1; }
+                const size_t bs = (size_t)(comp[o + 16] | (comp[o + 17] << 8)) + 1;
+                cb[b].assign(comp.begin() + (long)o, comp.begin() + (long)(o + bs));
+                o += bs;
+            }
+            if (o != clen) { fprintf(stderr, "device writer returned a different number of blocks\n"); return 1; }
+        } else {
             std::atomic<size_t> next(0);
             std::vector<std::thread> th;
             for (int w = 0; w < P.threads; ++w)
