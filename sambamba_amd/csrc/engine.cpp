@@ -1037,6 +1037,8 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
                 SBX_HIP(hipStreamSynchronize(s));
                 n_rewalked += R.n_rewalked;
             }
+            // whatever the repair rounds produced is only a proposal: the pass is repeated with these entries, and the chain
+            // check of that pass (k_check_scan, every block against its predecessor) is what accepts or rejects it
             entries_given = true;
             continue;
         }

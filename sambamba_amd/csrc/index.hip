@@ -680,6 +680,11 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
 // Parallel repair of wrong guesses: every block that is not entered where its predecessor was left is walked again
 // from there.  A wrong guess is isolated (its neighbours guessed right), so one round settles it; a block whose new
 // exit disagrees with the next block's entry is caught by the next round.  *n_changed counts the blocks re-walked.
+// A round reads exit_[b - 1] while other lanes of the same launch may be rewriting it (a block and its predecessor both being
+// re-walked), so what a round sees is not deterministic and "nothing changed" is only a hint for the host loop: the chain this
+// produces is NEVER accepted as it stands -- the engine always launches walk + k_check_scan again with the entries given
+// (entry_in), and k_check_scan verifies exit[b - 1] == entry[b] for every block from the exactly known start of the run.  A
+// chain that is still inconsistent then is reported as a corrupt file (engine.cpp: `entries_given` branch).
 __global__ __launch_bounds__(kWalkThreads) void k_rewalk_mismatched(IndexArgs a, uint32_t* n_changed) {
     const uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
     if (b >= a.n_blocks) return;
