@@ -1978,7 +1978,9 @@ int sbx_stream_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end
             const uint64_t total = format_measure(c, a, &n_chunks, s);       // (synchronises the compute stream only)
             drain(k);                                                          // buffer k is free again once its piece is written
             if (total) {
-                c->d_fmt_text2[k].ensure((size_t)total + 64);
+                // (pieces differ in size by a few percent: a buffer that had to grow with every larger piece would be freed and
+                //  allocated again and again, and hipFree waits for the whole device -- the copy of the previous piece included)
+                if (c->d_fmt_text2[k].n < (size_t)total + 64) c->d_fmt_text2[k].alloc((size_t)total + (size_t)(total / 4) + (1u << 20));
                 if (c->text_host_cap[k] < total) {
                     if (c->text_host[k]) SBX_HIP(hipHostFree(c->text_host[k]));
                     c->text_host[k] = nullptr;
