@@ -492,10 +492,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # rank 0 generates the synthetic BAM (minutes for N chr1-sized contigs on a CPU-quota'd box) while the others wait in a barrier
+        long_wait = datetime.timedelta(minutes=90)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=long_wait)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=long_wait)
 
     if rank == 0:
         ensure_built()
