@@ -864,16 +864,19 @@ __device__ __forceinline__ void lz77_resolve_body(
         // ---- phase A: everything that comes from global memory, all loads before the first store ---------
         {
             constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;       // bytes a lane copies itself
-            const uint32_t n_l = lr <= kOwn ? (lr < 16u ? lr : 16u) : 0u, n_f = far && len <= kOwn ? (len < 16u ? len : 16u) : 0u;
-            const uint32_t n_l2 = kOwn32 && lr > 16u && lr <= 32u ? lr - 16u : 0u, n_f2 = kOwn32 && far && len > 16u && len <= 32u ? len - 16u : 0u;
-            Short16 rl, rf, rl2, rf2;
-            rl.load(lit + el, n_l);
-            rf.load(o + src, n_f);
-            const bool second = kOwn32 && __any(n_l2 | n_f2);
-            if (second) { rl2.load(lit + el + 16, n_l2); rf2.load(o + src + 16, n_f2); }
-            rl.store(buf + (eo - base), n_l);
-            rf.store(buf + (dst - base), n_f);
-            if (second) { rl2.store(buf + (eo - base) + 16, n_l2); rf2.store(buf + (dst - base) + 16, n_f2); }
+            // own-lane copies in steps of 16 bytes: one step, or two when some item of the batch is 17 .. 32 bytes long (the same code
+            // and registers for both steps -- what matters is that the kernel keeps its 8 waves per SIMD)
+            const uint32_t own_l = lr <= kOwn ? lr : 0u, own_f = far && len <= kOwn ? len : 0u;
+            const uint32_t steps = kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
+            for (uint32_t h = 0; h < steps; ++h) {
+                const uint32_t n_l = own_l > 16u * h ? (own_l - 16u * h < 16u ? own_l - 16u * h : 16u) : 0u;
+                const uint32_t n_f = own_f > 16u * h ? (own_f - 16u * h < 16u ? own_f - 16u * h : 16u) : 0u;
+                Short16 rl, rf;
+                rl.load(lit + el + 16u * h, n_l);
+                rf.load(o + src + 16u * h, n_f);
+                rl.store(buf + (eo - base) + 16u * h, n_l);
+                rf.store(buf + (dst - base) + 16u * h, n_f);
+            }
             coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
             coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
         }
@@ -896,14 +899,14 @@ __device__ __forceinline__ void lz77_resolve_body(
             const bool plain = ready && dist >= len;
             {
                 constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;
-                const uint32_t n_s = plain && len <= kOwn ? (len < 16u ? len : 16u) : 0u;
-                const uint32_t n_s2 = kOwn32 && plain && len > 16u && len <= 32u ? len - 16u : 0u;
-                Short16 rs, rs2;
-                rs.load(buf + srco, n_s);
-                const bool second = kOwn32 && __any(n_s2);
-                if (second) rs2.load(buf + srco + 16, n_s2);       // (source and destination of a plain match do not overlap)
-                rs.store(buf + dsto, n_s);
-                if (second) rs2.store(buf + dsto + 16, n_s2);
+                const uint32_t own_s = plain && len <= kOwn ? len : 0u;       // (source and destination of a plain match do not overlap)
+                const uint32_t steps = kOwn32 && __any(own_s > 16u) ? 2u : 1u;
+                for (uint32_t h = 0; h < steps; ++h) {
+                    const uint32_t n_s = own_s > 16u * h ? (own_s - 16u * h < 16u ? own_s - 16u * h : 16u) : 0u;
+                    Short16 rs;
+                    rs.load(buf + srco + 16u * h, n_s);
+                    rs.store(buf + dsto + 16u * h, n_s);
+                }
                 coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
