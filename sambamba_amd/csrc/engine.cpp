@@ -9,9 +9,12 @@
 // requested regions (RandomAccessManager.getChunks / getReads, randomaccessmanager.d:247-348; StreamChunksSupplier,
 // inputstream.d:257-345), every run starting at a record boundary the index names.  Only those blocks are uploaded
 // and inflated; the inflated pieces are laid out back to back in one device buffer.
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "bai_writer.hpp"
@@ -77,6 +80,9 @@ struct HostResults {
 
 using namespace sbx;
 
+constexpr size_t kStageBytes = 32u << 20;   // one pinned staging buffer of the upload
+constexpr int kStages = 4;                   // ... of a ring of four
+
 struct sbx_ctx {
     std::string last_error;
     // several BAMs (MultiBamReader, multireader.d:244): this context is the first file and owns the merged view;
@@ -119,8 +125,8 @@ struct sbx_ctx {
     hipEvent_t text_ev_fmt[2] = {nullptr, nullptr}, text_ev_copy[2] = {nullptr, nullptr};
     std::string h_fmt_blob;
     std::vector<uint32_t> h_fmt_soff;
-    uint8_t* stage[2] = {nullptr, nullptr};
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    uint8_t* stage[kStages] = {};
+    hipEvent_t stage_ev[kStages] = {};
     hipEvent_t upload_done = nullptr;
     HostResults* res = nullptr;     // pinned
 
@@ -201,7 +207,7 @@ struct sbx_ctx {
 
 namespace {
 
-constexpr size_t kStageBytes = 32u << 20;
+
 
 // the files of a (possibly multi-BAM) context, the primary first
 std::vector<sbx_ctx*> files_of(sbx_ctx* c) {
@@ -329,52 +335,102 @@ void build_worklist(const sbx_ctx* c, std::vector<FileRun> runs, bool file_resid
     w->comp_bytes = file_resident ? c->file.size : co;
 }
 
-// ---- host -> device copies of file bytes: pread by a few threads into pinned staging buffers, asynchronous DMA from
-// there on the copy stream, two buffers in flight ------------------------------------------------------------------
+// ---- host -> device copies of file bytes: a pool of threads preads 2 MiB pieces into a ring of pinned staging buffers, the
+// calling thread sends every buffer that is complete with an asynchronous DMA on the copy stream (two DMAs in flight while the
+// other two buffers are being filled).  The page cache -> pinned copy is what bounds the upload (PCIe takes 57 GB/s, one
+// thread copies ~3 GB/s), so the pieces are small and claimed in order: all threads work on the oldest incomplete buffer.
 void ensure_staging(sbx_ctx* c) {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kStages; ++i) {
         if (!c->stage[i]) SBX_HIP(hipHostMalloc((void**)&c->stage[i], kStageBytes, hipHostMallocDefault));
         if (!c->stage_ev[i]) SBX_HIP(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
     }
     if (!c->upload_done) SBX_HIP(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
 }
 
-void read_file_bytes(const sbx_ctx* c, uint64_t off, size_t n, uint8_t* dst) {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t n_thr = n < (4u << 20) ? 1 : std::min<size_t>(8, hw);
-    auto work = [&](size_t lo, size_t hi) {
-        while (lo < hi) {
-            ssize_t k = pread(c->file.fd, dst + lo, hi - lo, (off_t)(off + lo));
-            if (k <= 0) { memcpy(dst + lo, c->file.data + off + lo, hi - lo); break; }     // (the mapping always works)
-            lo += (size_t)k;
-        }
-    };
-    if (n_thr == 1) { work(0, n); return; }
-    std::vector<std::thread> th;
-    const size_t per = (n + n_thr - 1) / n_thr;
-    for (size_t t = 0; t < n_thr; ++t) {
-        const size_t lo = std::min(n, t * per), hi = std::min(n, lo + per);
-        if (lo < hi) th.emplace_back(work, lo, hi);
+void read_file_piece(const sbx_ctx* c, uint64_t off, size_t n, uint8_t* dst) {
+    size_t lo = 0;
+    while (lo < n) {
+        ssize_t k = pread(c->file.fd, dst + lo, n - lo, (off_t)(off + lo));
+        if (k <= 0) { memcpy(dst + lo, c->file.data + off + lo, n - lo); break; }     // (the mapping always works)
+        lo += (size_t)k;
     }
-    for (auto& t : th) t.join();
+}
+
+unsigned upload_threads() {
+    static const unsigned n = [] {
+        if (const char* e = getenv("SBX_UPLOAD_THREADS")) return (unsigned)std::max(1, atoi(e));
+        return std::min(12u, std::max(1u, std::thread::hardware_concurrency()));
+    }();
+    return n;
 }
 
 // copies the ranges into d_comp; the compute stream waits for the last DMA (no host synchronisation here)
 void upload_ranges(sbx_ctx* c, const std::vector<WorkList::Range>& ranges) {
     ensure_staging(c);
-    int cur = 0;
-    bool used[2] = {false, false};
+    struct Chunk { uint64_t file_off, dst; size_t n; };
+    struct Piece { uint32_t chunk; uint32_t off, n; };
+    constexpr size_t kPiece = 2u << 20;
+    std::vector<Chunk> chunks;
+    std::vector<Piece> pieces;
     for (auto& r : ranges)
         for (uint64_t done = 0; done < r.len;) {
             const size_t n = (size_t)std::min<uint64_t>(kStageBytes, r.len - done);
-            if (used[cur]) SBX_HIP(hipEventSynchronize(c->stage_ev[cur]));
-            read_file_bytes(c, r.file_off + done, n, c->stage[cur]);
-            SBX_HIP(hipMemcpyAsync(c->d_comp.p + r.dst + done, c->stage[cur], n, hipMemcpyHostToDevice, c->copy_stream));
-            SBX_HIP(hipEventRecord(c->stage_ev[cur], c->copy_stream));
-            used[cur] = true;
-            cur ^= 1;
+            for (size_t o = 0; o < n; o += kPiece) pieces.push_back({(uint32_t)chunks.size(), (uint32_t)o, (uint32_t)std::min(kPiece, n - o)});
+            chunks.push_back({r.file_off + done, r.dst + done, n});
             done += n;
         }
+    if (chunks.size() == 1 && pieces.size() <= 2) {       // a small transfer: no pool
+        read_file_piece(c, chunks[0].file_off, chunks[0].n, c->stage[0]);
+        SBX_HIP(hipMemcpyAsync(c->d_comp.p + chunks[0].dst, c->stage[0], chunks[0].n, hipMemcpyHostToDevice, c->copy_stream));
+        SBX_HIP(hipEventRecord(c->stage_ev[0], c->copy_stream));
+        SBX_HIP(hipEventSynchronize(c->stage_ev[0]));      // (the buffer may be refilled by the next call)
+        SBX_HIP(hipEventRecord(c->upload_done, c->copy_stream));
+        return;
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<uint32_t> left(chunks.size(), 0);
+    for (auto& p : pieces) ++left[p.chunk];
+    size_t avail = kStages;                 // chunks [0, avail) may be filled: the buffer of chunk x is free once chunk x - kStages has left it
+    std::atomic<size_t> next{0};
+    bool abort_all = false;
+    auto worker = [&] {
+        for (;;) {
+            const size_t p = next.fetch_add(1);
+            if (p >= pieces.size()) return;
+            const Piece& pc = pieces[p];
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return abort_all || pc.chunk < avail; });
+                if (abort_all) return;
+            }
+            read_file_piece(c, chunks[pc.chunk].file_off + pc.off, pc.n, c->stage[pc.chunk % kStages] + pc.off);
+            std::lock_guard<std::mutex> g(mu);
+            if (--left[pc.chunk] == 0) cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    const size_t n_thr = std::min<size_t>(upload_threads(), pieces.size());
+    for (size_t t = 0; t < n_thr; ++t) pool.emplace_back(worker);
+    struct Stop {       // an error on the way out must not leave the pool waiting
+        std::mutex& mu; std::condition_variable& cv; bool& abort_all; std::vector<std::thread>& pool;
+        ~Stop() { { std::lock_guard<std::mutex> g(mu); abort_all = true; } cv.notify_all(); for (auto& t : pool) t.join(); }
+    } stop{mu, cv, abort_all, pool};
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return left[ci] == 0; }); }
+        const int slot = (int)(ci % kStages);
+        SBX_HIP(hipMemcpyAsync(c->d_comp.p + chunks[ci].dst, c->stage[slot], chunks[ci].n, hipMemcpyHostToDevice, c->copy_stream));
+        SBX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
+        if (ci + 2 >= (size_t)kStages) {       // two DMAs stay in flight; the buffer of the one before them is free again
+            const size_t j = ci + 2 - kStages;
+            SBX_HIP(hipEventSynchronize(c->stage_ev[j % kStages]));
+            std::lock_guard<std::mutex> g(mu);
+            avail = j + kStages + 1;
+            cv.notify_all();
+        }
+    }
+    // the buffers must be free when the next call starts to fill them
+    for (int i = 0; i < kStages; ++i) SBX_HIP(hipEventSynchronize(c->stage_ev[i]));
     SBX_HIP(hipEventRecord(c->upload_done, c->copy_stream));      // (the callers wait for the copy stream on the host)
 }
 

@@ -52,6 +52,7 @@ constexpr int kLitHiOff = 288;               // u8[36]   bit 8 of those symbols,
 constexpr int kRingOff = 324;                // u32[8]   input ring (32 bytes of this lane's compressed payload)
 constexpr int kClLenOff = 32;                // u8[19]   code-length code lengths while a dynamic header is parsed (in the
                                              //          literal area, which is rebuilt afterwards; its symbols sit at 0..18)
+constexpr int kLenTabBytes = 64, kDistTabBytes = 128;   // (tuned variants) symbol -> base / extra bits, shared by the workgroup
 constexpr int kLensScratch = 320;            // bytes of global scratch per lane: code lengths being built
 
 enum : uint32_t {
@@ -190,13 +191,28 @@ struct Code {
     uint32_t d1;
 };
 
-__device__ __forceinline__ void decode_len(const Code& C, uint32_t v, int* len, uint32_t* delta) {
+// pairs [kFrom, kTo) of the sum above
+template <int kFrom, int kTo>
+__device__ __forceinline__ uint32_t decode_pairs(const Code& C, uint32_t v, uint32_t acc) {
     const s16x2 vv = {(short)v, (short)v};
-    uint32_t acc = C.d1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = kFrom; j < kTo; ++j) {
         const u16x2 m = (u16x2)(C.lim1[j] - vv) >> 15;   // 1 where v >= limit
         acc = __builtin_amdgcn_udot2(m, C.dd[j], acc, false);
+    }
+    return acc;
+}
+
+// kShortPairs < 8 and `is_short` (wave-uniform): every lane's code is COMPLETE within 2 * kShortPairs bits -- the limit of
+// that length is 2^15, no 15-bit prefix reaches any longer length, the remaining pairs would add nothing -- and they are
+// skipped.  zlib's codes for a BAM block: the literal/length code reaches 14 bits, never 15, the distance code 12 at most
+// (tools/token_stats.cpp).
+template <int kShortPairs>
+__device__ __forceinline__ void decode_len(const Code& C, uint32_t v, bool is_short, int* len, uint32_t* delta) {
+    uint32_t acc = decode_pairs<0, kShortPairs>(C, v, C.d1);
+    if (kShortPairs < 8 && !is_short) {
+        asm volatile("");                                 // a real (scalar) branch: the compiler would otherwise compute the pairs and select
+        acc = decode_pairs<kShortPairs, 8>(C, v, acc);
     }
     *len = 1 + (int)(acc >> 13);
     *delta = acc;                                        // low 9 bits: the caller masks
@@ -251,8 +267,9 @@ struct DistSyms {
 // permutation to LDS, limits/deltas to registers.  Returns false on an over-subscribed code.
 // (Incomplete codes are accepted, as zlib accepts the single-code distance tree; an unused code
 // decodes as "invalid symbol".)
-template <bool kIsLit>
-__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* lds, DistSyms& DS, Code& C) {
+// *complete_within = the code is complete using lengths <= kWithin only (limit[kWithin] == 2^15).
+template <bool kIsLit, int kWithin>
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* lds, DistSyms& DS, Code& C, bool* complete_within) {
     Pack16 tmp;
     tmp.clear();
     for (int s = 0; s < n; ++s) tmp.add(lens[s] & 15u, 1u);
@@ -284,6 +301,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
                         (unsigned short)(((D[2 * j + 3] - D[2 * j + 2]) & 0x1FFu) | 0x2000u)};
     }
     C.d1 = D[1] & 0x1FFu;
+    *complete_within = lim[kWithin] == 32768u;
     if (!ok) return false;
     if (kIsLit) {
 #pragma unroll
@@ -310,20 +328,22 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
 // line that is completed by eight separate 16-byte stores over ~50 loop iterations does not survive in L2 next to the
 // 230,000 other open lines of the launch: it goes to HBM half-filled, several times (WRITE_SIZE 2.9x the token bytes,
 // profiles/round1).  The emitter therefore keeps the last 16 literal bytes and the last 4 match entries in registers
-// (byte / dword shift registers), parks every completed 16-byte group in a four-deep register FIFO and writes a stream
-// only in aligned 64-BYTE bursts -- four back-to-back 16-byte stores that fill a whole 64-byte sector at once.
+// (byte / dword shift registers), parks every completed 16-byte group in a register FIFO of kDepth groups and writes a
+// stream only in aligned bursts of kDepth back-to-back 16-byte stores (kDepth = 4: a whole 64-byte sector at once; 2: the
+// 32 bytes of one write request; the FIFO is shifted with register moves, so a shorter one is fewer instructions).
 // The stores are DEFERRED: flush(), which the decode loop calls right after the input-ring service, writes the bursts
 // that are full.  gfx9 counts loads and stores in the same in-order vmcnt, so the wait in front of the ring service
 // would otherwise also wait for token stores issued moments before -- a store round trip of stall in every iteration;
 // this way every VMEM operation of an iteration is issued at its top and has a whole iteration to complete.
+template <int kDepth>
 struct Emitter {
     uint8_t* lit;         // 64-byte aligned literal stream of this block
     uint32_t* ent;        // 64-byte aligned entry stream of this block
     u32x4 la, ea;         // the last 20 literal bytes (la + lx: a group that has just been completed stays whole while up
     uint32_t lx;          //  to three more literals of the same loop iteration are pushed) / the entry group being filled
     uint32_t n_grp;       // literal groups parked so far
-    u32x4 l0, l1, l2, l3; // parked literal groups: the newest in l3, the oldest of lq_n in l[4 - lq_n]
-    u32x4 e0, e1, e2, e3;
+    u32x4 lq[kDepth];     // parked literal groups: the newest in lq[kDepth - 1], the oldest of lq_n in lq[kDepth - lq_n]
+    u32x4 eq[kDepth];
     uint32_t lq_n, eq_n;  // parked groups
     uint32_t lq_at, eq_at;    // byte offset / entry index of the oldest parked group
     uint32_t n_lit, n_ent, run;
@@ -333,22 +353,24 @@ struct Emitter {
         const u32x4 z = {0, 0, 0, 0};
         la = ea = z;
         lx = 0; n_grp = 0;
-        l0 = l1 = l2 = l3 = z;
-        e0 = e1 = e2 = e3 = z;
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) lq[k] = eq[k] = z;
         lq_n = eq_n = 0;
         lq_at = eq_at = 0;
     }
     __device__ __forceinline__ void burst_lit() {
-        store16(lit + lq_at, l0); store16(lit + lq_at + 16, l1); store16(lit + lq_at + 32, l2); store16(lit + lq_at + 48, l3);
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) store16(lit + lq_at + 16 * k, lq[k]);
         lq_n = 0;
     }
     __device__ __forceinline__ void burst_ent() {
-        store16(ent + eq_at, e0); store16(ent + eq_at + 4, e1); store16(ent + eq_at + 8, e2); store16(ent + eq_at + 12, e3);
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) store16(ent + eq_at + 4 * k, eq[k]);
         eq_n = 0;
     }
     __device__ __forceinline__ void flush() {
-        if (lq_n == 4u) burst_lit();
-        if (eq_n == 4u) burst_ent();
+        if (lq_n == (uint32_t)kDepth) burst_lit();
+        if (eq_n == (uint32_t)kDepth) burst_ent();
     }
     __device__ __forceinline__ void push_byte(uint32_t byte) {      // {lx, la} = ({lx, la} >> 8) | byte << 152
         la.x = __builtin_amdgcn_alignbit(la.y, la.x, 8);
@@ -370,9 +392,11 @@ struct Emitter {
             g.z = __builtin_amdgcn_alignbyte(la.w, la.z, sh);
             g.w = __builtin_amdgcn_alignbyte(lx, la.w, sh);
             if (k == 0u) { g.x = la.y; g.y = la.z; g.z = la.w; g.w = lx; }
-            if (lq_n == 4u) burst_lit();                       // (stored blocks: a group every 16 iterations, flush() keeps up)
+            if (lq_n == (uint32_t)kDepth) burst_lit();         // (stored blocks: a group every 16 iterations, flush() keeps up)
             if (lq_n == 0u) lq_at = n_grp * 16u;
-            l0 = l1; l1 = l2; l2 = l3; l3 = g;
+#pragma unroll
+            for (int q = 0; q + 1 < kDepth; ++q) lq[q] = lq[q + 1];
+            lq[kDepth - 1] = g;
             ++lq_n;
             ++n_grp;
         }
@@ -381,9 +405,11 @@ struct Emitter {
         ea.x = ea.y; ea.y = ea.z; ea.z = ea.w; ea.w = e;
         ++n_ent;
         if ((n_ent & 3u) == 0) {
-            if (eq_n == 4u) burst_ent();                       // (a second group within one iteration: split runs only)
+            if (eq_n == (uint32_t)kDepth) burst_ent();         // (a second group within one iteration: split runs only)
             if (eq_n == 0u) eq_at = n_ent - 4;
-            e0 = e1; e1 = e2; e2 = e3; e3 = ea;
+#pragma unroll
+            for (int q = 0; q + 1 < kDepth; ++q) eq[q] = eq[q + 1];
+            eq[kDepth - 1] = ea;
             ++eq_n;
         }
     }
@@ -405,21 +431,19 @@ struct Emitter {
         park_lits();
         split_run();
         if (run) { push_entry(make_entry(run, 0, 1)); run = 0; }
-        // parked groups (an incomplete burst: the oldest sits in slot 4 - n)
+        // parked groups (an incomplete burst: the oldest sits in slot kDepth - n)
         {
-            const uint32_t skip = 4u - lq_n;
-            if (skip <= 0u) store16(lit + lq_at + 16u * (0u - skip), l0);
-            if (skip <= 1u) store16(lit + lq_at + 16u * (1u - skip), l1);
-            if (skip <= 2u) store16(lit + lq_at + 16u * (2u - skip), l2);
-            if (skip <= 3u) store16(lit + lq_at + 16u * (3u - skip), l3);
+            const uint32_t skip = (uint32_t)kDepth - lq_n;
+#pragma unroll
+            for (int k = 0; k < kDepth; ++k)
+                if (skip <= (uint32_t)k) store16(lit + lq_at + 16u * ((uint32_t)k - skip), lq[k]);
             lq_n = 0;
         }
         {
-            const uint32_t skip = 4u - eq_n;
-            if (skip <= 0u) store16(ent + eq_at + 4u * (0u - skip), e0);
-            if (skip <= 1u) store16(ent + eq_at + 4u * (1u - skip), e1);
-            if (skip <= 2u) store16(ent + eq_at + 4u * (2u - skip), e2);
-            if (skip <= 3u) store16(ent + eq_at + 4u * (3u - skip), e3);
+            const uint32_t skip = (uint32_t)kDepth - eq_n;
+#pragma unroll
+            for (int k = 0; k < kDepth; ++k)
+                if (skip <= (uint32_t)k) store16(ent + eq_at + 4u * ((uint32_t)k - skip), eq[k]);
             eq_n = 0;
         }
         const uint32_t rl = n_lit & 15u;
@@ -436,9 +460,13 @@ struct Emitter {
     }
 };
 
-// kTrim (variant 1): one input refill per loop iteration covers both literal/length slots (2 x 15 bits <= the 32 a refill
-// guarantees) instead of one per slot; the output position is not counted per literal but derived (literals + match bytes).
-template <bool kTrim>
+// One input refill per loop iteration covers both literal/length slots (2 x 15 bits <= the 32 a refill guarantees); the
+// output position is not counted per literal but derived (literals + match bytes).
+// kDepth: groups per token-store burst (Emitter).  kTuned: the base value / extra-bit count of a length or distance symbol
+// come from two small tables shared by the workgroup in LDS (29 x u16, 30 x u32: different entries lie in different banks,
+// equal ones are broadcast) instead of ~12 VALU instructions of arithmetic each, and the canonical decode skips the pairs of
+// code lengths no lane's code uses (decode_len).
+template <int kDepth, bool kTuned>
 __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
     const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
@@ -454,15 +482,33 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     uint8_t* lens = lens_scratch + (size_t)b * kLensScratch;
     DistSyms DS;
     DS.clear();
+    // (kTuned) RFC 1951 3.2.5 as tables behind the lanes' areas: length symbol 257 + i -> base | extra bits << 9,
+    // distance symbol i -> base | extra bits << 16 (entries 30, 31 exist so that an invalid symbol reads something)
+    uint16_t* const len_tab = (uint16_t*)(smem + kInfThreads * kLaneLds);
+    uint32_t* const dist_tab = (uint32_t*)(smem + kInfThreads * kLaneLds + kLenTabBytes);
+    if (kTuned) {
+        const uint32_t i = threadIdx.x;
+        if (i < 32u) {
+            const uint32_t t = i - 4u;
+            const bool direct = i < 8u || i >= 28u;
+            const uint32_t le = direct ? 0u : t >> 2;
+            const uint32_t lb = i < 8u ? i + 3u : i >= 28u ? 258u : ((4u + (t & 3u)) << le) + 3u;
+            len_tab[i] = (uint16_t)(lb | le << 9);
+            const uint32_t de = i < 4u ? 0u : ((i >> 1) - 1u) & 15u;
+            const uint32_t db = i < 4u ? i + 1u : ((2u + (i & 1u)) << de) + 1u;
+            dist_tab[i] = db | de << 16;
+        }
+        __syncthreads();
+    }
 
     const uint8_t* in = comp + comp_off[b];
     const uint32_t in_bits = comp_len[b] * 8u;
     const uint32_t osize = isize[b];
     const uint64_t oo = out_off[b];
-    uint32_t opos = 0;          // (!kTrim) output position; kTrim: bytes produced by matches and stored blocks only
+    uint32_t opos = 0;          // bytes produced by matches (literals and stored bytes are counted by the emitter)
     uint32_t err = INF_OK;
 
-    Emitter em;   // (lanes past the last block stay inactive and never emit)
+    Emitter<kDepth> em;   // (lanes past the last block stay inactive and never emit)
     em.init(lit_stream + lit_off(oo, block0 + b), ent_stream + ent_off(oo, block0 + b));
     BitReader br;
     br.init(in, (uint32_t*)(lds + kRingOff));
@@ -494,8 +540,8 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             br.refill();
             uint32_t nlen = br.take(16);
             if ((len ^ 0xFFFFu) != nlen) { err = INF_BAD_STORED; active = false; }
-            else if ((kTrim ? opos + em.n_lit : opos) + len > osize) { err = INF_OUTPUT_OVERRUN; active = false; }
-            else { stored_left = len; if (!kTrim) opos += len; }
+            else if (opos + em.n_lit + len > osize) { err = INF_OUTPUT_OVERRUN; active = false; }
+            else { stored_left = len; }
         }
         while (__any(stored_left != 0)) {
             if (stored_left) {
@@ -604,10 +650,13 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             if (err != INF_OK) active = false;
         }
         bool sym_loop = huff && active;
+        bool lit_in_14 = true, dist_in_12 = true;
         if (sym_loop) {
-            if (!build_code<true>(lens, nlit, lds, DS, CL)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
-            else if (!build_code<false>(lens + nlit, ndist, lds, DS, CD)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
+            if (!build_code<true, 14>(lens, nlit, lds, DS, CL, &lit_in_14)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
+            else if (!build_code<false, 12>(lens + nlit, ndist, lds, DS, CD, &dist_in_12)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
         }
+        // wave-uniform: every decoding lane's code is complete within 14 / 12 bits (decode_len)
+        const bool short_lit = kTuned && __all(!sym_loop || lit_in_14), short_dist = kTuned && __all(!sym_loop || dist_in_12);
 
         // ---- symbol loop -----------------------------------------------------------------
         // Under SIMT the (long) match path is paid by the whole wave in every iteration in which any
@@ -620,50 +669,63 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             uint32_t msym = 0;          // pending length symbol (257..285) of this lane, 0 = none
             uint32_t bad = INF_OK;
             static_assert(kLitPerIter * 15 <= 32, "one refill must cover the literal/length slots of an iteration");
-            if (kTrim && sym_loop) br.refill();
+            if (sym_loop) br.refill();
 #pragma unroll
             for (int r = 0; r < kLitPerIter; ++r) {
                 if (sym_loop && msym == 0 && bad == INF_OK) {
-                    if (!kTrim) br.refill();
                     const uint32_t v = __brev((uint32_t)br.buf) >> 17;
                     int len;
                     uint32_t delta;
-                    decode_len(CL, v, &len, &delta);
+                    decode_len<kTuned ? 7 : 8>(CL, v, short_lit, &len, &delta);
                     const int lc = len > 15 ? 15 : len;
                     const uint32_t idx0 = (delta + (v >> (15 - lc))) & 0x1FFu;
                     const uint32_t idx = idx0 > 287u ? 287u : idx0;
                     const uint32_t sym = (uint32_t)lds[kLitSymOff + idx] | (((uint32_t)lds[kLitHiOff + (idx >> 3)] >> (idx & 7)) & 1u) << 8;
                     br.drop(lc);
                     const bool ok = len <= 15 && idx0 <= 287u && sym <= 285u;
-                    if (ok && sym < 256u) { if (!kTrim) ++opos; em.literal(sym); }     // (overrun: checked once per iteration below)
+                    if (ok && sym < 256u) em.literal(sym);             // (overrun: checked once per iteration below)
                     sym_loop = !(ok && sym == 256u);
                     msym = ok && sym > 256u ? sym : 0u;
                     bad = ok ? INF_OK : INF_BAD_SYMBOL;
                 }
             }
             em.park_lits();
-            const uint32_t opos_now = kTrim ? opos + em.n_lit : opos;
+            const uint32_t opos_now = opos + em.n_lit;
             if (opos_now > osize && bad == INF_OK) { bad = INF_OUTPUT_OVERRUN; msym = 0; }
             if (msym != 0) {
                 // One refill covers the whole match: <= 5 length-extra + 15 code + 13 distance-extra bits.
                 br.refill();
-                // match length (RFC 1951 3.2.5), computed arithmetically, no branches
-                const uint32_t t = msym - 261u;                                     // valid for msym >= 265
-                const bool direct = msym < 265u || msym == 285u;
-                const uint32_t le = direct ? 0u : t >> 2;
-                const uint32_t lb = msym < 265u ? msym - 254u : msym == 285u ? 258u : ((4u + (t & 3u)) << le) + 3u;
+                // match length (RFC 1951 3.2.5): base and extra bits from the shared table, or computed arithmetically, no branches
+                uint32_t le, lb;
+                if (kTuned) {
+                    const uint32_t lt = len_tab[msym - 257u];
+                    le = lt >> 9;
+                    lb = lt & 0x1FFu;
+                } else {
+                    const uint32_t t = msym - 261u;                                 // valid for msym >= 265
+                    const bool direct = msym < 265u || msym == 285u;
+                    le = direct ? 0u : t >> 2;
+                    lb = msym < 265u ? msym - 254u : msym == 285u ? 258u : ((4u + (t & 3u)) << le) + 3u;
+                }
                 const uint32_t mlen = lb + br.take((int)le);
                 const uint32_t dv = __brev((uint32_t)br.buf) >> 17;
                 int dl;
                 uint32_t ddelta;
-                decode_len(CD, dv, &dl, &ddelta);
+                decode_len<kTuned ? 6 : 8>(CD, dv, short_dist, &dl, &ddelta);
                 const int dc = dl > 15 ? 15 : dl;
                 const uint32_t didx0 = (ddelta + (dv >> (15 - dc))) & 0x1FFu;
                 const uint32_t dsym = DS.get(didx0 > 29u ? 29u : didx0);
                 br.drop(dc);
                 // distance (RFC 1951 3.2.5)
-                const uint32_t de = dsym < 4u ? 0u : ((dsym >> 1) - 1u) & 15u;
-                const uint32_t db = dsym < 4u ? dsym + 1u : ((2u + (dsym & 1u)) << de) + 1u;
+                uint32_t de, db;
+                if (kTuned) {
+                    const uint32_t dt = dist_tab[dsym];
+                    de = dt >> 16;
+                    db = dt & 0xFFFFu;
+                } else {
+                    de = dsym < 4u ? 0u : ((dsym >> 1) - 1u) & 15u;
+                    db = dsym < 4u ? dsym + 1u : ((2u + (dsym & 1u)) << de) + 1u;
+                }
                 const uint32_t dist = db + br.take((int)de);
                 const bool code_ok = dl <= 15 && didx0 < 30u && dsym <= 29u && dist <= opos_now;
                 const bool fits = opos_now + mlen <= osize;
@@ -675,7 +737,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         if (active && last) active = false;
     }
     em.finish();
-    if (err == INF_OK && (kTrim ? opos + em.n_lit : opos) != osize) err = INF_SIZE_MISMATCH;
+    if (err == INF_OK && opos + em.n_lit != osize) err = INF_SIZE_MISMATCH;
     if (err == INF_OK && br.consumed() > in_bits) err = INF_INPUT_OVERRUN;
     if (live) {
         status[b] = err;
@@ -1016,14 +1078,20 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
     if (n_blocks == 0) { if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream)); return; }
     {
         dim3 grid((n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
-        size_t lds = (size_t)kInfThreads * kLaneLds;
+        const size_t lds = (size_t)kInfThreads * kLaneLds, lds_tuned = lds + kLenTabBytes + kDistTabBytes;
         static const int variant = [] { const char* e = getenv("SBX_K1A_VARIANT"); return e ? atoi(e) : 1; }();
-        if (variant == 0)
-            hipLaunchKernelGGL(k_huffman_decode<false>, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off,
-                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes);
-        else
-            hipLaunchKernelGGL(k_huffman_decode<true>, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off,
-                               n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes);
+#define SBX_K1A_LAUNCH(DEPTH, TUNED)                                                                                                    \
+    hipLaunchKernelGGL((k_huffman_decode<DEPTH, TUNED>), grid, block, TUNED ? lds_tuned : lds, stream, d_comp, d_comp_off, d_comp_len, \
+                       d_isize, d_out_off, n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes)
+        switch (variant) {
+            case 2: SBX_K1A_LAUNCH(2, false); break;
+            case 3: SBX_K1A_LAUNCH(1, false); break;
+            case 4: SBX_K1A_LAUNCH(4, true); break;
+            case 5: SBX_K1A_LAUNCH(2, true); break;
+            case 6: SBX_K1A_LAUNCH(1, true); break;
+            default: SBX_K1A_LAUNCH(4, false); break;
+        }
+#undef SBX_K1A_LAUNCH
         SBX_HIP(hipGetLastError());
     }
     if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream));

@@ -38,17 +38,22 @@ struct Huff {
         for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + count[l];
         for (int i = 0; i < n; ++i) if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
     }
-    int decode(Bits& b) const {
+    int max_len() const { int m = 0; for (int l = 1; l <= 15; ++l) if (count[l]) m = l; return m; }
+    int decode(Bits& b, uint64_t* use = nullptr) const {
         int code = 0, first = 0, index = 0;
         for (int l = 1; l <= 15; ++l) {
             code |= (int)b.take(1);
             int c = count[l];
-            if (code - c < first) return symbol[index + (code - first)];
+            if (code - c < first) { if (use) ++use[l]; return symbol[index + (code - first)]; }
             index += c; first += c; first <<= 1; code <<= 1;
         }
         throw std::runtime_error("bad code");
     }
 };
+
+// code-length statistics of the dynamic codes (what K1a's canonical decode works through): longest code per block, and the
+// lengths of the codes actually decoded
+static uint64_t g_maxL[16], g_maxD[16], g_useL[16], g_useD[16];
 
 struct Entry { uint32_t lit_run, len, dist; };     // lit_run literals, then a match (len == 0: literals only)
 
@@ -97,14 +102,16 @@ static void tokens_of(const uint8_t* p, size_t n, std::vector<Entry>* out) {
             }
             L.build(lens, nlen);
             D.build(lens + nlen, ndist);
+            ++g_maxL[L.max_len()];
+            ++g_maxD[D.max_len()];
         }
         for (;;) {
-            int sym = L.decode(b);
+            int sym = L.decode(b, g_useL);
             if (sym < 256) { ++run; continue; }
             if (sym == 256) break;
             sym -= 257;
             uint32_t len = lbase[sym] + b.take(lext[sym]);
-            int ds = D.decode(b);
+            int ds = D.decode(b, g_useD);
             uint32_t dist = dbase[ds] + b.take(dext[ds]);
             while (run > 255) { out->push_back({255, 0, 1}); run -= 255; }
             out->push_back({run, len, dist});
@@ -262,6 +269,14 @@ int main(int argc, char** argv) {
            100.0 * plain_long_hist[0] / std::max<uint64_t>(1, rb_plain_long_tasks), 100.0 * plain_long_hist[1] / std::max<uint64_t>(1, rb_plain_long_tasks),
            100.0 * plain_long_hist[2] / std::max<uint64_t>(1, rb_plain_long_tasks), 100.0 * plain_long_hist[3] / std::max<uint64_t>(1, rb_plain_long_tasks),
            (double)rb_plain_gt32 / batches);
+    printf("code lengths (K1a): longest literal/length code per block | longest distance code per block | decoded literal/length codes | decoded distance codes\n");
+    {
+        uint64_t tb = 0, tl = 0, td = 0;
+        for (int l = 0; l < 16; ++l) { tb += g_maxL[l]; tl += g_useL[l]; td += g_useD[l]; }
+        for (int l = 1; l < 16; ++l)
+            printf("  %2d  %6.2f %%  %6.2f %%  %6.2f %%  %6.2f %%\n", l, 100.0 * g_maxL[l] / std::max<uint64_t>(1, tb), 100.0 * g_maxD[l] / std::max<uint64_t>(1, tb),
+                   100.0 * g_useL[l] / std::max<uint64_t>(1, tl), 100.0 * g_useD[l] / std::max<uint64_t>(1, td));
+    }
     printf("rounds histogram (frontier | exact):\n");
     for (int r = 0; r < 16; ++r) printf("  %2d  %6.2f %%  %6.2f %%\n", r, 100.0 * hist_a[r] / batches, 100.0 * hist_b[r] / batches);
     return 0;
