@@ -43,3 +43,9 @@ for tag in "detached:" "single:SBX_NO_DETACH=1" "thr4:SBX_UPLOAD_THREADS=4" "thr
   for i in 1 2 3; do s=$(now); env $envs sambamba_amd/csrc/sbx-depth base -o /dev/null $BAM 2> $OUT/e2e_${name}_$i.err; e=$(now); python -c "print('$name wall %.3f s' % ($e - $s))" >> $OUT/e2e_runs.txt; grep "sbx-depth\] open\|batch refs" $OUT/e2e_${name}_$i.err | tail -2 | cut -c1-230 >> $OUT/e2e_runs.txt; sleep 2; done
 done
 cat $OUT/e2e_runs.txt
+# fixed cost of a CLI run on a tiny input, both process models
+for tag in "tiny_detached:" "tiny_single:SBX_NO_DETACH=1"; do
+  name=${tag%%:*}; envs=${tag#*:}
+  for i in 1 2 3; do s=$(now); env $envs sambamba_amd/csrc/sbx-depth base -o /dev/null tests/golden/issue_193.bam 2>/dev/null; e=$(now); python -c "print('$name wall %.3f s' % ($e - $s))" >> $OUT/e2e_runs.txt; sleep 1; done
+done
+tail -6 $OUT/e2e_runs.txt
