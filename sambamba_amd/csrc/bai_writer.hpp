@@ -27,6 +27,32 @@ struct BaiRecord {
     uint64_t start_vo, end_vo;
 };
 
+// Virtual offsets (compressed block start << 16 | offset inside the inflated block) of positions of the inflated stream, for
+// queries that never go backwards.  The reference takes them from its reader: BgzfInputStream sets up the next block as soon
+// as the current one is exhausted (inputstream.d:497-530), so the position BEHIND the last byte of a block is offset 0 of the
+// block that starts there -- even an empty one: the end of the last read of a file is the start of its EOF block (this is
+// what the .bai files of the reference's test-suite hold) -- while the position OF a byte is the block that holds it.
+class VoffCursor {
+  public:
+    // block i: file offset coffset[i], inflated bytes [ustart[i], ustart[i + 1]); file_end = offset behind the last block
+    VoffCursor(const uint64_t* coffset, const uint64_t* ustart, size_t n_blocks, uint64_t file_end)
+        : coff_(coffset), ustart_(ustart), n_(n_blocks), file_end_(file_end) {}
+    uint64_t of_byte(uint64_t u) {          // start of a record
+        while (bi_ < n_ && ustart_[bi_ + 1] <= u) ++bi_;
+        return bi_ < n_ ? (coff_[bi_] << 16) | (u - ustart_[bi_]) : file_end_ << 16;
+    }
+    uint64_t behind(uint64_t u) {           // end of a record whose last byte is u - 1
+        while (bi_ < n_ && ustart_[bi_ + 1] <= u && ustart_[bi_] != u) ++bi_;
+        return bi_ < n_ ? (coff_[bi_] << 16) | (u - ustart_[bi_]) : file_end_ << 16;
+    }
+
+  private:
+    const uint64_t* coff_;
+    const uint64_t* ustart_;
+    size_t n_, bi_ = 0;
+    uint64_t file_end_;
+};
+
 class BaiBuilder {
   public:
     BaiBuilder(int n_refs) : n_refs_(n_refs), linear_(37450 - 4681 + 1, 0) {

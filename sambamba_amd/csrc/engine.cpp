@@ -1542,34 +1542,22 @@ int sbx_build_index(const char* bam_path, const char* bai_path, int device, char
             SBX_HIP(hipMemcpy(ref.data(), c->d_rec_ref.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
             SBX_HIP(hipMemcpy(bins.data(), d_bins.p, (size_t)nrec * 2, hipMemcpyDeviceToHost));
         }
-        // virtual offset of a position of the inflated stream: the block that holds the byte, or -- at a block boundary and at
-        // the end of the stream -- the block that starts there (BgzfInputStream.readBlock sets up the next block as soon as
-        // the current one is exhausted, inputstream.d:497-530)
         const BlockTable& bt = c->blocks;
         const size_t nbk = bt.size();
         const uint64_t file_end_coff = nbk ? bt.coffset[nbk - 1] + (bt.comp_off[nbk - 1] - bt.coffset[nbk - 1]) + bt.comp_len[nbk - 1] + 8 : 0;
-        size_t bi = 0;
-        auto voff = [&](uint64_t u) -> uint64_t {        // u is non-decreasing over the calls
-            while (bi < nbk && bt.out_off[bi + 1] <= u) ++bi;
-            if (bi >= nbk) return file_end_coff << 16;
-            return (bt.coffset[bi] << 16) | (u - bt.out_off[bi]);
-        };
+        VoffCursor vc(bt.coffset.data(), bt.out_off.data(), nbk, file_end_coff);
         BaiBuilder bb((int)c->hdr.refs.size());
         const uint64_t total = bt.out_off.back();
-        uint64_t vo = nrec ? voff(desc[0].rec_off) : 0;
         for (uint64_t i = 0; i < nrec; ++i) {
-            const uint64_t next_u = i + 1 < nrec ? desc[(size_t)i + 1].rec_off : total;
-            const uint64_t ve = voff(next_u);
             BaiRecord r;
             r.ref_id = ref[(size_t)i];
             r.position = desc[(size_t)i].pos;
             r.end_position = desc[(size_t)i].end;
             r.bin = bins[(size_t)i];
             r.is_unmapped = (desc[(size_t)i].flag & 0x4) != 0;
-            r.start_vo = vo;
-            r.end_vo = ve;
+            r.start_vo = vc.of_byte(desc[(size_t)i].rec_off);
+            r.end_vo = vc.behind(i + 1 < nrec ? desc[(size_t)i + 1].rec_off : total);
             bb.put(r);
-            vo = ve;
         }
         const std::vector<uint8_t>& bytes = bb.finish();
         FILE* f = fopen(bai_path, "wb");

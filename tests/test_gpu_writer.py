@@ -196,3 +196,21 @@ def test_generator_with_the_device_codec_writes_the_same_reads(tmp_path):
     assert run_oracle(["base", b]) == want and run_cli(["base", b]) == want
     reg = ["base", "-L", "chrA:100000-101000"]
     assert run_cli(reg + [b]) == run_oracle(reg + [a])
+
+
+@pytest.mark.parametrize("name", ["issue225", "issue_193", "issue_204", "mate_overlaps_1_3M_4M"])
+def test_device_index_equals_the_reference_index(tmp_path, name):
+    """sbx_build_index on the reference's fixtures against the .bai files `sambamba index` wrote for them (the host half of
+    the same comparison: tests/test_bai_cpu.py): equal as structures, byte-identical where the reference wrote ascending bins."""
+    from tests.test_bai_cpu import parse_bai
+    from tests.util import GOLDEN
+    bam = str(tmp_path / (name + ".bam"))
+    shutil.copy(os.path.join(GOLDEN, name + ".bam"), bam)
+    sambamba_amd.build_index(bam)
+    mine, tail_m = parse_bai(bam + ".bai")
+    ref, tail_r = parse_bai(os.path.join(GOLDEN, name + ".bam.bai"))
+    assert tail_m == tail_r and len(mine) == len(ref)
+    for (bm, lm, _), (br, lr, _) in zip(mine, ref):
+        assert bm == br and lm == lr
+    if all(o == sorted(o) for _, _, o in ref):
+        assert open(bam + ".bai", "rb").read() == open(os.path.join(GOLDEN, name + ".bam.bai"), "rb").read()
