@@ -15,10 +15,11 @@
 //      VGPRs (two 16-bit limits per register) next to per-length deltas, and ONE accumulator of
 //      v_dot2_u32_u16 products yields both the code length (1 + sum_l (peek >= limit[l])) and the
 //      symbol-index delta -- 3 VALU ops per pair of lengths, branch-free, identical in every lane.
-//      Only the literal/length symbol permutation (288 B + a 36-byte "symbol >= 256" bitmap) and a
+//      Only the literal/length symbol permutation (288 x 9 bits, bit-packed: 324 B) and a
 //      32-byte ring of the lane's compressed input are in LDS: 356 B per lane at an 89-dword stride
 //      (odd => conflict-free for equal offsets), 7 waves per CU; distance symbols and the table-build
-//      counters are packed into VGPRs.  The ring is topped up by the whole wave in synchronous events,
+//      counters are packed into VGPRs; base values and extra-bit counts of length / distance symbols come
+//      from two tables shared by the workgroup.  The ring is topped up by the whole wave in synchronous events,
 //      so that the decode loop never waits on a global load.  The decoder does NOT touch the LZ77
 //      window: it emits the literal bytes (16-byte stores out of a byte shift register) and one 32-bit
 //      entry {literals-before:8, distance-1:15, length:9} per match.  Nothing it loads depends on
@@ -47,12 +48,13 @@ namespace {
 
 constexpr int kInfThreads = 64;              // K1a: one wavefront per workgroup, one lane per BGZF block
 constexpr int kLaneLds = 356;                // bytes of LDS per lane (89 dwords: odd stride; 7 waves x 64 lanes fit 160 KiB)
-constexpr int kLitSymOff = 0;                // u8[288]  low 8 bits of literal/length symbols, canonical order
-constexpr int kLitHiOff = 288;               // u8[36]   bit 8 of those symbols, bit-packed
+constexpr int kLitSymOff = 0;                // 288 x 9 bits: the literal/length symbols in canonical order, bit-packed (324 bytes): one
+                                             //          unaligned 16-bit read and one bit-field extract per symbol
+constexpr int kLitSymBytes = 324;
 constexpr int kRingOff = 324;                // u32[8]   input ring (32 bytes of this lane's compressed payload)
 constexpr int kClLenOff = 32;                // u8[19]   code-length code lengths while a dynamic header is parsed (in the
                                              //          literal area, which is rebuilt afterwards; its symbols sit at 0..18)
-constexpr int kLenTabBytes = 64, kDistTabBytes = 128;   // (tuned variants) symbol -> base / extra bits, shared by the workgroup
+constexpr int kLenTabBytes = 64, kDistTabBytes = 128;   // symbol -> base / extra bits, shared by the workgroup
 constexpr int kLensScratch = 320;            // bytes of global scratch per lane: code lengths being built
 
 enum : uint32_t {
@@ -208,10 +210,13 @@ __device__ __forceinline__ uint32_t decode_pairs(const Code& C, uint32_t v, uint
 // skipped.  zlib's codes for a BAM block: the literal/length code reaches 14 bits, never 15, the distance code 12 at most
 // (tools/token_stats.cpp).
 template <int kShortPairs>
-__device__ __forceinline__ void decode_len(const Code& C, uint32_t v, bool is_short, int* len, uint32_t* delta) {
+__device__ __forceinline__ void decode_len(const Code& C, uint32_t v, uint32_t is_short, int* len, uint32_t* delta) {
     uint32_t acc = decode_pairs<0, kShortPairs>(C, v, C.d1);
-    if (kShortPairs < 8 && !is_short) {
-        asm volatile("");                                 // a real (scalar) branch: the compiler would otherwise compute the pairs and select
+    // (the flag is re-read from its scalar register at every use: hoisted out of the loop, the comparison becomes a lane mask that
+    // costs two vector instructions per test; and a real branch: the compiler would otherwise compute the pairs and select)
+    asm volatile("" : "+s"(is_short));
+    if (kShortPairs < 8 && is_short == 0u) {
+        asm volatile("");
         acc = decode_pairs<kShortPairs, 8>(C, v, acc);
     }
     *len = 1 + (int)(acc >> 13);
@@ -242,24 +247,22 @@ struct Pack16 {
     __device__ __forceinline__ void set(uint32_t l, uint32_t x) { add(l, x - get(l)); }
 };
 
-// The <= 30 distance symbols in canonical order, 5 bits each, six per VGPR.
+// The <= 30 distance symbols in canonical order, 5 bits each: twelve per 64-bit register pair, the last six in a dword.
 struct DistSyms {
-    uint32_t r[5];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) r[j] = 0;
-    }
+    uint64_t a, b;
+    uint32_t c;
+    __device__ __forceinline__ void clear() { a = b = 0; c = 0; }
     __device__ __forceinline__ void put(uint32_t idx, uint32_t sym) {   // idx < 30, slot still zero
-        const uint32_t w = (idx * 43u) >> 8, a = sym << (5u * (idx - 6u * w));
-#pragma unroll
-        for (int j = 0; j < 5; ++j) r[j] |= w == (uint32_t)j ? a : 0u;
+        const uint32_t base = idx >= 24u ? 24u : idx >= 12u ? 12u : 0u;
+        const uint64_t v = (uint64_t)sym << (5u * (idx - base));
+        a |= idx < 12u ? v : 0ull;
+        b |= idx >= 12u && idx < 24u ? v : 0ull;
+        c |= idx >= 24u ? (uint32_t)v : 0u;
     }
     __device__ __forceinline__ uint32_t get(uint32_t idx) const {       // idx < 30
-        const uint32_t w = (idx * 43u) >> 8;
-        uint32_t v = 0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) v = w == (uint32_t)j ? r[j] : v;
-        return (v >> (5u * (idx - 6u * w))) & 31u;
+        const uint32_t base = idx >= 24u ? 24u : idx >= 12u ? 12u : 0u;
+        const uint64_t v = idx >= 24u ? (uint64_t)c : idx >= 12u ? b : a;
+        return (uint32_t)(v >> (5u * (idx - base))) & 31u;
     }
 };
 
@@ -304,8 +307,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
     *complete_within = lim[kWithin] == 32768u;
     if (!ok) return false;
     if (kIsLit) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) ((uint32_t*)(lds + kLitHiOff))[i] = 0;
+        for (int i = 0; i < kLitSymBytes / 4; ++i) ((uint32_t*)(lds + kLitSymOff))[i] = 0;
     }
     if (!kIsLit) DS.clear();
     for (int s = 0; s < n; ++s) {
@@ -314,8 +316,9 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
             uint32_t idx = tmp.get(l);
             tmp.add(l, 1u);
             if (kIsLit) {
-                lds[kLitSymOff + idx] = (uint8_t)s;
-                if (s & 256) lds[kLitHiOff + (idx >> 3)] |= (uint8_t)(1u << (idx & 7));
+                const uint32_t bo = 9u * idx, v = (uint32_t)s << (bo & 7u);     // 9 + 7 bits: two bytes
+                lds[kLitSymOff + (bo >> 3)] |= (uint8_t)v;
+                lds[kLitSymOff + (bo >> 3) + 1] |= (uint8_t)(v >> 8);
             } else if (idx < 30u) {
                 DS.put(idx, (uint32_t)s);
             }
@@ -462,11 +465,11 @@ struct Emitter {
 
 // One input refill per loop iteration covers both literal/length slots (2 x 15 bits <= the 32 a refill guarantees); the
 // output position is not counted per literal but derived (literals + match bytes).
-// kDepth: groups per token-store burst (Emitter).  kTuned: the base value / extra-bit count of a length or distance symbol
-// come from two small tables shared by the workgroup in LDS (29 x u16, 30 x u32: different entries lie in different banks,
-// equal ones are broadcast) instead of ~12 VALU instructions of arithmetic each, and the canonical decode skips the pairs of
-// code lengths no lane's code uses (decode_len).
-template <int kDepth, bool kTuned>
+// kDepth: groups per token-store burst (Emitter).  The base value / extra-bit count of a length or distance symbol come from
+// two small tables shared by the workgroup in LDS (29 x u16, 30 x u32: different entries lie in different banks, equal ones
+// are broadcast) instead of ~12 VALU instructions of arithmetic each, and the canonical decode skips the pairs of code
+// lengths no lane's code uses (decode_len).
+template <int kDepth>
 __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
     const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
@@ -482,11 +485,11 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     uint8_t* lens = lens_scratch + (size_t)b * kLensScratch;
     DistSyms DS;
     DS.clear();
-    // (kTuned) RFC 1951 3.2.5 as tables behind the lanes' areas: length symbol 257 + i -> base | extra bits << 9,
+    // RFC 1951 3.2.5 as tables behind the lanes' areas: length symbol 257 + i -> base | extra bits << 9,
     // distance symbol i -> base | extra bits << 16 (entries 30, 31 exist so that an invalid symbol reads something)
     uint16_t* const len_tab = (uint16_t*)(smem + kInfThreads * kLaneLds);
     uint32_t* const dist_tab = (uint32_t*)(smem + kInfThreads * kLaneLds + kLenTabBytes);
-    if (kTuned) {
+    {
         const uint32_t i = threadIdx.x;
         if (i < 32u) {
             const uint32_t t = i - 4u;
@@ -656,7 +659,10 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             else if (!build_code<false, 12>(lens + nlit, ndist, lds, DS, CD, &dist_in_12)) { err = INF_BAD_CODELENS; active = false; sym_loop = false; }
         }
         // wave-uniform: every decoding lane's code is complete within 14 / 12 bits (decode_len)
-        const bool short_lit = kTuned && __all(!sym_loop || lit_in_14), short_dist = kTuned && __all(!sym_loop || dist_in_12);
+        // (in scalar registers: a flag the compiler keeps as a lane mask costs two vector instructions per test)
+        uint32_t short_lit = __builtin_amdgcn_readfirstlane(__all(!sym_loop || lit_in_14) ? 1u : 0u);
+        uint32_t short_dist = __builtin_amdgcn_readfirstlane(__all(!sym_loop || dist_in_12) ? 1u : 0u);
+        asm volatile("" : "+s"(short_lit), "+s"(short_dist));
 
         // ---- symbol loop -----------------------------------------------------------------
         // Under SIMT the (long) match path is paid by the whole wave in every iteration in which any
@@ -676,11 +682,14 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
                     const uint32_t v = __brev((uint32_t)br.buf) >> 17;
                     int len;
                     uint32_t delta;
-                    decode_len<kTuned ? 7 : 8>(CL, v, short_lit, &len, &delta);
+                    decode_len<7>(CL, v, short_lit, &len, &delta);
                     const int lc = len > 15 ? 15 : len;
                     const uint32_t idx0 = (delta + (v >> (15 - lc))) & 0x1FFu;
                     const uint32_t idx = idx0 > 287u ? 287u : idx0;
-                    const uint32_t sym = (uint32_t)lds[kLitSymOff + idx] | (((uint32_t)lds[kLitHiOff + (idx >> 3)] >> (idx & 7)) & 1u) << 8;
+                    const uint32_t bo = 9u * idx;
+                    uint16_t packed;
+                    __builtin_memcpy(&packed, lds + kLitSymOff + (bo >> 3), 2);
+                    const uint32_t sym = ((uint32_t)packed >> (bo & 7u)) & 0x1FFu;
                     br.drop(lc);
                     const bool ok = len <= 15 && idx0 <= 287u && sym <= 285u;
                     if (ok && sym < 256u) em.literal(sym);             // (overrun: checked once per iteration below)
@@ -695,37 +704,21 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
             if (msym != 0) {
                 // One refill covers the whole match: <= 5 length-extra + 15 code + 13 distance-extra bits.
                 br.refill();
-                // match length (RFC 1951 3.2.5): base and extra bits from the shared table, or computed arithmetically, no branches
-                uint32_t le, lb;
-                if (kTuned) {
-                    const uint32_t lt = len_tab[msym - 257u];
-                    le = lt >> 9;
-                    lb = lt & 0x1FFu;
-                } else {
-                    const uint32_t t = msym - 261u;                                 // valid for msym >= 265
-                    const bool direct = msym < 265u || msym == 285u;
-                    le = direct ? 0u : t >> 2;
-                    lb = msym < 265u ? msym - 254u : msym == 285u ? 258u : ((4u + (t & 3u)) << le) + 3u;
-                }
+                // match length (RFC 1951 3.2.5): base and extra bits from the shared table
+                const uint32_t lt = len_tab[msym - 257u];
+                const uint32_t le = lt >> 9, lb = lt & 0x1FFu;
                 const uint32_t mlen = lb + br.take((int)le);
                 const uint32_t dv = __brev((uint32_t)br.buf) >> 17;
                 int dl;
                 uint32_t ddelta;
-                decode_len<kTuned ? 6 : 8>(CD, dv, short_dist, &dl, &ddelta);
+                decode_len<6>(CD, dv, short_dist, &dl, &ddelta);
                 const int dc = dl > 15 ? 15 : dl;
                 const uint32_t didx0 = (ddelta + (dv >> (15 - dc))) & 0x1FFu;
                 const uint32_t dsym = DS.get(didx0 > 29u ? 29u : didx0);
                 br.drop(dc);
                 // distance (RFC 1951 3.2.5)
-                uint32_t de, db;
-                if (kTuned) {
-                    const uint32_t dt = dist_tab[dsym];
-                    de = dt >> 16;
-                    db = dt & 0xFFFFu;
-                } else {
-                    de = dsym < 4u ? 0u : ((dsym >> 1) - 1u) & 15u;
-                    db = dsym < 4u ? dsym + 1u : ((2u + (dsym & 1u)) << de) + 1u;
-                }
+                const uint32_t dt = dist_tab[dsym];
+                const uint32_t de = dt >> 16, db = dt & 0xFFFFu;
                 const uint32_t dist = db + br.take((int)de);
                 const bool code_ok = dl <= 15 && didx0 < 30u && dsym <= 29u && dist <= opos_now;
                 const bool fits = opos_now + mlen <= osize;
@@ -1078,18 +1071,17 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
     if (n_blocks == 0) { if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream)); return; }
     {
         dim3 grid((n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
-        const size_t lds = (size_t)kInfThreads * kLaneLds, lds_tuned = lds + kLenTabBytes + kDistTabBytes;
-        static const int variant = [] { const char* e = getenv("SBX_K1A_VARIANT"); return e ? atoi(e) : 1; }();
-#define SBX_K1A_LAUNCH(DEPTH, TUNED)                                                                                                    \
-    hipLaunchKernelGGL((k_huffman_decode<DEPTH, TUNED>), grid, block, TUNED ? lds_tuned : lds, stream, d_comp, d_comp_off, d_comp_len, \
-                       d_isize, d_out_off, n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes)
-        switch (variant) {
-            case 2: SBX_K1A_LAUNCH(2, false); break;
-            case 3: SBX_K1A_LAUNCH(1, false); break;
-            case 4: SBX_K1A_LAUNCH(4, true); break;
-            case 5: SBX_K1A_LAUNCH(2, true); break;
-            case 6: SBX_K1A_LAUNCH(1, true); break;
-            default: SBX_K1A_LAUNCH(4, false); break;
+        const size_t lds = (size_t)kInfThreads * kLaneLds + kLenTabBytes + kDistTabBytes;
+        // 16-byte groups per token-store burst: 1 (default) is the fastest -- no register FIFO to shift -- and writes partial
+        // sectors (WRITE_SIZE 2.7 x the token bytes); 2 and 4 trade instructions for write traffic (1.5 x, 1.2 x): DESIGN.md K1a
+        static const int burst = [] { const char* e = getenv("SBX_K1A_BURST"); return e ? atoi(e) : 1; }();
+#define SBX_K1A_LAUNCH(DEPTH)                                                                                                            \
+    hipLaunchKernelGGL((k_huffman_decode<DEPTH>), grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, n_blocks, \
+                       block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes)
+        switch (burst) {
+            case 4: SBX_K1A_LAUNCH(4); break;
+            case 2: SBX_K1A_LAUNCH(2); break;
+            default: SBX_K1A_LAUNCH(1); break;
         }
 #undef SBX_K1A_LAUNCH
         SBX_HIP(hipGetLastError());
