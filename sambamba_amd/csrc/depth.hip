@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(
     const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
 
     // 4 bases of a match run held by this lane: bases q..q+nb-1 of the read at tile offsets p0..
     auto add4 = [&](uint32_t qw, uint32_t sw, uint32_t q, uint32_t nb, uint32_t p0, uint32_t sample) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate16(
     const int32_t te = ts + (int32_t)T;
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
     // counter dword of (tile offset p, sample, code) and its increment
     auto add_code = [&](uint32_t p, uint32_t sample, uint32_t code) {
         atomicAdd(&cnt[(__umul24(swz(p), S) + sample) * 4u + (code >> 1)], 1u << ((code & 1u) << 4));
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 
     if (r_hi - r_lo >= deep_thr) return;                // left to the 32-bit kernel
     const uint32_t n_cnt_dw = 4u * T + (T >> 4);
     uint32_t* cnt = lds;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
     uint8_t* map = (uint8_t*)(lds + ((n_cnt_dw + 3u) & ~3u)) + wave * kMapBytes;
     for (uint32_t i = threadIdx.x; i < n_cnt_dw; i += kAccThreads) lds[i] = 0;
 
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 
     if (r_hi - r_lo >= deep_thr) return;                // left to the 32-bit kernel
     const uint32_t n_cnt_dw = 4u * T + (T >> 4);
     uint32_t* cnt = lds;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
     // per wave: 704 bytes -- the lane map of the single-run reads, then (second stage) 22 run items of 16 bytes + the lane map
     // of their blocks -- and 8 gap items of 8 bytes
     uint8_t* map = (uint8_t*)(lds + ((n_cnt_dw + 3u) & ~3u)) + wave * kWaveBytesC;

@@ -759,7 +759,7 @@ __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5,
     if (threadIdx.x < 7) tot[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t b = blockIdx.x * (kDescThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t b = blockIdx.x * (kDescThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
     // (descriptor array too small: nothing is written, the host enlarges it and launches again)
     const uint32_t count = (b < a.n_blocks && !a.flags[2]) ? a.count[b] : 0u;
     uint32_t n_adm = 0, n_bad = 0, n_urg = 0, b_seq = 0, b_qual = 0, m_span = 0;

@@ -861,7 +861,9 @@ __device__ __forceinline__ void lz77_resolve_body(
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
     uint8_t* out, const uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler then knows that the block, its streams, the batch loop and every running
+    // position are wave-uniform -- scalar registers, scalar arithmetic, scalar branches)
+    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
     if (kOwn32) {
         uint32_t* tab = (uint32_t*)(smem + (kResThreads / 64) * (kHist + 1024u + kSpanMax + 16u));
@@ -947,11 +949,16 @@ __device__ __forceinline__ void lz77_resolve_body(
         const uint32_t s_hi = src + (len < dist ? len : dist);
         const uint32_t dsto = dst - base, srco = src - base;
         bool pending = len != 0 && !far;
+        // what the rounds of this batch can meet at all, in scalar registers: testing for a rare kind of match costs every round
+        // two vector instructions (the wave-wide test of a lane condition), so the kinds a batch does not hold are tested once
+        const uint32_t has_long_b = __builtin_amdgcn_readfirstlane(__any(pending && len > 16u && (dist < len || len > (kOwn32 ? 32u : 16u))) ? 1u : 0u);
+        const uint32_t has_per_short_b = __builtin_amdgcn_readfirstlane(__any(pending && dist < len && len <= 16u) ? 1u : 0u);
         for (uint64_t pm = __ballot(pending); pm; pm = __ballot(pending)) {
             const uint32_t F = __builtin_amdgcn_readlane(dst, __builtin_ctzll(pm));
             const bool ready = pending && s_hi <= F;
             pending = pending && !ready;
             const bool plain = ready && dist >= len;
+            uint32_t has_long = has_long_b, has_per_short = has_per_short_b;
             {
                 constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;
                 const uint32_t own_s = plain && len <= kOwn ? len : 0u;       // (source and destination of a plain match do not overlap)
@@ -962,14 +969,14 @@ __device__ __forceinline__ void lz77_resolve_body(
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
                 }
-                coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
+                if (has_long) coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
             // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
             // 1, 2, 4 ... periods copied from the match's own output.
             const bool per = ready && dist < len;
             const bool per_perm = kOwn32 && per && len <= 16 && dist <= 8;
-            if (kOwn32 && __any(per_perm)) {
+            if (kOwn32 && has_per_short && __any(per_perm)) {
                 // output byte k = period[k mod dist]: the period sits in the first (<= 8) bytes at src, output dword j is one byte
                 // permute of them; the tail dword (offset len - 4) is cut out of two neighbours
                 Short16 ws;
@@ -991,7 +998,7 @@ __device__ __forceinline__ void lz77_resolve_body(
                 }
                 ws.store(buf + dsto, n_p);
             }
-            if (per && len <= 16 && !per_perm) {
+            if (has_per_short && per && len <= 16 && !per_perm) {
                 uint32_t lo = 0, hi = 0, m = 0;      // 16 bytes in two 64-bit halves would need 4 regs; len <= 16
                 uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1006,7 +1013,7 @@ __device__ __forceinline__ void lz77_resolve_body(
                 for (uint32_t k = 0; k < 16; ++k)
                     if (k < len) buf[dsto + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
             }
-            for (uint64_t lm = __ballot(per && len > 16); lm; lm &= lm - 1) {
+            for (uint64_t lm = has_long ? __ballot(per && len > 16) : 0ull; lm; lm &= lm - 1) {
                 const int q = __builtin_ctzll(lm);
                 const uint32_t D = __builtin_amdgcn_readlane(dsto, q), P = __builtin_amdgcn_readlane(dist, q), N = __builtin_amdgcn_readlane(len, q);
                 wave_copy(buf + D, buf + D - P, P, lane);

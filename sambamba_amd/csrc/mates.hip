@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     __syncthreads();
     if (fast_path) {
         // ---- phase 1: eligible reads, 16 aligned positions per lane ------------------------------------------------------
-        const uint32_t wlane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint32_t wlane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         uint8_t* map = (uint8_t*)(lds + 4 * sub_dw + (kSpan ? T : 0u)) + wave * kMateMapBytes;
         for (uint32_t c0 = r_lo + wave * 64u; c0 < r_hi; c0 += (kMateThreads / 64) * 64u) {
             const uint32_t ri = c0 + wlane;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kMateThreads) void k_mates_columns(
     const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T), te = ts + (int32_t)T;
     const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
     for (uint32_t ri = r_lo + wave; ri < r_hi; ri += kMateThreads / 64) {
         const RecDesc a = desc[ri];
         if (a.kind == 0 || a.pos >= te || a.end <= ts) continue;
