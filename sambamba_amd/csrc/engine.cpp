@@ -1542,12 +1542,25 @@ int sbx_build_index(const char* bam_path, const char* bai_path, int device, char
             SBX_HIP(hipMemcpy(ref.data(), c->d_rec_ref.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
             SBX_HIP(hipMemcpy(bins.data(), d_bins.p, (size_t)nrec * 2, hipMemcpyDeviceToHost));
         }
+        // block table of the stream the record offsets refer to: the blocks of the work list (it starts at the block of the
+        // first record -- a header that fills its blocks exactly is not part of it), then whatever blocks follow it in the file
+        // (the EOF block)
         const BlockTable& bt = c->blocks;
+        const WorkList& wl = c->wl;
         const size_t nbk = bt.size();
         const uint64_t file_end_coff = nbk ? bt.coffset[nbk - 1] + (bt.comp_off[nbk - 1] - bt.coffset[nbk - 1]) + bt.comp_len[nbk - 1] + 8 : 0;
-        VoffCursor vc(bt.coffset.data(), bt.out_off.data(), nbk, file_end_coff);
+        std::vector<uint64_t> v_coff, v_ustart;
+        for (size_t i = 0; i < wl.n_blocks(); ++i) { v_coff.push_back(bt.coffset[wl.file_blk[i]]); v_ustart.push_back(wl.out_off[i]); }
+        uint64_t u_end = wl.out_off.empty() ? 0 : wl.out_off.back();
+        for (size_t j = wl.n_blocks() ? (size_t)wl.file_blk.back() + 1 : 0; j < nbk; ++j) {
+            v_coff.push_back(bt.coffset[j]);
+            v_ustart.push_back(u_end);
+            u_end += bt.isize[j];
+        }
+        v_ustart.push_back(u_end);
+        VoffCursor vc(v_coff.data(), v_ustart.data(), v_coff.size(), file_end_coff);
         BaiBuilder bb((int)c->hdr.refs.size());
-        const uint64_t total = bt.out_off.back();
+        const uint64_t total = wl.out_off.empty() ? 0 : wl.out_off.back();
         for (uint64_t i = 0; i < nrec; ++i) {
             BaiRecord r;
             r.ref_id = ref[(size_t)i];

@@ -855,7 +855,7 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // by their own lane with a second 16-byte step; and a short self-overlapping match (a run, a dinucleotide repeat: 0.8 per
 // batch, 84 % with a period of at most 8) is no longer expanded byte by byte but with four byte permutes of the period
 // (v_perm_b32, selectors per period from a 128-byte table in LDS).
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32>
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kUniformWave, bool kBatchFlags>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -863,7 +863,7 @@ __device__ __forceinline__ void lz77_resolve_body(
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // (the wave index through readfirstlane: the compiler then knows that the block, its streams, the batch loop and every running
     // position are wave-uniform -- scalar registers, scalar arithmetic, scalar branches)
-    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u, wv = kUniformWave ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
     if (kOwn32) {
         uint32_t* tab = (uint32_t*)(smem + (kResThreads / 64) * (kHist + 1024u + kSpanMax + 16u));
@@ -951,8 +951,8 @@ __device__ __forceinline__ void lz77_resolve_body(
         bool pending = len != 0 && !far;
         // what the rounds of this batch can meet at all, in scalar registers: testing for a rare kind of match costs every round
         // two vector instructions (the wave-wide test of a lane condition), so the kinds a batch does not hold are tested once
-        const uint32_t has_long_b = __builtin_amdgcn_readfirstlane(__any(pending && len > 16u && (dist < len || len > (kOwn32 ? 32u : 16u))) ? 1u : 0u);
-        const uint32_t has_per_short_b = __builtin_amdgcn_readfirstlane(__any(pending && dist < len && len <= 16u) ? 1u : 0u);
+        const uint32_t has_long_b = !kBatchFlags ? 1u : __builtin_amdgcn_readfirstlane(__any(pending && len > 16u && (dist < len || len > (kOwn32 ? 32u : 16u))) ? 1u : 0u);
+        const uint32_t has_per_short_b = !kBatchFlags ? 1u : __builtin_amdgcn_readfirstlane(__any(pending && dist < len && len <= 16u) ? 1u : 0u);
         for (uint64_t pm = __ballot(pending); pm; pm = __ballot(pending)) {
             const uint32_t F = __builtin_amdgcn_readlane(dst, __builtin_ctzll(pm));
             const bool ready = pending && s_hi <= F;
@@ -1048,20 +1048,20 @@ __device__ __forceinline__ void lz77_resolve_body(
                       const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0, uint8_t* out, \
                       const uint32_t* __restrict__ status
 #define SBX_LZ77_PASS lit_stream, ent_stream, n_entries, out_off, isize, n_blocks, block0, out, status
-// the same body at different register budgets (waves per SIMD): the variant with the 32-byte own-lane copies needs 77 VGPRs
-// left alone (6 waves), 72 with 4 spilled dwords (7 waves), 64 with 15 (8 waves); which one wins is a measurement
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) void k_lz77_resolve(SBX_LZ77_ARGS) { lz77_resolve_body<kHist, kSpanMax, false>(SBX_LZ77_PASS); }
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) void k_lz77_resolve_o32(SBX_LZ77_ARGS) { lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS); }
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lz77_resolve_o32w7(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS);
-}
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_o32w8(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS);
-}
+// the same body with and without the two hints to the compiler (measured per variant: DESIGN.md K1b)
+#define SBX_LZ77_KERNEL(NAME, OWN32, UNIFORM, FLAGS, ATTR)                                                                       \
+    template <uint32_t kHist, uint32_t kSpanMax>                                                                                \
+    __global__ __launch_bounds__(kResThreads) ATTR void NAME(SBX_LZ77_ARGS) {                                                   \
+        lz77_resolve_body<kHist, kSpanMax, OWN32, UNIFORM, FLAGS>(SBX_LZ77_PASS);                                               \
+    }
+SBX_LZ77_KERNEL(k_lz77_resolve, false, false, false, )
+SBX_LZ77_KERNEL(k_lz77_resolve_o32, true, false, false, )
+SBX_LZ77_KERNEL(k_lz77_resolve_o32_w8, true, false, false, __attribute__((amdgpu_waves_per_eu(8, 8))))
+SBX_LZ77_KERNEL(k_lz77_resolve_o32_u, true, true, false, )
+SBX_LZ77_KERNEL(k_lz77_resolve_o32_f, true, false, true, )
+SBX_LZ77_KERNEL(k_lz77_resolve_o32_uf, true, true, true, )
+SBX_LZ77_KERNEL(k_lz77_resolve_o32_uf_w8, true, true, true, __attribute__((amdgpu_waves_per_eu(8, 8))))
+#undef SBX_LZ77_KERNEL
 
 }  // namespace
 
@@ -1099,18 +1099,19 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
         const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
         static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 1; }();
-        if (variant == 0)
-            hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize,
-                               n_blocks, block0, d_out, d_status);
-        else if (variant == 2)
-            hipLaunchKernelGGL((k_lz77_resolve_o32w7<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
-                               d_isize, n_blocks, block0, d_out, d_status);
-        else if (variant == 3)
-            hipLaunchKernelGGL((k_lz77_resolve_o32w8<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
-                               d_isize, n_blocks, block0, d_out, d_status);
-        else
-            hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
-                               d_isize, n_blocks, block0, d_out, d_status);
+#define SBX_K1B_LAUNCH(NAME, LDS)                                                                                                        \
+    hipLaunchKernelGGL((NAME<kHistDefault, kSpanDefault>), grid, block, LDS, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks, \
+                       block0, d_out, d_status)
+        switch (variant) {
+            case 0: SBX_K1B_LAUNCH(k_lz77_resolve, lds); break;
+            case 3: SBX_K1B_LAUNCH(k_lz77_resolve_o32_uf_w8, lds + 128); break;
+            case 4: SBX_K1B_LAUNCH(k_lz77_resolve_o32_u, lds + 128); break;
+            case 5: SBX_K1B_LAUNCH(k_lz77_resolve_o32_f, lds + 128); break;
+            case 6: SBX_K1B_LAUNCH(k_lz77_resolve_o32_uf, lds + 128); break;
+            case 7: SBX_K1B_LAUNCH(k_lz77_resolve_o32_w8, lds + 128); break;
+            default: SBX_K1B_LAUNCH(k_lz77_resolve_o32, lds + 128); break;
+        }
+#undef SBX_K1B_LAUNCH
         SBX_HIP(hipGetLastError());
     }
 }

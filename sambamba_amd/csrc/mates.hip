@@ -261,6 +261,7 @@ __device__ MultiPlan plan_multi(const RecDesc* __restrict__ desc, uint32_t ia, c
                   SBX_M_LUT_OFF_ENTRY(15))
 #define kMLutHalf ((1u << 4) | (1u << 16))
 constexpr uint32_t kMateMapBytes = 704;      // 64 reads x 11 blocks
+constexpr uint32_t kMateWorkCap = 382;       // records of a tile left to the per-position path (u16 indices) + two counters: 768 bytes
 
 __device__ __forceinline__ bool single_run_ok(const RecDesc& d) {      // one run of aligned bases that lies inside the sequence
     return d.kind == 1 && (uint64_t)d.q_start + (uint64_t)(d.end - d.pos) <= (uint64_t)d.l_seq;
@@ -291,6 +292,12 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     }
     const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T), te = ts + (int32_t)T;
     const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
+    // the records phase 1 leaves to the per-position path are listed here (indices relative to r_lo), so that phase 2 does not
+    // have to walk all records of the tile again -- descriptor -> mate -> mate's descriptor, three dependent loads each -- just
+    // to find that there is nothing left for it; work_n[0] = entries, work_n[1] != 0: the list overflowed, phase 2 scans
+    uint16_t* const work = (uint16_t*)((uint8_t*)(lds + 4 * sub_dw + (kSpan ? T : 0u)) + (kMateThreads / 64) * kMateMapBytes);
+    uint32_t* const work_n = (uint32_t*)(work + kMateWorkCap);
+    if (fast_path && threadIdx.x < 2) work_n[threadIdx.x] = threadIdx.x == 1 && r_hi - r_lo > 0xFFFFu ? 1u : 0u;
     __syncthreads();
     if (fast_path) {
         // ---- phase 1: eligible reads, 16 aligned positions per lane ------------------------------------------------------
@@ -321,6 +328,19 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
             // (runs of more than eleven blocks -- long reads -- would overflow the map: they stay on the per-position path; the
             //  test below is repeated there)
             const uint32_t nblk = nblk_all <= 11u ? nblk_all : 0u;
+            {
+                const bool todo = a.kind != 0 && a.pos < te && a.end > ts && !(el && nblk_all <= 11u);
+                const uint64_t tm = __ballot(todo);
+                if (tm) {
+                    uint32_t at = 0;
+                    if (wlane == 0) at = atomicAdd(&work_n[0], (uint32_t)__popcll(tm));
+                    at = __builtin_amdgcn_readfirstlane(at) + (uint32_t)__popcll(tm & ((1ull << wlane) - 1ull));
+                    if (todo) {
+                        if (at < kMateWorkCap) work[at] = (uint16_t)(ri - r_lo);
+                        else work_n[1] = 1u;
+                    }
+                }
+            }
             const uint32_t q0 = (uint32_t)a.q_start + (uint32_t)i0;
             const uint64_t a_seq = a.rec_off + 36u + a.l_name + 4u * (uint32_t)a.n_cigar;
             const uint64_t a_nib = a_seq + (q0 >> 1);                                   // byte of the run's first base
@@ -402,13 +422,17 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     // loads a record needs -- descriptor -> mate index -> mate's descriptor -> both reads' bytes -- is in flight for
     // four records per wave instead of one.
     const uint32_t lane = threadIdx.x & 15u, quarter = threadIdx.x >> 4;
-    for (uint32_t ri = r_lo + quarter; ri < r_hi; ri += kMateThreads / 16) {
+    __syncthreads();                                                // (the list is complete)
+    const bool listed = fast_path && work_n[1] == 0u;
+    const uint32_t n_it = listed ? work_n[0] : r_hi - r_lo;
+    for (uint32_t it = quarter; it < n_it; it += kMateThreads / 16) {
+        const uint32_t ri = r_lo + (listed ? (uint32_t)work[it] : it);
         const RecDesc a = desc[ri];
         if (a.kind == 0 || a.pos >= te || a.end <= ts) continue;
         const uint32_t sample = S > 1 ? a.sample : 0u;
         const int32_t p0 = a.pos > ts ? a.pos : ts, p1 = a.end < te ? a.end : te;
         const uint32_t np = ext ? n_partners[ri] : 0u;
-        if (fast_path && np <= 1u && single_run_ok(a)) {
+        if (!listed && fast_path && np <= 1u && single_run_ok(a)) {
             // handled by phase 1?  (the same test, with the same inputs)
             const uint32_t mi_f = mate[ri];
             RecDesc bf;
@@ -593,7 +617,7 @@ void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const ui
     if (!n_active) return;
     static const int fast = [] { const char* e = getenv("SBX_K7_VARIANT"); return e ? atoi(e) : 1; }();
     size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0) +
-                 (fast ? (size_t)(kMateThreads / 64) * kMateMapBytes : 0);
+                 (fast ? (size_t)(kMateThreads / 64) * kMateMapBytes + kMateWorkCap * 2 + 8 : 0);
     if (d_span) {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate_mates<true>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,
