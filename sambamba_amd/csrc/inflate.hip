@@ -855,15 +855,16 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // by their own lane with a second 16-byte step; and a short self-overlapping match (a run, a dinucleotide repeat: 0.8 per
 // batch, 84 % with a period of at most 8) is no longer expanded byte by byte but with four byte permutes of the period
 // (v_perm_b32, selectors per period from a 128-byte table in LDS).
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kUniformWave, bool kBatchFlags>
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
     uint8_t* out, const uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // (the wave index through readfirstlane: the compiler then knows that the block, its streams, the batch loop and every running
-    // position are wave-uniform -- scalar registers, scalar arithmetic, scalar branches)
-    const uint32_t lane = threadIdx.x & 63u, wv = kUniformWave ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
+    // (measured: telling the compiler that the wave index is uniform -- readfirstlane -- moves the block's state and the batch loop
+    // into scalar registers, 879 -> 791 vector instructions, and makes the kernel 6 % SLOWER; per-batch scalar flags for the rare
+    // kinds of matches change nothing: profiles/round3/call_i_stdout_summary.txt)
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
     if (kOwn32) {
         uint32_t* tab = (uint32_t*)(smem + (kResThreads / 64) * (kHist + 1024u + kSpanMax + 16u));
@@ -949,16 +950,11 @@ __device__ __forceinline__ void lz77_resolve_body(
         const uint32_t s_hi = src + (len < dist ? len : dist);
         const uint32_t dsto = dst - base, srco = src - base;
         bool pending = len != 0 && !far;
-        // what the rounds of this batch can meet at all, in scalar registers: testing for a rare kind of match costs every round
-        // two vector instructions (the wave-wide test of a lane condition), so the kinds a batch does not hold are tested once
-        const uint32_t has_long_b = !kBatchFlags ? 1u : __builtin_amdgcn_readfirstlane(__any(pending && len > 16u && (dist < len || len > (kOwn32 ? 32u : 16u))) ? 1u : 0u);
-        const uint32_t has_per_short_b = !kBatchFlags ? 1u : __builtin_amdgcn_readfirstlane(__any(pending && dist < len && len <= 16u) ? 1u : 0u);
         for (uint64_t pm = __ballot(pending); pm; pm = __ballot(pending)) {
             const uint32_t F = __builtin_amdgcn_readlane(dst, __builtin_ctzll(pm));
             const bool ready = pending && s_hi <= F;
             pending = pending && !ready;
             const bool plain = ready && dist >= len;
-            uint32_t has_long = has_long_b, has_per_short = has_per_short_b;
             {
                 constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;
                 const uint32_t own_s = plain && len <= kOwn ? len : 0u;       // (source and destination of a plain match do not overlap)
@@ -969,14 +965,14 @@ __device__ __forceinline__ void lz77_resolve_body(
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
                 }
-                if (has_long) coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
+                coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
             // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
             // 1, 2, 4 ... periods copied from the match's own output.
             const bool per = ready && dist < len;
             const bool per_perm = kOwn32 && per && len <= 16 && dist <= 8;
-            if (kOwn32 && has_per_short && __any(per_perm)) {
+            if (kOwn32 && __any(per_perm)) {
                 // output byte k = period[k mod dist]: the period sits in the first (<= 8) bytes at src, output dword j is one byte
                 // permute of them; the tail dword (offset len - 4) is cut out of two neighbours
                 Short16 ws;
@@ -998,7 +994,7 @@ __device__ __forceinline__ void lz77_resolve_body(
                 }
                 ws.store(buf + dsto, n_p);
             }
-            if (has_per_short && per && len <= 16 && !per_perm) {
+            if (per && len <= 16 && !per_perm) {
                 uint32_t lo = 0, hi = 0, m = 0;      // 16 bytes in two 64-bit halves would need 4 regs; len <= 16
                 uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1013,7 +1009,7 @@ __device__ __forceinline__ void lz77_resolve_body(
                 for (uint32_t k = 0; k < 16; ++k)
                     if (k < len) buf[dsto + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
             }
-            for (uint64_t lm = has_long ? __ballot(per && len > 16) : 0ull; lm; lm &= lm - 1) {
+            for (uint64_t lm = __ballot(per && len > 16); lm; lm &= lm - 1) {
                 const int q = __builtin_ctzll(lm);
                 const uint32_t D = __builtin_amdgcn_readlane(dsto, q), P = __builtin_amdgcn_readlane(dist, q), N = __builtin_amdgcn_readlane(len, q);
                 wave_copy(buf + D, buf + D - P, P, lane);
@@ -1048,20 +1044,14 @@ __device__ __forceinline__ void lz77_resolve_body(
                       const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0, uint8_t* out, \
                       const uint32_t* __restrict__ status
 #define SBX_LZ77_PASS lit_stream, ent_stream, n_entries, out_off, isize, n_blocks, block0, out, status
-// the same body with and without the two hints to the compiler (measured per variant: DESIGN.md K1b)
-#define SBX_LZ77_KERNEL(NAME, OWN32, UNIFORM, FLAGS, ATTR)                                                                       \
-    template <uint32_t kHist, uint32_t kSpanMax>                                                                                \
-    __global__ __launch_bounds__(kResThreads) ATTR void NAME(SBX_LZ77_ARGS) {                                                   \
-        lz77_resolve_body<kHist, kSpanMax, OWN32, UNIFORM, FLAGS>(SBX_LZ77_PASS);                                               \
-    }
-SBX_LZ77_KERNEL(k_lz77_resolve, false, false, false, )
-SBX_LZ77_KERNEL(k_lz77_resolve_o32, true, false, false, )
-SBX_LZ77_KERNEL(k_lz77_resolve_o32_w8, true, false, false, __attribute__((amdgpu_waves_per_eu(8, 8))))
-SBX_LZ77_KERNEL(k_lz77_resolve_o32_u, true, true, false, )
-SBX_LZ77_KERNEL(k_lz77_resolve_o32_f, true, false, true, )
-SBX_LZ77_KERNEL(k_lz77_resolve_o32_uf, true, true, true, )
-SBX_LZ77_KERNEL(k_lz77_resolve_o32_uf_w8, true, true, true, __attribute__((amdgpu_waves_per_eu(8, 8))))
-#undef SBX_LZ77_KERNEL
+// k_lz77_resolve: round 2's kernel (own-lane copies up to 16 bytes); k_lz77_resolve_o32: own-lane copies up to 32 bytes + byte-permute
+// expansion of short periodic matches, compiled for 8 waves per SIMD (64 VGPRs either way; the attribute is worth 0.4 ms)
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) void k_lz77_resolve(SBX_LZ77_ARGS) { lz77_resolve_body<kHist, kSpanMax, false>(SBX_LZ77_PASS); }
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_o32(SBX_LZ77_ARGS) {
+    lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS);
+}
 
 }  // namespace
 
@@ -1099,19 +1089,12 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
         const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
         static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 1; }();
-#define SBX_K1B_LAUNCH(NAME, LDS)                                                                                                        \
-    hipLaunchKernelGGL((NAME<kHistDefault, kSpanDefault>), grid, block, LDS, stream, d_lit, d_ent, d_nent, d_out_off, d_isize, n_blocks, \
-                       block0, d_out, d_status)
-        switch (variant) {
-            case 0: SBX_K1B_LAUNCH(k_lz77_resolve, lds); break;
-            case 3: SBX_K1B_LAUNCH(k_lz77_resolve_o32_uf_w8, lds + 128); break;
-            case 4: SBX_K1B_LAUNCH(k_lz77_resolve_o32_u, lds + 128); break;
-            case 5: SBX_K1B_LAUNCH(k_lz77_resolve_o32_f, lds + 128); break;
-            case 6: SBX_K1B_LAUNCH(k_lz77_resolve_o32_uf, lds + 128); break;
-            case 7: SBX_K1B_LAUNCH(k_lz77_resolve_o32_w8, lds + 128); break;
-            default: SBX_K1B_LAUNCH(k_lz77_resolve_o32, lds + 128); break;
-        }
-#undef SBX_K1B_LAUNCH
+        if (variant == 0)
+            hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize,
+                               n_blocks, block0, d_out, d_status);
+        else
+            hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
+                               d_isize, n_blocks, block0, d_out, d_status);
         SBX_HIP(hipGetLastError());
     }
 }

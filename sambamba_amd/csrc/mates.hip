@@ -284,7 +284,8 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     uint32_t* cnt = lds;
     uint32_t* spn = lds + 4 * sub_dw;
     const uint32_t tile = active[blockIdx.x];
-    for (uint32_t i = threadIdx.x; i < 4 * sub_dw + (kSpan ? T : 0u); i += kMateThreads) lds[i] = 0;
+    const uint32_t spn_dw = kSpan ? T : 0u;
+    for (uint32_t i = threadIdx.x; i < 4 * sub_dw + spn_dw; i += kMateThreads) lds[i] = 0;
     int lo_r = 0, hi_r = n_ref;
     while (hi_r - lo_r > 1) {
         int mid = (lo_r + hi_r) >> 1;
@@ -295,14 +296,20 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     // the records phase 1 leaves to the per-position path are listed here (indices relative to r_lo), so that phase 2 does not
     // have to walk all records of the tile again -- descriptor -> mate -> mate's descriptor, three dependent loads each -- just
     // to find that there is nothing left for it; work_n[0] = entries, work_n[1] != 0: the list overflowed, phase 2 scans
-    uint16_t* const work = (uint16_t*)((uint8_t*)(lds + 4 * sub_dw + (kSpan ? T : 0u)) + (kMateThreads / 64) * kMateMapBytes);
+    uint16_t* const work = (uint16_t*)((uint8_t*)(lds + 4 * sub_dw + spn_dw) + (kMateThreads / 64) * kMateMapBytes);
     uint32_t* const work_n = (uint32_t*)(work + kMateWorkCap);
     if (fast_path && threadIdx.x < 2) work_n[threadIdx.x] = threadIdx.x == 1 && r_hi - r_lo > 0xFFFFu ? 1u : 0u;
+    // span counts of the reads phase 1 takes: a difference array (+1 at the first, -1 behind the last position of the clipped run --
+    // two atomics per read instead of one per base, whose lanes, 16 positions apart, would share four banks), integrated when the
+    // tile is written; [T + 1] entries, then 4 wave totals
+    int32_t* const sdf = (int32_t*)(work_n + 2);
+    if (kSpan && fast_path)
+        for (uint32_t i = threadIdx.x; i < T + 5u; i += kMateThreads) sdf[i] = 0;
     __syncthreads();
     if (fast_path) {
         // ---- phase 1: eligible reads, 16 aligned positions per lane ------------------------------------------------------
         const uint32_t wlane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        uint8_t* map = (uint8_t*)(lds + 4 * sub_dw + (kSpan ? T : 0u)) + wave * kMateMapBytes;
+        uint8_t* map = (uint8_t*)(lds + 4 * sub_dw + spn_dw) + wave * kMateMapBytes;
         for (uint32_t c0 = r_lo + wave * 64u; c0 < r_hi; c0 += (kMateThreads / 64) * 64u) {
             const uint32_t ri = c0 + wlane;
             RecDesc a, b;
@@ -342,6 +349,7 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
                 }
             }
             const uint32_t q0 = (uint32_t)a.q_start + (uint32_t)i0;
+            if (kSpan && nblk != 0u) { atomicAdd(&sdf[t0], 1); atomicAdd(&sdf[t0 + n_run], -1); }
             const uint64_t a_seq = a.rec_off + 36u + a.l_name + 4u * (uint32_t)a.n_cigar;
             const uint64_t a_nib = a_seq + (q0 >> 1);                                   // byte of the run's first base
             const uint64_t a_qual = a_seq + ((a.l_seq + 1u) >> 1) + q0;                 // quality of the run's first base
@@ -411,7 +419,6 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
                     const uint32_t inc = v & (low ^ 1u) & ((ov ^ 1u) | win);
                     // dword of position pb + k: (k & 3) * sub_dw + ((pb >> 2) + (k >> 2)) * s7
                     atomicAdd(cbase + (k & 3u) * sub_dw + (k >> 2) * s7 + code, inc);
-                    if (kSpan) atomicAdd(&spn[pb + k], v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -516,7 +523,29 @@ __global__ __launch_bounds__(kMateThreads) void k_accumulate_mates(
     }
     if (kSpan) {
         uint32_t* so = span_out + (size_t)blockIdx.x * T;
-        for (uint32_t i = threadIdx.x; i < T; i += kMateThreads) so[i] = spn[i];
+        if (!fast_path) {
+            for (uint32_t i = threadIdx.x; i < T; i += kMateThreads) so[i] = spn[i];
+        } else {
+            // per-position counts of phase 2 + the integrated difference array of phase 1: every thread owns `chunk` consecutive positions
+            const uint32_t wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+            const uint32_t chunk = (T + kMateThreads - 1) / kMateThreads;
+            const uint32_t q0 = threadIdx.x * chunk;
+            int32_t loc = 0;
+            for (uint32_t k = 0; k < chunk; ++k) if (q0 + k < T) loc += sdf[q0 + k];
+            int32_t incl = loc;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int32_t o = __shfl_up(incl, dlt, 64);
+                if ((int)wl >= dlt) incl += o;
+            }
+            int32_t* wtot = sdf + T + 1;
+            if (wl == 63) wtot[wv] = incl;
+            __syncthreads();
+            int32_t run = incl - loc;
+            for (uint32_t w = 0; w < wv; ++w) run += wtot[w];
+            for (uint32_t k = 0; k < chunk; ++k)
+                if (q0 + k < T) { run += sdf[q0 + k]; so[q0 + k] = spn[q0 + k] + (uint32_t)run; }
+        }
     }
 }
 
@@ -617,7 +646,7 @@ void launch_accumulate_mates(const uint8_t* d_U, const RecDesc* d_desc, const ui
     if (!n_active) return;
     static const int fast = [] { const char* e = getenv("SBX_K7_VARIANT"); return e ? atoi(e) : 1; }();
     size_t lds = ((size_t)(tile_pos / 4) * n_samples * 7 + 8) * 16 + (d_span ? (size_t)tile_pos * 4 : 0) +
-                 (fast ? (size_t)(kMateThreads / 64) * kMateMapBytes + kMateWorkCap * 2 + 8 : 0);
+                 (fast ? (size_t)(kMateThreads / 64) * kMateMapBytes + kMateWorkCap * 2 + 8 + (d_span ? (size_t)(tile_pos + 5) * 4 : 0) : 0);
     if (d_span) {
         SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate_mates<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_accumulate_mates<true>, dim3(n_active), dim3(kMateThreads), lds, stream, d_U, d_desc, d_mate, d_tile_lo,

@@ -61,6 +61,6 @@ if sq:
     with open(os.path.join(out, "pmc_sq.csv"), "w") as fh:
         fh.write("kernel,counter,value\n")
         for (k, c), v in sorted(agg.items()):
-            if k in ("k_huffman_decode", "k_lz77_resolve", "k_accumulate16", "k_accumulate", "k_describe_blocks", "k_walk_blocks", "k_check_scan"):
+            if k.startswith(("k_huffman_decode", "k_lz77_resolve", "k_accumulate", "k_describe_blocks", "k_walk_blocks", "k_check_scan")):
                 fh.write("%s,%s,%d\n" % (k, c, v))
                 print("sq", k, c, int(v))

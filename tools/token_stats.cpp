@@ -7,7 +7,7 @@
 //   (a) under K1b's rule: a match may start once everything below its source end is final, "final" being everything
 //       below the start of the first unfinished match (one readlane per round);
 //   (b) under the exact rule: a match may start once no unfinished match writes into its source range.
-// Host-only, no device code; g++ -O2 -o token_stats token_stats.cpp.  Numbers quoted in DESIGN.md section 9.
+// Host-only, no device code; g++ -O2 -o token_stats token_stats.cpp.  Numbers quoted in DESIGN.md sections 3 (K1a, K1b) and 10.
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
