@@ -197,11 +197,15 @@ struct Code {
 template <int kFrom, int kTo>
 __device__ __forceinline__ uint32_t decode_pairs(const Code& C, uint32_t v, uint32_t acc) {
     const s16x2 vv = {(short)v, (short)v};
+    // all masks first, then the chain of dot products: back to back, a packed subtract, its shift and the dot product that reads it
+    // need wait states (s_nop) that occupy the wave's issue slot as an instruction does
+    u16x2 m[kTo - kFrom];
 #pragma unroll
-    for (int j = kFrom; j < kTo; ++j) {
-        const u16x2 m = (u16x2)(C.lim1[j] - vv) >> 15;   // 1 where v >= limit
-        acc = __builtin_amdgcn_udot2(m, C.dd[j], acc, false);
-    }
+    for (int j = kFrom; j < kTo; ++j) m[j - kFrom] = (u16x2)(C.lim1[j] - vv);
+#pragma unroll
+    for (int j = kFrom; j < kTo; ++j) m[j - kFrom] = m[j - kFrom] >> 15;   // 1 where v >= limit
+#pragma unroll
+    for (int j = kFrom; j < kTo; ++j) acc = __builtin_amdgcn_udot2(m[j - kFrom], C.dd[j], acc, false);
     return acc;
 }
 
@@ -784,7 +788,7 @@ struct Short16 {
     __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
         if (n >= 4) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; w[k] = ldu32(s + o); }
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k < n - 4 ? 4 * k : n - 4; w[k] = ldu32(s + o); }      // min(4 k, n - 4): one v_min, no mask register
         } else if (n) {
             w[0] = ldu32(s);
         }
@@ -792,7 +796,7 @@ struct Short16 {
     __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
         if (n >= 4) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; stu32(d + o, w[k]); }
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k < n - 4 ? 4 * k : n - 4; stu32(d + o, w[k]); }
         } else if (n) {
             if (n & 2u) { const uint16_t h = (uint16_t)w[0]; __builtin_memcpy(d, &h, 2); }
             if (n & 1u) d[n & 2u] = (uint8_t)(w[0] >> (8u * (n & 2u)));
@@ -821,7 +825,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (off < N[j]) {
-                const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
+                const uint32_t a = off < N[j] - 4 ? off : N[j] - 4, c = off + 4 < N[j] - 4 ? off + 4 : N[j] - 4;      // min(.., N - 4); N > 16
                 wa[j] = ldu32(sbase + S[j] + a);
                 wb[j] = ldu32(sbase + S[j] + c);
             }
@@ -829,7 +833,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (off < N[j]) {
-                const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
+                const uint32_t a = off < N[j] - 4 ? off : N[j] - 4, c = off + 4 < N[j] - 4 ? off + 4 : N[j] - 4;      // min(.., N - 4); N > 16
                 stu32(buf + D[j] + a, wa[j]);
                 stu32(buf + D[j] + c, wb[j]);
             }
@@ -841,7 +845,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
 __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t N, uint32_t lane) {
     if (N >= 4) {
         for (uint32_t off = 4 * lane; off < N; off += 256) {
-            const uint32_t o2 = off + 4 <= N ? off : N - 4;
+            const uint32_t o2 = off < N - 4 ? off : N - 4;
             stu32(d + o2, ldu32(s + o2));
         }
     } else if (lane < N) {
