@@ -788,7 +788,7 @@ struct Short16 {
     __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
         if (n >= 4) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k < n - 4 ? 4 * k : n - 4; w[k] = ldu32(s + o); }      // min(4 k, n - 4): one v_min, no mask register
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; w[k] = ldu32(s + o); }
         } else if (n) {
             w[0] = ldu32(s);
         }
@@ -796,7 +796,7 @@ struct Short16 {
     __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
         if (n >= 4) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k < n - 4 ? 4 * k : n - 4; stu32(d + o, w[k]); }
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; stu32(d + o, w[k]); }
         } else if (n) {
             if (n & 2u) { const uint16_t h = (uint16_t)w[0]; __builtin_memcpy(d, &h, 2); }
             if (n & 1u) d[n & 2u] = (uint8_t)(w[0] >> (8u * (n & 2u)));
@@ -825,7 +825,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (off < N[j]) {
-                const uint32_t a = off < N[j] - 4 ? off : N[j] - 4, c = off + 4 < N[j] - 4 ? off + 4 : N[j] - 4;      // min(.., N - 4); N > 16
+                const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
                 wa[j] = ldu32(sbase + S[j] + a);
                 wb[j] = ldu32(sbase + S[j] + c);
             }
@@ -833,7 +833,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (off < N[j]) {
-                const uint32_t a = off < N[j] - 4 ? off : N[j] - 4, c = off + 4 < N[j] - 4 ? off + 4 : N[j] - 4;      // min(.., N - 4); N > 16
+                const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
                 stu32(buf + D[j] + a, wa[j]);
                 stu32(buf + D[j] + c, wb[j]);
             }
@@ -845,7 +845,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
 __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t N, uint32_t lane) {
     if (N >= 4) {
         for (uint32_t off = 4 * lane; off < N; off += 256) {
-            const uint32_t o2 = off < N - 4 ? off : N - 4;
+            const uint32_t o2 = off + 4 <= N ? off : N - 4;
             stu32(d + o2, ldu32(s + o2));
         }
     } else if (lane < N) {
@@ -865,9 +865,10 @@ __device__ __forceinline__ void lz77_resolve_body(
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
     uint8_t* out, const uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // (measured: telling the compiler that the wave index is uniform -- readfirstlane -- moves the block's state and the batch loop
-    // into scalar registers, 879 -> 791 vector instructions, and makes the kernel 6 % SLOWER; per-batch scalar flags for the rare
-    // kinds of matches change nothing: profiles/round3/call_i_stdout_summary.txt)
+    // (measured, profiles/round3: fewer instructions do not make this kernel faster -- telling the compiler that the wave index is
+    // uniform (readfirstlane: the block's state and the batch loop in scalar registers, 879 -> 791 vector instructions) costs 6 %,
+    // copy offsets as min(4 k, n - 4) instead of compare + select (772 instructions, 15 instead of 73 s_nop) cost 3.5 %, per-batch
+    // scalar flags for the rare kinds of matches change nothing)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kResThreads / 64) + wv;
     if (kOwn32) {
