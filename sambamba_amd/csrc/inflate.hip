@@ -342,7 +342,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint8_t* 
 // that are full.  gfx9 counts loads and stores in the same in-order vmcnt, so the wait in front of the ring service
 // would otherwise also wait for token stores issued moments before -- a store round trip of stall in every iteration;
 // this way every VMEM operation of an iteration is issued at its top and has a whole iteration to complete.
-template <int kDepth>
+template <int kDepth, bool kStream>
 struct Emitter {
     uint8_t* lit;         // 64-byte aligned literal stream of this block
     uint32_t* ent;        // 64-byte aligned entry stream of this block
@@ -354,7 +354,12 @@ struct Emitter {
     uint32_t lq_n, eq_n;  // parked groups
     uint32_t lq_at, eq_at;    // byte offset / entry index of the oldest parked group
     uint32_t n_lit, n_ent, run;
-    __device__ __forceinline__ static void store16(void* p, u32x4 v) { *(u32x4*)p = v; }
+    // kStream: the token stores bypass the caches' allocation (nontemporal): a 16-byte store into a line L2 does not hold would
+    // otherwise fetch the line first
+    __device__ __forceinline__ static void store16(void* p, u32x4 v) {
+        if (kStream) __builtin_nontemporal_store(v, (u32x4*)p);
+        else *(u32x4*)p = v;
+    }
     __device__ __forceinline__ void init(uint8_t* l, uint32_t* e) {
         lit = l; ent = e; n_lit = n_ent = run = 0;
         const u32x4 z = {0, 0, 0, 0};
@@ -473,7 +478,7 @@ struct Emitter {
 // two small tables shared by the workgroup in LDS (29 x u16, 30 x u32: different entries lie in different banks, equal ones
 // are broadcast) instead of ~12 VALU instructions of arithmetic each, and the canonical decode skips the pairs of code
 // lengths no lane's code uses (decode_len).
-template <int kDepth>
+template <int kDepth, bool kStream>
 __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
     const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     uint32_t opos = 0;          // bytes produced by matches (literals and stored bytes are counted by the emitter)
     uint32_t err = INF_OK;
 
-    Emitter<kDepth> em;   // (lanes past the last block stay inactive and never emit)
+    Emitter<kDepth, kStream> em;   // (lanes past the last block stay inactive and never emit)
     em.init(lit_stream + lit_off(oo, block0 + b), ent_stream + ent_off(oo, block0 + b));
     BitReader br;
     br.init(in, (uint32_t*)(lds + kRingOff));
@@ -1077,13 +1082,15 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         // 16-byte groups per token-store burst: 1 (default) is the fastest -- no register FIFO to shift -- and writes partial
         // sectors (WRITE_SIZE 2.7 x the token bytes); 2 and 4 trade instructions for write traffic (1.5 x, 1.2 x): DESIGN.md K1a
         static const int burst = [] { const char* e = getenv("SBX_K1A_BURST"); return e ? atoi(e) : 1; }();
-#define SBX_K1A_LAUNCH(DEPTH)                                                                                                            \
-    hipLaunchKernelGGL((k_huffman_decode<DEPTH>), grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, n_blocks, \
-                       block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes)
+#define SBX_K1A_LAUNCH(DEPTH, STREAM)                                                                                                    \
+    hipLaunchKernelGGL((k_huffman_decode<DEPTH, STREAM>), grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, \
+                       n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes)
         switch (burst) {
-            case 4: SBX_K1A_LAUNCH(4); break;
-            case 2: SBX_K1A_LAUNCH(2); break;
-            default: SBX_K1A_LAUNCH(1); break;
+            case 4: SBX_K1A_LAUNCH(4, false); break;
+            case 2: SBX_K1A_LAUNCH(2, false); break;
+            case 21: SBX_K1A_LAUNCH(1, true); break;
+            case 22: SBX_K1A_LAUNCH(2, true); break;
+            default: SBX_K1A_LAUNCH(1, false); break;
         }
 #undef SBX_K1A_LAUNCH
         SBX_HIP(hipGetLastError());
