@@ -673,6 +673,11 @@ def main():
         if dom in pmc:
             roof.update({"traffic": pmc[dom]["traffic"], "traffic_unit": "bytes per launch", "traffic_source": pmc[dom]["source"],
                          "traffic_over_algorithmic": per_kernel[dom]["traffic_over_algorithmic"]})
+            if dom == "huffman_decode" and os.environ.get("SBX_K1A_BURST", "1") == "1":
+                roof["traffic_note"] = ("K1a is issue / latency bound (the memory system moves 1.5 of its 8 TB/s under it); its default writes the "
+                                        "token streams in 16-byte stores, which costs 28.6 GB of partial-sector traffic per launch and saves "
+                                        "1.7 ms; SBX_K1A_BURST=22 (32-byte nontemporal bursts): 29.2 ms, 14.2 GB = 1.11 x algorithmic "
+                                        "(DESIGN.md section 3, K1a; profiles/round3/call_l_stdout_summary.txt)")
         # the fused-path figure of SURVEY.md 8(d): compressed bytes in + counters out over the whole pass
         fused = (comp + cnt) / (sum(kern.values()) * 1e-3) / 1e9 if sum(kern.values()) > 0 else 0.0
         cpu = None
