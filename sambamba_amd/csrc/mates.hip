@@ -105,9 +105,28 @@ __global__ __launch_bounds__(kMateThreads) void k_find_mates(const uint8_t* __re
     const int32_t ref = rec_ref[i];
     const uint32_t ref_tag = (uint32_t)ref & 0x7FFFFFFFu, h32 = (uint32_t)h;
     bool done = false;
-    for (uint32_t k = threadIdx.x + 1; k < kFindWin; ++k) {
+    uint32_t k = threadIdx.x + 1;
+    // four window entries per step: twelve LDS reads in flight and one wait instead of three dependent round trips per entry (the
+    // scan is a few hundred entries long at 300x and nearly all of it is "different hash, next"); the entries are still taken in
+    // order -- `nv` of the four lie before the first one that ends the scan, only those can link
+    for (; !done && k + 4 <= kFindWin; k += 4) {
+        uint32_t rj[4], hj[4];
+        int32_t pj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { rj[q] = s_ref[k + q]; pj[q] = s_pos[k + q]; hj[q] = s_h[k + q]; }
+        uint32_t nv = 4, hits = 0;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+            if ((rj[q] & 0x7FFFFFFFu) != ref_tag || pj[q] >= a.end) nv = (uint32_t)q;      // coordinate sorted: nothing further can overlap A
+            if (hj[q] == h32 && !(rj[q] >> 31)) hits |= 1u << q;
+        }
+        hits &= (1u << nv) - 1u;
+        for (; hits; hits &= hits - 1u) link_if_mates(U, desc, hash, a, h, i, i0 + k + (uint32_t)__builtin_ctz(hits), mate, n_partners);
+        if (nv < 4u) done = true;
+    }
+    for (; !done && k < kFindWin; ++k) {
         const uint32_t rj = s_ref[k];
-        if ((rj & 0x7FFFFFFFu) != ref_tag || s_pos[k] >= a.end) { done = true; break; }     // coordinate sorted: nothing further can overlap A
+        if ((rj & 0x7FFFFFFFu) != ref_tag || s_pos[k] >= a.end) { done = true; break; }
         if (s_h[k] == h32 && !(rj >> 31)) link_if_mates(U, desc, hash, a, h, i, i0 + k, mate, n_partners);
     }
     if (!done)
