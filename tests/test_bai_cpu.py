@@ -1,6 +1,7 @@
 """The BAI builder (csrc/bai_writer.hpp: the restatement of IndexBuilder, BioD/bio/std/hts/bam/bai/indexing.d:52-346, and the
 virtual-offset rule of sbx_build_index) against the index files the REFERENCE's own test-suite ships next to its BAMs
-(tests/golden/*.bam.bai, written by `sambamba index`).  The builder is compiled for the host and fed by a zlib reader
+(tests/golden/*.bam.bai: checked into the reference next to the BAMs; which indexer wrote them is not recorded -- IndexBuilder
+and samtools produce the same bytes for these files up to the order of the bins).  The builder is compiled for the host and fed by a zlib reader
 (tests/native/bai_host.cpp); on the device the same two classes get their record fields from K2 (tests/test_gpu_writer.py).
 Bins, chunks, linear index, the metadata pseudo-bin and the no-coordinate trailer must be equal; the ORDER of the bins of a
 reference is unspecified in the reference (it iterates a D associative array), so files are compared as structures, and byte

@@ -200,7 +200,7 @@ def test_generator_with_the_device_codec_writes_the_same_reads(tmp_path):
 
 @pytest.mark.parametrize("name", ["issue225", "issue_193", "issue_204", "mate_overlaps_1_3M_4M"])
 def test_device_index_equals_the_reference_index(tmp_path, name):
-    """sbx_build_index on the reference's fixtures against the .bai files `sambamba index` wrote for them (the host half of
+    """sbx_build_index on the reference's fixtures against the .bai files the reference ships for them (the host half of
     the same comparison: tests/test_bai_cpu.py): equal as structures, byte-identical where the reference wrote ascending bins."""
     from tests.test_bai_cpu import parse_bai
     from tests.util import GOLDEN
