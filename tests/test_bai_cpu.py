@@ -74,3 +74,93 @@ def test_three_of_the_fixtures_are_byte_identical(bai_host, tmp_path):
         subprocess.check_call([bai_host, os.path.join(GOLDEN, name + ".bam"), out])
         same += open(out, "rb").read() == open(os.path.join(GOLDEN, name + ".bam.bai"), "rb").read()
     assert same >= 3
+
+
+# ---- virtual offsets at block boundaries (VoffCursor): hand-made files --------------------------------------------------------
+def _records(n, ref=0, start=100, step=50):
+    import random
+    from tests import bamgen as bg
+    rng = random.Random(11)
+    return [bg.make_record(ref, start + step * i, "40M", "".join(rng.choice("ACGT") for _ in range(40)), 30, name="r%d" % i)
+            for i in range(n)]
+
+
+def _blocks(path):
+    b = open(path, "rb").read()
+    out, p = [], 0
+    while p + 18 <= len(b):
+        bsize = struct.unpack_from("<H", b, p + 16)[0] + 1
+        out.append((p, struct.unpack_from("<I", b, p + bsize - 4)[0]))
+        p += bsize
+    return out, len(b)
+
+
+def test_header_that_fills_its_block_and_end_of_file_offsets(bai_host, tmp_path):
+    """Block 0 holds exactly the header: the first read starts at offset 0 of block 1; the end of the last read is offset 0 of the
+    EOF block (not the end of the file)."""
+    from tests import bamgen as bg
+    refs = [("k1", 100000)]
+    recs = _records(300)
+    probe = bg.write_bam(str(tmp_path / "probe.bam"), refs, recs, write_index=False)
+    bam = str(tmp_path / "a.bam")
+    bg.write_bam(bam, refs, recs, cuts=[probe["header_len"]], block_size=4000, write_index=False)
+    out = str(tmp_path / "a.bai")
+    subprocess.check_call([bai_host, bam, out])
+    refs_b, tail = parse_bai(out)
+    blocks, size = _blocks(bam)
+    assert blocks[0][1] == probe["header_len"] and blocks[-1][1] == 0           # header block, EOF block
+    bins, lin, _ = refs_b[0]
+    meta = bins.pop(37450)
+    assert meta[0] == (blocks[1][0] << 16, blocks[-1][0] << 16)                   # first read .. end of the last read
+    assert min(c[0] for ch in bins.values() for c in ch) == blocks[1][0] << 16
+    assert max(c[1] for ch in bins.values() for c in ch) == blocks[-1][0] << 16
+    assert lin[0] == blocks[1][0] << 16
+
+
+def test_file_without_eof_block_and_empty_block_in_the_middle(bai_host, tmp_path):
+    """Without an EOF block the end of the last read is the end of the file; an empty block in the middle of the data is where
+    the read in front of it ends (the block that starts there), while the read behind it starts in the next block that holds
+    bytes."""
+    from tests import bamgen as bg
+    refs = [("k1", 100000)]
+    recs = _records(200)
+    info = bg.write_bam(str(tmp_path / "p.bam"), refs, recs, write_index=False)
+    cut = info["records"][100][3]                                                  # block boundary in front of read 100
+    bam = str(tmp_path / "b.bam")
+    bg.write_bam(bam, refs, recs, cuts=[cut], block_size=3000, write_index=False)
+    raw = open(bam, "rb").read()
+    blocks, size = _blocks(bam)
+    assert blocks[-1][1] == 0
+    # the block that starts at `cut`: the first one whose inflated start equals cut
+    u, at = 0, None
+    for i, (coff, isz) in enumerate(blocks):
+        if u == cut:
+            at = i
+            break
+        u += isz
+    assert at is not None
+    eof = raw[blocks[-1][0]:]
+    mod = raw[:blocks[at][0]] + eof + raw[blocks[at][0]:blocks[-1][0]]            # empty block inserted at the cut, EOF block dropped
+    open(bam, "wb").write(mod)
+    out = str(tmp_path / "b.bai")
+    subprocess.check_call([bai_host, bam, out])
+    refs_b, tail = parse_bai(out)
+    blocks2, size2 = _blocks(bam)
+    assert blocks2[at][1] == 0 and blocks2[-1][1] != 0
+    bins, lin, _ = refs_b[0]
+    meta = bins.pop(37450)
+    assert meta[0][1] == size2 << 16                                               # no EOF block: the file's end
+    assert meta[1] == (200, 0)
+    # all reads share one bin here: one chunk from the first read to the end (chunks are only cut when the bin changes)
+    chunks = [c for ch in bins.values() for c in ch]
+    assert min(c[0] for c in chunks) >> 16 == blocks2[0][0] and max(c[1] for c in chunks) == size2 << 16
+    # and the same file through a reader that needs the index: the oracle fetches reads on both sides of the empty block
+    os.replace(out, bam + ".bai")
+    from tests.util import run_oracle
+    whole = run_oracle(["base", bam])
+    pos100 = info["records"][100][1]
+    part = run_oracle(["base", "-L", "k1:%d-%d" % (pos100 - 200, pos100 + 200), bam])
+    rows = {ln.split(b"\t")[1]: ln for ln in whole.splitlines()[1:]}
+    for ln in part.splitlines()[1:]:
+        assert rows[ln.split(b"\t")[1]] == ln
+    assert len(part.splitlines()) > 100
