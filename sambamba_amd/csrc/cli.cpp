@@ -855,7 +855,9 @@ int depth_main(int argc, char** argv) {
         // (sbx_run_interval), device -> text (sbx_stream_base_rows) -- on two contexts that alternate.  PCIe is full duplex:
         // the upload of slice k + 1 and the text of slice k - 1 travel while slice k is computed.
         if (o.mode == "base" && !o.has_regions && o.min_cov > 0 && bp.device_format_applies() && paths.size() == 1 &&
-            !getenv("SBX_NO_PIPELINE") && (hi.compressed_bytes >= (256u << 20) || getenv("SBX_FORCE_PIPELINE"))) {
+            !getenv("SBX_NO_PIPELINE") && ((hi.compressed_bytes >= (256u << 20) && g_done_fd >= 0) || getenv("SBX_FORCE_PIPELINE"))) {
+            // (as ONE process -- SBX_NO_DETACH=1 -- the two contexts of the pipeline cost more at exit than their overlap saves:
+            //  0.86 s against 0.75 s for config 2; the one-pass form below is used then)
             struct Slice { uint32_t ref; uint64_t beg, end, print_end; };
             std::vector<Slice> sl;
             {
