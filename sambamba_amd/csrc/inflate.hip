@@ -40,6 +40,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "inflate2_core.hpp"
 #include "kernels.hpp"
 
 namespace sbx {
@@ -55,7 +56,11 @@ constexpr int kRingOff = 324;                // u32[8]   input ring (32 bytes of
 constexpr int kClLenOff = 32;                // u8[19]   code-length code lengths while a dynamic header is parsed (in the
                                              //          literal area, which is rebuilt afterwards; its symbols sit at 0..18)
 constexpr int kLenTabBytes = 64, kDistTabBytes = 128;   // symbol -> base / extra bits, shared by the workgroup
-constexpr int kLensScratch = 320;            // bytes of global scratch per lane: code lengths being built
+constexpr int kLensScratch = 320;            // bytes of global scratch the general kernel uses per block: code lengths being built
+constexpr int kScratchStride = inf2::kScratchBytes;     // scratch per block (the fast kernel's layout, inflate2_core.hpp)
+constexpr int kGeneralLensOff = inf2::kScratchTabs;     // where the general kernel keeps its code lengths inside it (a block it decodes has no
+                                                        // translation tables; the info words in front stay intact)
+static_assert(kGeneralLensOff + kLensScratch <= kScratchStride, "scratch layout");
 
 enum : uint32_t {
     INF_OK = 0,
@@ -483,15 +488,18 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
     const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
     const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
     uint8_t* __restrict__ lit_stream, uint32_t* __restrict__ ent_stream, uint32_t* __restrict__ n_entries,
-    uint8_t* __restrict__ lens_scratch, uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes) {
+    uint8_t* __restrict__ lens_scratch, uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes, uint32_t only_flagged) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // Lanes past the last block shadow block n_blocks-1 but stay inactive: every lane of the wave
     // must take part in the wave-synchronous input service.
+    // only_flagged: this launch follows the fast kernel (k_huffman_decode2) and decodes the blocks that one handed over
+    // (status kNeedsGeneral); a wavefront none of whose blocks is flagged ends here.
     const uint32_t b_raw = blockIdx.x * kInfThreads + threadIdx.x;
-    const bool live = b_raw < n_blocks;
-    const uint32_t b = live ? b_raw : n_blocks - 1;
+    const uint32_t b = b_raw < n_blocks ? b_raw : n_blocks - 1;
+    const bool live = b_raw < n_blocks && (only_flagged == 0u || status[b] == inf2::kNeedsGeneral);
+    if (only_flagged != 0u && !__any(live)) return;
     uint8_t* lds = smem + threadIdx.x * kLaneLds;
-    uint8_t* lens = lens_scratch + (size_t)b * kLensScratch;
+    uint8_t* lens = lens_scratch + (size_t)b * kScratchStride + kGeneralLensOff;
     DistSyms DS;
     DS.clear();
     // RFC 1951 3.2.5 as tables behind the lanes' areas: length symbol 257 + i -> base | extra bits << 9,
@@ -750,6 +758,97 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
         unsigned long long t = live ? (unsigned long long)em.n_lit + 4ull * em.n_ent : 0ull;
         for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
         if (threadIdx.x == 0) atomicAdd(tok_bytes + (blockIdx.x & 63u), t);
+    }
+}
+
+
+// ---- K1a, round 4: the fast kernel -------------------------------------------------------------------------------------
+// One lane per BGZF block, the lane program of inflate2_core.hpp (literal ranks instead of literal bytes, windows instead of a
+// bit buffer, build state in LDS): 164 bytes of LDS per lane and <= 128 VGPRs, so that 15 wavefronts share a CU (round 3's
+// kernel: 7) and the 3,379 wavefronts of a chromosome-sized file are resident at once.  Blocks it does not decode are flagged
+// kNeedsGeneral and decoded by k_huffman_decode in a second launch.
+constexpr int kInf2Threads = 64;
+__global__ __launch_bounds__(kInf2Threads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_huffman_decode2(
+    const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
+    const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
+    uint8_t* __restrict__ lit_stream, uint32_t* __restrict__ ent_stream, uint32_t* __restrict__ n_entries,
+    uint8_t* __restrict__ scratch, uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b_raw = blockIdx.x * kInf2Threads + lane;
+    const bool live = b_raw < n_blocks;
+    const uint32_t b = live ? b_raw : n_blocks - 1;
+    uint16_t* const len_tab = (uint16_t*)(smem + inf2::kWaveLds);
+    uint32_t* const dist_tab = (uint32_t*)(smem + inf2::kWaveLds + inf2::kLenTabBytes);
+    if (lane < 32u) inf2::rfc_tables_entry(lane, &len_tab[lane], &dist_tab[lane]);
+    __syncthreads();
+    const uint64_t oo = out_off[b];
+    inf2::LaneIo io;
+    io.in = comp + comp_off[b];
+    io.in_bits = comp_len[b] * 8u;
+    io.osize = isize[b];
+    io.lit = lit_stream + lit_off(oo, block0 + b);
+    io.ent = ent_stream + ent_off(oo, block0 + b);
+    io.scratch = scratch + (size_t)b * kScratchStride;
+    io.live = live;
+    inf2::Lane L;
+    const inf2::LaneResult R = L.run(io, smem, lane, len_tab, dist_tab);
+    if (live) {
+        status[b] = R.status;
+        n_entries[b] = R.n_ent;
+    }
+    if (tok_bytes) {
+        unsigned long long t = live && R.status == 0u ? (unsigned long long)R.n_lit + 4ull * R.n_ent : 0ull;
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0) atomicAdd(tok_bytes + (blockIdx.x & 63u), t);
+    }
+}
+
+// Literal ranks -> literal bytes, in place in the literal stream, between K1a and K1b: one wavefront per BGZF block, the block's
+// (<= kMaxSeg) tables of 256 bytes in LDS -- a table spans exactly the 64 banks, so the 64 lanes' byte lookups never conflict --
+// every lane translates 16-byte groups.  A group that straddles two deflate blocks picks the table per byte.
+__global__ __launch_bounds__(64) void k_translate_literals(
+    uint8_t* __restrict__ lit_stream, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
+    const uint8_t* __restrict__ scratch, const uint32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[inf2::kMaxSeg * 256];
+    __shared__ uint32_t seg_start[inf2::kMaxSeg + 1];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (status[b] != INF_OK) return;
+    const uint8_t* sc = scratch + (size_t)b * kScratchStride;
+    const uint32_t* info = (const uint32_t*)(sc + inf2::kScratchInfo);
+    const uint32_t n_seg = info[0], n_lit = info[1];
+    if (n_seg == 0u || n_lit == 0u) return;
+    for (uint32_t s = 0; s < n_seg; ++s) ((uint32_t*)tabs)[64u * s + lane] = ((const uint32_t*)(sc + inf2::kScratchTabs))[64u * s + lane];
+    if (lane <= n_seg) seg_start[lane] = lane < n_seg ? info[2 + lane] : n_lit;
+    __syncthreads();
+    uint8_t* lit = lit_stream + lit_off(out_off[b], block0 + b);
+    const uint32_t n_grp = (n_lit + 15u) >> 4;
+    for (uint32_t g = lane; g < n_grp; g += 64) {
+        u32x4 v = *(const u32x4*)(lit + 16u * g);
+        const uint32_t p0 = 16u * g;
+        // segment of the group's first byte (segments are few: a linear search)
+        uint32_t s0 = 0;
+        while (s0 + 1u < n_seg && seg_start[s0 + 1u] <= p0) ++s0;
+        const uint32_t next = seg_start[s0 + 1u];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (next >= p0 + 16u || s0 + 1u >= n_seg) {
+            const uint8_t* t = tabs + 256u * s0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t x = w[k];
+                w[k] = (uint32_t)t[x & 0xFFu] | (uint32_t)t[(x >> 8) & 0xFFu] << 8 | (uint32_t)t[(x >> 16) & 0xFFu] << 16 | (uint32_t)t[x >> 24] << 24;
+            }
+        } else {
+            for (uint32_t i = 0; i < 16; ++i) {
+                const uint32_t p = p0 + i;
+                uint32_t sg = s0;
+                while (sg + 1u < n_seg && seg_start[sg + 1u] <= p) ++sg;
+                const uint32_t x = (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
+                const uint32_t y = tabs[256u * sg + x];
+                w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8u * (i & 3u)))) | y << (8u * (i & 3u));
+            }
+        }
+        *(u32x4*)(lit + 16u * g) = u32x4{w[0], w[1], w[2], w[3]};
     }
 }
 
@@ -1065,7 +1164,7 @@ __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 
 
 }  // namespace
 
-size_t inflate_scratch_bytes(uint32_t n_blocks) { return (size_t)n_blocks * kLensScratch; }
+size_t inflate_scratch_bytes(uint32_t n_blocks) { return (size_t)n_blocks * kScratchStride + 64; }
 
 // sizes of the two token streams for n_blocks blocks producing `total` output bytes
 size_t inflate_lit_bytes(uint64_t total, uint32_t n_blocks) { return (size_t)(lit_off(total, n_blocks) + 65536 + 64); }
@@ -1076,15 +1175,28 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
                          uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
                          uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid, unsigned long long* d_tok_bytes) {
     if (n_blocks == 0) { if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream)); return; }
+    // SBX_K1A=1: round 3's kernel alone (the general kernel: every kind of block); default: the fast kernel, then the general one for
+    // the blocks the fast one flagged (a wavefront without a flagged block ends at once), then the literal translation
+    static const int k1a = [] { const char* e = getenv("SBX_K1A"); return e ? atoi(e) : 2; }();
+    if (k1a != 1) {
+        dim3 grid((n_blocks + kInf2Threads - 1) / kInf2Threads), block(kInf2Threads);
+        // (SBX_K1A_LDS_PAD: extra LDS per workgroup -- an occupancy experiment)
+        static const size_t pad = [] { const char* e = getenv("SBX_K1A_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
+        const size_t lds = (size_t)inf2::kWaveLds + inf2::kLenTabBytes + inf2::kDistTabBytes + pad;
+        hipLaunchKernelGGL(k_huffman_decode2, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, n_blocks, block0,
+                           d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes);
+        SBX_HIP(hipGetLastError());
+    }
     {
         dim3 grid((n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
         const size_t lds = (size_t)kInfThreads * kLaneLds + kLenTabBytes + kDistTabBytes;
+        const uint32_t only_flagged = k1a != 1 ? 1u : 0u;
         // 16-byte groups per token-store burst: 1 (default) is the fastest -- no register FIFO to shift -- and writes partial
         // sectors (WRITE_SIZE 2.7 x the token bytes); 2 and 4 trade instructions for write traffic (1.5 x, 1.2 x): DESIGN.md K1a
         static const int burst = [] { const char* e = getenv("SBX_K1A_BURST"); return e ? atoi(e) : 1; }();
 #define SBX_K1A_LAUNCH(DEPTH, STREAM)                                                                                                    \
     hipLaunchKernelGGL((k_huffman_decode<DEPTH, STREAM>), grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, \
-                       n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes)
+                       n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes, only_flagged)
         switch (burst) {
             case 4: SBX_K1A_LAUNCH(4, false); break;
             case 2: SBX_K1A_LAUNCH(2, false); break;
@@ -1093,6 +1205,10 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
             default: SBX_K1A_LAUNCH(1, false); break;
         }
 #undef SBX_K1A_LAUNCH
+        SBX_HIP(hipGetLastError());
+    }
+    if (k1a != 1) {
+        hipLaunchKernelGGL(k_translate_literals, dim3(n_blocks), dim3(64), 0, stream, d_lit, d_out_off, n_blocks, block0, d_scratch, d_status);
         SBX_HIP(hipGetLastError());
     }
     if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream));
