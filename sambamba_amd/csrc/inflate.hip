@@ -1170,33 +1170,48 @@ size_t inflate_scratch_bytes(uint32_t n_blocks) { return (size_t)n_blocks * kScr
 size_t inflate_lit_bytes(uint64_t total, uint32_t n_blocks) { return (size_t)(lit_off(total, n_blocks) + 65536 + 64); }
 size_t inflate_ent_words(uint64_t total, uint32_t n_blocks) { return (size_t)(ent_off(total, n_blocks) + 65536 / 3 + 65536 / 255 + 64); }   // (slack covers the padded last slice)
 
-void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
-                         const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
-                         uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
-                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid, unsigned long long* d_tok_bytes) {
-    if (n_blocks == 0) { if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream)); return; }
+namespace {
+
+struct InflateArgs {
+    const uint8_t* comp; const uint64_t* comp_off; const uint32_t* comp_len; const uint32_t* isize; const uint64_t* out_off; uint8_t* out;
+    uint32_t n_blocks, block0;
+    uint8_t* scratch; uint8_t* lit; uint32_t* ent; uint32_t* nent; uint32_t* status; unsigned long long* tok;
+    // the blocks [first, first + n) of these arrays
+    InflateArgs slice(uint32_t first, uint32_t n) const {
+        InflateArgs a = *this;
+        a.comp_off += first; a.comp_len += first; a.isize += first; a.out_off += first; a.nent += first; a.status += first;
+        a.scratch += (size_t)first * kScratchStride;
+        a.block0 += first;
+        a.n_blocks = n;
+        return a;
+    }
+};
+
+// K1a of a range of blocks: the fast kernel, the general one for the blocks that one flagged, the literal translation
+void launch_k1a(const InflateArgs& a, hipStream_t stream) {
+    if (a.n_blocks == 0) return;
     // SBX_K1A=1: round 3's kernel alone (the general kernel: every kind of block); default: the fast kernel, then the general one for
     // the blocks the fast one flagged (a wavefront without a flagged block ends at once), then the literal translation
     static const int k1a = [] { const char* e = getenv("SBX_K1A"); return e ? atoi(e) : 2; }();
     if (k1a != 1) {
-        dim3 grid((n_blocks + kInf2Threads - 1) / kInf2Threads), block(kInf2Threads);
+        dim3 grid((a.n_blocks + kInf2Threads - 1) / kInf2Threads), block(kInf2Threads);
         // (SBX_K1A_LDS_PAD: extra LDS per workgroup -- an occupancy experiment)
         static const size_t pad = [] { const char* e = getenv("SBX_K1A_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
         const size_t lds = (size_t)inf2::kWaveLds + inf2::kLenTabBytes + inf2::kDistTabBytes + pad;
-        hipLaunchKernelGGL(k_huffman_decode2, grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, n_blocks, block0,
-                           d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes);
+        hipLaunchKernelGGL(k_huffman_decode2, grid, block, lds, stream, a.comp, a.comp_off, a.comp_len, a.isize, a.out_off, a.n_blocks, a.block0,
+                           a.lit, a.ent, a.nent, a.scratch, a.status, a.tok);
         SBX_HIP(hipGetLastError());
     }
     {
-        dim3 grid((n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
+        dim3 grid((a.n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
         const size_t lds = (size_t)kInfThreads * kLaneLds + kLenTabBytes + kDistTabBytes;
         const uint32_t only_flagged = k1a != 1 ? 1u : 0u;
         // 16-byte groups per token-store burst: 1 (default) is the fastest -- no register FIFO to shift -- and writes partial
         // sectors (WRITE_SIZE 2.7 x the token bytes); 2 and 4 trade instructions for write traffic (1.5 x, 1.2 x): DESIGN.md K1a
         static const int burst = [] { const char* e = getenv("SBX_K1A_BURST"); return e ? atoi(e) : 1; }();
-#define SBX_K1A_LAUNCH(DEPTH, STREAM)                                                                                                    \
-    hipLaunchKernelGGL((k_huffman_decode<DEPTH, STREAM>), grid, block, lds, stream, d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, \
-                       n_blocks, block0, d_lit, d_ent, d_nent, d_scratch, d_status, d_tok_bytes, only_flagged)
+#define SBX_K1A_LAUNCH(DEPTH, STREAM)                                                                                                      \
+    hipLaunchKernelGGL((k_huffman_decode<DEPTH, STREAM>), grid, block, lds, stream, a.comp, a.comp_off, a.comp_len, a.isize, a.out_off, \
+                       a.n_blocks, a.block0, a.lit, a.ent, a.nent, a.scratch, a.status, a.tok, only_flagged)
         switch (burst) {
             case 4: SBX_K1A_LAUNCH(4, false); break;
             case 2: SBX_K1A_LAUNCH(2, false); break;
@@ -1208,23 +1223,39 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
         SBX_HIP(hipGetLastError());
     }
     if (k1a != 1) {
-        hipLaunchKernelGGL(k_translate_literals, dim3(n_blocks), dim3(64), 0, stream, d_lit, d_out_off, n_blocks, block0, d_scratch, d_status);
+        hipLaunchKernelGGL(k_translate_literals, dim3(a.n_blocks), dim3(64), 0, stream, a.lit, a.out_off, a.n_blocks, a.block0, a.scratch, a.status);
         SBX_HIP(hipGetLastError());
     }
+}
+
+void launch_k1b(const InflateArgs& a, hipStream_t stream) {
+    if (a.n_blocks == 0) return;
+    const uint32_t per = kResThreads / 64;
+    dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
+    const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
+    static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 0)
+        hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
+                           a.n_blocks, a.block0, a.out, a.status);
+    else
+        hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, a.lit, a.ent, a.nent, a.out_off,
+                           a.isize, a.n_blocks, a.block0, a.out, a.status);
+    SBX_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
+                         const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
+                         uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
+                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid, unsigned long long* d_tok_bytes) {
+    if (n_blocks == 0) { if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream)); return; }
+    const InflateArgs all{d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, d_out, n_blocks, block0, d_scratch, d_lit, d_ent, d_nent, d_status, d_tok_bytes};
+    // (measured and dropped, profiles/round4/README.md: K1a of the second half of the blocks on a second stream next to K1b of the first half --
+    // the two kernels do not fill each other's issue slots, the inflate takes 51-54 ms instead of 48)
+    launch_k1a(all, stream);
     if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream));
-    {
-        const uint32_t per = kResThreads / 64;
-        dim3 grid((n_blocks + per - 1) / per), block(kResThreads);
-        const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
-        static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 1; }();
-        if (variant == 0)
-            hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, d_lit, d_ent, d_nent, d_out_off, d_isize,
-                               n_blocks, block0, d_out, d_status);
-        else
-            hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, d_lit, d_ent, d_nent, d_out_off,
-                               d_isize, n_blocks, block0, d_out, d_status);
-        SBX_HIP(hipGetLastError());
-    }
+    launch_k1b(all, stream);
 }
 
 const char* inflate_status_string(uint32_t s) {
