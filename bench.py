@@ -242,11 +242,11 @@ def parity_text(d, bam, ref_name, ref, beg, end, extra_args):
 
 
 def cli_e2e(bam, mode_args, reads):
-    """The product CLI end to end: file (page cache) -> device -> text on /dev/null, wall clock of the command.
-    The CLI does its work in a child process and returns when the output is complete; the teardown of the device context is
-    left to that child.  Three runs a few seconds apart (a process started right behind a teardown waits for the driver to
-    scrub the freed memory); the best is reported, all are listed, with the CLI's own phase clock of the best one.  Two more
-    runs with SBX_NO_DETACH=1 time the same command as ONE process, teardown included (`single_process_seconds`)."""
+    """The product CLI end to end: file (page cache) -> device -> text on /dev/null, wall clock of the command as ONE process,
+    teardown of the device context included (`seconds`: the like-for-like figure next to cpu_baseline).  Three runs, the best is
+    reported, all are listed, with the CLI's own phase clock of the best one.  Two more runs with SBX_DETACH=1 -- the work in a
+    child process, the command returns when the output is complete and leaves the teardown to the child -- are a side field
+    (`detached_seconds`); a few seconds apart: a process started right behind a detached teardown waits for the driver."""
     from sambamba_amd import cli_path
     cmd = [cli_path()] + mode_args + ["-o", "/dev/null", bam]
 
@@ -259,26 +259,25 @@ def cli_e2e(bam, mode_args, reads):
         return dt, [ln for ln in r.stderr.decode().splitlines() if ln.startswith("[sbx")]
 
     try:
-        runs, single = [], []
+        runs, det = [], []
         for k in range(3):
-            if k:
-                time.sleep(3.0)
             runs.append(once(dict(os.environ, SBX_TIMING="1")))
         for k in range(2):
             time.sleep(3.0)
-            single.append(once(dict(os.environ, SBX_TIMING="1", SBX_NO_DETACH="1")))
+            det.append(once(dict(os.environ, SBX_TIMING="1", SBX_DETACH="1")))
+        time.sleep(2.0)
     except RuntimeError as e:
         return {"error": str(e)}
     best = min(runs, key=lambda x: x[0])
-    one = min(single, key=lambda x: x[0])
+    d = min(det, key=lambda x: x[0])
     return {"seconds": round(best[0], 3), "Mreads_per_s": round(reads / best[0] / 1e6, 2), "all_seconds": [round(x[0], 3) for x in runs],
-            "single_process_seconds": round(one[0], 3), "single_process_Mreads_per_s": round(reads / one[0] / 1e6, 2),
-            "single_process_all_seconds": [round(x[0], 3) for x in single],
+            "detached_seconds": round(d[0], 3), "detached_Mreads_per_s": round(reads / d[0] / 1e6, 2),
+            "detached_all_seconds": [round(x[0], 3) for x in det],
             "phases": best[1][-4:],
-            "what": "sbx-depth %s -o /dev/null <bam> (file in page cache; process start, open, pinned H2D, device pipeline, device text "
-                    "formatting, pinned D2H, write -- slices through the three stages concurrently), best of 3; `seconds` = until the "
-                    "command returns with the output complete (device teardown left to the detached worker process), "
-                    "`single_process_seconds` = the same with SBX_NO_DETACH=1, teardown included" % " ".join(mode_args)}
+            "what": "sbx-depth %s -o /dev/null <bam> (file in page cache; process start, open, pinned H2D, device kernels, device text "
+                    "formatting, pinned D2H, write, teardown of the device context) as ONE process, best of 3; `detached_seconds` = the "
+                    "same with SBX_DETACH=1: slices through upload / kernels / text concurrently in a child process, the command "
+                    "returns with the output complete and the child tears the context down" % " ".join(mode_args)}
 
 
 class Job:

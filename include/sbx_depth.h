@@ -143,8 +143,9 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
 /* The write side of the same seam: bgzfCompress (BioD/bio/core/bgzf/compress.d:34-103) for a whole buffer at once.  in[0, n) is
  * cut into 0xFF00-byte pieces (bgzf/constants.d:33), every piece becomes one BGZF block -- 18-byte header with the BC
  * subfield, raw deflate, CRC32, ISIZE -- compressed on the device (one lane per block; fixed Huffman code + greedy LZ77:
- * any RFC 1951 stream is valid for every BGZF reader, the reference's included; level 0 = stored blocks, any other level
- * = the one compressing mode).  with_eof != 0 appends the 28-byte EOF block (constants.d:37-49).  All pointers are host
+ * any RFC 1951 stream is valid for every BGZF reader, the reference's included; level 0 = stored blocks, every other level of
+ * zlib's range -- 1 .. 9 and -1, Z_DEFAULT_COMPRESSION, which is the reference's default (bgzfCompress(chunk, level = -1),
+ * BamWriter(compression_level = -1)) -- = the one compressing mode; anything else: SBX_EINVAL).  with_eof != 0 appends the 28-byte EOF block (constants.d:37-49).  All pointers are host
  * memory; *out_len receives the size of the stream (also on SBX_ENOMEM, when cap is too small: n + n / 2048 + 64 is
  * always enough).  device: HIP ordinal or -1. */
 int sbx_bgzf_compress(const uint8_t* in, size_t n, int level, int with_eof, int device, uint8_t* out, size_t cap, size_t* out_len,

@@ -856,8 +856,10 @@ int depth_main(int argc, char** argv) {
         // the upload of slice k + 1 and the text of slice k - 1 travel while slice k is computed.
         if (o.mode == "base" && !o.has_regions && o.min_cov > 0 && bp.device_format_applies() && paths.size() == 1 &&
             !getenv("SBX_NO_PIPELINE") && ((hi.compressed_bytes >= (256u << 20) && g_done_fd >= 0) || getenv("SBX_FORCE_PIPELINE"))) {
-            // (as ONE process -- SBX_NO_DETACH=1 -- the two contexts of the pipeline cost more at exit than their overlap saves:
-            //  0.86 s against 0.75 s for config 2; the one-pass form below is used then)
+            // (as ONE process -- the default -- the two contexts of the pipeline cost more at exit than their overlap saves: 0.86 s against
+            //  0.75 s for config 2; the one-pass form below is used then.  The pipeline keeps two contexts resident and cuts its slices
+            //  by positions, not by the planner's byte budget: when a slice does not fit (SBX_ENOMEM before any text was written) the
+            //  run falls back to the one-pass form, which goes through sbx_plan_batches)
             struct Slice { uint32_t ref; uint64_t beg, end, print_end; };
             std::vector<Slice> sl;
             {
@@ -884,10 +886,15 @@ int depth_main(int argc, char** argv) {
             std::condition_variable cv;
             std::vector<int> uploaded(sl.size(), 0), computed(sl.size(), 0), printed(sl.size(), 0);
             std::string failure;
+            int failure_code = SBX_OK;
             bool opened2 = false;
             double busy_up = 0, busy_run = 0, busy_print = 0, t_open2 = 0;       // seconds every stage was working (SBX_TIMING)
             std::vector<double> done_at(sl.size(), 0);
-            auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> g(mu); if (failure.empty()) failure = m; cv.notify_all(); };
+            auto fail = [&](const std::string& m, int code = SBX_EINVAL) {
+                std::lock_guard<std::mutex> g(mu);
+                if (failure.empty()) { failure = m.empty() ? std::string("pipeline stage failed") : m; failure_code = code; }
+                cv.notify_all();
+            };
             auto wait_for = [&](auto&& pred) { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return !failure.empty() || pred(); }); return failure.empty(); };
             auto mark = [&](std::vector<int>& v, size_t k) { std::lock_guard<std::mutex> g(mu); v[k] = 1; cv.notify_all(); };
             std::thread opener([&] {       // the second context opens while the first slice is on its way
@@ -910,7 +917,8 @@ int depth_main(int argc, char** argv) {
                     if (k >= 2 && !wait_for([&] { return computed[k - 2] != 0; })) return;       // the context's compressed bytes are free again
                     sbx_ctx* c = cx[k & 1];
                     const double tu = now();
-                    if (sbx_prefetch_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end) != SBX_OK) { fail(sbx_last_error(c)); return; }
+                    const int rc = sbx_prefetch_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end);
+                    if (rc != SBX_OK) { fail(sbx_last_error(c), rc); return; }
                     busy_up += now() - tu;
                     mark(uploaded, k);
                 }
@@ -920,24 +928,48 @@ int depth_main(int argc, char** argv) {
                     if (!wait_for([&] { return uploaded[k] != 0 && (k < 2 || printed[k - 2] != 0); })) return;
                     sbx_ctx* c = cx[k & 1];
                     const double tr = now();
-                    if (sbx_run_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end) != SBX_OK) { fail(sbx_last_error(c)); return; }
+                    const int rc = sbx_run_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end);
+                    if (rc != SBX_OK) { fail(sbx_last_error(c), rc); return; }
                     busy_run += now() - tr;
                     mark(computed, k);
                 }
             });
-            std::string print_failure;
+            // whatever leaves this scope -- an exception of any kind included -- first releases the stage threads, then joins them
+            struct JoinAll {
+                std::thread &a, &b, &c;
+                decltype(fail)& stop;
+                ~JoinAll() {
+                    stop("pipeline aborted", SBX_EINVAL);        // (no effect after a regular end: every stage is past its last wait)
+                    if (a.joinable()) a.join();
+                    if (b.joinable()) b.join();
+                    if (c.joinable()) c.join();
+                }
+            };
             const double t0 = now();
-            for (size_t k = 0; k < sl.size(); ++k) {
-                if (!wait_for([&] { return computed[k] != 0; })) break;
-                const double tp = now();
-                try { bp.run_slice(cx[k & 1], sl[k].ref, sl[k].beg, sl[k].print_end); }
-                catch (const Fail& f) { fail(f.msg); break; }
-                busy_print += now() - tp;
-                done_at[k] = now() - t0;
-                mark(printed, k);
+            size_t n_printed = 0;
+            bool all_printed = false;
+            {
+                JoinAll guard{opener, uploader, computer, fail};
+                for (size_t k = 0; k < sl.size(); ++k) {
+                    if (!wait_for([&] { return computed[k] != 0; })) break;
+                    const double tp = now();
+                    try { bp.run_slice(cx[k & 1], sl[k].ref, sl[k].beg, sl[k].print_end); }
+                    catch (const Fail& f) { fail(f.msg); break; }
+                    busy_print += now() - tp;
+                    done_at[k] = now() - t0;
+                    mark(printed, k);
+                    ++n_printed;
+                }
+                std::lock_guard<std::mutex> g(mu);
+                all_printed = n_printed == sl.size() && failure.empty();
             }
-            opener.join(); uploader.join(); computer.join();
-            if (!failure.empty()) { if (cx[1]) sbx_close(cx[1]); throw Fail{failure}; }
+            if (!all_printed && failure_code == SBX_ENOMEM && n_printed == 0) {
+                // nothing was written yet: the one-pass form below sizes its batches from the device's free memory
+                if (cx[1]) sbx_close(cx[1]);
+                if (timing) fprintf(stderr, "[sbx-depth] a slice of the pipeline does not fit the device next to the other context (%s): one pass instead\n", failure.c_str());
+                goto one_pass;
+            }
+            if (!all_printed) { if (cx[1]) sbx_close(cx[1]); throw Fail{failure}; }
             out.flush();
             if (out.fp != stdout) fclose(out.fp);
             if (timing) {
@@ -955,6 +987,7 @@ int depth_main(int argc, char** argv) {
             sbx_close(ctx);
             return 0;
         }
+    one_pass:
         WindowPrinter wp{ctx, o, out, samples, false, 0, 0, -1, 0, {}, {}, {}};
         RegionPrinter rp{ctx, o, out, samples, raw, raw_lines, {}, {}, {}};
         for (auto& b : plan) {
@@ -1010,13 +1043,15 @@ int depth_main(int argc, char** argv) {
 
 }  // namespace
 
-// The work runs in a child process and this one returns as soon as the child reports that the output is complete and its
-// descriptors are closed.  What is left for the child then is the teardown of a HIP process with tens of gigabytes mapped --
-// ~0.3 s inside the driver (measured: the same for an orderly close and for _exit, profiles/round3) -- which nothing
-// downstream depends on.  SBX_NO_DETACH=1 keeps everything in one process.
+// One process by default.  SBX_DETACH=1: the work runs in a child process and this one returns as soon as the child reports that the
+// output is complete and its descriptors are closed.  What is left for the child then is the teardown of a HIP process with tens
+// of gigabytes mapped -- ~0.3 s inside the driver (measured: the same for an orderly close and for _exit, profiles/round3) -- which
+// nothing downstream depends on; but the orphan still holds the device while it goes, and the next command of a shell loop or a
+// scheduler would start against its memory: a caller has to ask for that trade.
 int main(int argc, char** argv) {
     int fd[2];
-    if (getenv("SBX_NO_DETACH") || pipe(fd) != 0) return depth_main(argc, argv);
+    const char* det = getenv("SBX_DETACH");
+    if (!det || !*det || *det == '0' || getenv("SBX_NO_DETACH") || pipe(fd) != 0) return depth_main(argc, argv);
     const pid_t self = getpid();
     const pid_t pid = fork();                  // before anything touches HIP: a device context does not survive a fork
     if (pid < 0) { close(fd[0]); close(fd[1]); return depth_main(argc, argv); }
@@ -1035,7 +1070,12 @@ int main(int argc, char** argv) {
     ssize_t n;
     do n = read(fd[0], &st, 1); while (n < 0 && errno == EINTR);
     if (n == 1) _exit(st);
-    int ws = 0;                                // the child ended without a report: its exit status is the command's
+    int ws = 0;                                // the child ended without a report: its fate is the command's
     while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {}
-    return WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + WTERMSIG(ws);
+    if (WIFSIGNALED(ws)) {                     // killed by a signal (SIGPIPE from a consumer that left, SIGKILL ...): die by the same one
+        signal(WTERMSIG(ws), SIG_DFL);
+        raise(WTERMSIG(ws));
+        return 128 + WTERMSIG(ws);             // (a signal that cannot kill this process)
+    }
+    return WIFEXITED(ws) ? WEXITSTATUS(ws) : 1;
 }

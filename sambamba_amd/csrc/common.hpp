@@ -1,6 +1,8 @@
 // common.hpp -- shared host-side helpers for libsbx_depth (HIP error handling, device buffers).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <ctime>
 
 #include <cstdint>
@@ -33,7 +35,9 @@ struct Error : std::runtime_error {
 inline double& alloc_seconds() { static double s = 0; return s; }
 inline double wall_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
-inline double& devbuf_slack_pct() { static double p = 0.0; return p; }      // see DevBuf::ensure
+// growth slack of device buffers in percent (DevBuf::ensure); read and raised from several threads (sbx_prefetch_interval runs next to
+// the thread that computes): an atomic
+inline std::atomic<int>& devbuf_slack_pct() { static std::atomic<int> p{0}; return p; }
 
 template <class T>
 struct DevBuf {
@@ -66,7 +70,7 @@ struct DevBuf {
     // grow-only (keeps the allocation when it is already large enough).  A buffer that has to grow takes `slack_pct` percent
     // more than asked for: consecutive runs of similar size (the slices of a pipelined job, the batches of a genome) then
     // keep their allocations -- hipFree synchronises the whole device, which stalls every other stream.
-    void ensure(size_t count) { if (count > n) alloc(count + (size_t)((double)count * devbuf_slack_pct() / 100.0)); }
+    void ensure(size_t count) { if (count > n) alloc(count + (size_t)((double)count * devbuf_slack_pct().load(std::memory_order_relaxed) / 100.0)); }
     void release() {
         if (p) { const double t0 = wall_now(); (void)hipFree(p); alloc_seconds() += wall_now() - t0; }
         p = nullptr; n = 0;

@@ -13,7 +13,7 @@
 #include <string.h>
 
 #ifndef SBX_HD
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SBX_HD __host__ __device__
 #else
 #define SBX_HD
@@ -167,11 +167,12 @@ SBX_HD inline uint32_t crc32_bytes(const uint32_t* table, const uint8_t* p, uint
 }
 
 // A whole BGZF block around in[0, n) (n <= 0xFF00) at out[0, kBgzfSlot): header with the BC subfield, deflate data, CRC32,
-// ISIZE (SAM specification 4.1; bgzf/compress.d:60-103).  Returns the block length.  level 0: stored.
+// ISIZE (SAM specification 4.1; bgzf/compress.d:60-103).  Returns the block length.  level 0: stored; every other level of zlib's
+// range, -1 (Z_DEFAULT_COMPRESSION, the reference's default: bgzfCompress(chunk, level = -1)) included: the one compressing mode.
 SBX_HD inline uint32_t bgzf_block(const uint8_t* in, uint32_t n, int level, uint8_t* out, uint16_t* table, const uint32_t* crc_table) {
     const uint8_t hdr[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 'B', 'C', 2, 0};
     for (int k = 0; k < 16; ++k) out[k] = hdr[k];
-    uint32_t clen = level > 0 ? deflate_fixed(in, n, out + 18, kBgzfSlot - 18 - 8, table) : 0;
+    uint32_t clen = level != 0 ? deflate_fixed(in, n, out + 18, kBgzfSlot - 18 - 8, table) : 0;
     if (clen == 0 || clen > n + 5u) clen = deflate_stored(in, n, out + 18, kBgzfSlot - 18 - 8);   // incompressible: one stored block
     const uint32_t total = 18 + clen + 8;
     out[16] = (uint8_t)(total - 1); out[17] = (uint8_t)((total - 1) >> 8);

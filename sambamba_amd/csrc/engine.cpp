@@ -85,6 +85,8 @@ constexpr int kStages = 4;                   // ... of a ring of four
 
 struct sbx_ctx {
     std::string last_error;
+    std::mutex err_mu;                       // last_error: sbx_prefetch_interval may run on a second thread
+    std::atomic<double> upload_ms{0.0};      // wall clock of the last upload (make_resident)
     // several BAMs (MultiBamReader, multireader.d:244): this context is the first file and owns the merged view;
     // every further file is a complete single-file context of its own
     std::vector<sbx_ctx*> members;
@@ -222,10 +224,10 @@ int guarded(sbx_ctx* c, F&& f) {
         f();
         return SBX_OK;
     } catch (const Error& e) {
-        if (c) c->last_error = e.what();
+        if (c) { std::lock_guard<std::mutex> g(c->err_mu); c->last_error = e.what(); }
         return e.code;
     } catch (const std::exception& e) {
-        if (c) c->last_error = e.what();
+        if (c) { std::lock_guard<std::mutex> g(c->err_mu); c->last_error = e.what(); }
         return SBX_EINVAL;
     }
 }
@@ -463,7 +465,7 @@ void make_resident(sbx_ctx* c, std::vector<FileRun> runs) {
         upload_ranges(c, w.ranges);
         SBX_HIP(hipStreamSynchronize(c->copy_stream));
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        c->stats.ms_h2d = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+        c->upload_ms.store((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, std::memory_order_relaxed);
     }
     c->wl_resident = true;
 }
@@ -680,7 +682,14 @@ void sbx_close(sbx_ctx* c) {
     delete c;
 }
 
-const char* sbx_last_error(sbx_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
+const char* sbx_last_error(sbx_ctx* c) {
+    if (!c) return "null context";
+    // (a prefetch on a second thread may set the message while this one reads it: the caller gets its own copy)
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(c->err_mu);
+    copy = c->last_error;
+    return copy.c_str();
+}
 
 int sbx_header(sbx_ctx* c, sbx_header_info* out) {
     if (!c || !out) return SBX_EINVAL;
@@ -832,7 +841,7 @@ int sbx_preload(sbx_ctx* c) {
             upload_ranges(m, {{0, m->file.size, 0}});
             SBX_HIP(hipStreamSynchronize(m->copy_stream));
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            m->stats.ms_h2d = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+            m->upload_ms.store((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, std::memory_order_relaxed);
             m->preloaded = true;
             m->wl_resident = false;
         }
@@ -945,14 +954,13 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     SBX_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->have_run = false;
-    const double ms_h2d_prev = c->stats.ms_h2d;
     c->stats = sbx_run_stats{};
     if (!c->res) SBX_HIP(hipHostMalloc((void**)&c->res, sizeof(HostResults), hipHostMallocDefault));
     HostResults& R = *c->res;
 
     // ---- work list, tables, compressed bytes ----
     make_resident(c, build_runs(c, sel, restricted));
-    if (c->stats.ms_h2d == 0) c->stats.ms_h2d = ms_h2d_prev;
+    c->stats.ms_h2d = c->upload_ms.load(std::memory_order_relaxed);      // (the upload may have been a prefetch on another thread)
     const WorkList& w = c->wl;
     const uint32_t nb = (uint32_t)w.n_blocks();
     EventTimer t_all, t1, t1m, t2, t3;
@@ -990,7 +998,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     // descriptor capacity: sized for records of >= 160 bytes on average; K2 reports an overflow and the pass is repeated
     // with the exact number (short-read fixtures, amplicon data with tiny records)
     uint64_t want_cap = std::max<uint64_t>(c->desc_cap, w.u_bytes / 160 + 4096);
-    if (want_cap > c->desc_cap) want_cap += (uint64_t)((double)want_cap * devbuf_slack_pct() / 100.0);
+    if (want_cap > c->desc_cap) want_cap += (uint64_t)((double)want_cap * devbuf_slack_pct().load(std::memory_order_relaxed) / 100.0);
     const bool dbg = getenv("SBX_DEBUG") != nullptr;
     const char* force = getenv("SBX_FORCE_REPAIR");   // debug hook (tests/test_gpu_repair.py)
     // tiles with this many records or more keep 32-bit LDS counters in K3 (debug hook: a small value sends ordinary tiles
@@ -1400,7 +1408,10 @@ int sbx_prefetch_interval(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t en
         if (ref_id >= c->hdr.refs.size()) throw Error(SBX_EINVAL, "Invalid reference sequence index");
         if (!(beg < end)) throw Error(SBX_EINVAL, "empty interval");
         if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
-        if (devbuf_slack_pct() < 8.0) devbuf_slack_pct() = 8.0;       // slices of similar size follow: no buffer should have to grow twice
+        {   // slices of similar size follow: no buffer should have to grow twice
+            int cur = devbuf_slack_pct().load(std::memory_order_relaxed);
+            while (cur < 8 && !devbuf_slack_pct().compare_exchange_weak(cur, 8, std::memory_order_relaxed)) {}
+        }
         std::vector<sbx_region> sel;
         if (c->regions.empty()) sel.push_back({ref_id, beg, end});
         else
@@ -1492,6 +1503,7 @@ int sbx_bgzf_compress(const uint8_t* in, size_t n, int level, int with_eof, int 
                       char* err, size_t errlen) {
     try {
         if ((!in && n) || !out_len) throw Error(SBX_EINVAL, "null argument");
+        if (level < -1 || level > 9) throw Error(SBX_EINVAL, "compression level must be -1 (default) or 0 .. 9");
         require_device(device);
         size_t pos = 0;
         bgzf_compress_stream(in, n, level, [&](const uint8_t* p, size_t k) {
@@ -1593,6 +1605,7 @@ int sbx_build_index(const char* bam_path, const char* bai_path, int device, char
 int sbx_write_bam(const char* path, const uint8_t* stream, size_t n, int level, int with_index, int device, char* err, size_t errlen) {
     try {
         if (!path || (!stream && n)) throw Error(SBX_EINVAL, "null argument");
+        if (level < -1 || level > 9) throw Error(SBX_EINVAL, "compression level must be -1 (default) or 0 .. 9");
         require_device(device);
         FILE* f = fopen(path, "wb");
         if (!f) throw Error(SBX_EIO, std::string("cannot write ") + path);

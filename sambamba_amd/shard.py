@@ -205,13 +205,23 @@ def exclusive_offset(nbytes, dist=None):
 
 class TextFunnel:
     """Rank-ordered concatenation of the ranks' text on rank 0, streamed: a rank calls write(chunk) as its pieces are
-    produced (bounded memory: one piece in flight) and end() when it is done; rank 0 first drains its own writes straight
-    to `sink`, then receives rank 1's pieces, rank 2's, ...  Point to point through host memory (`group`: gloo)."""
+    produced and end() when it is done; rank 0 first drains its own writes straight to `sink`, then receives rank 1's
+    pieces, rank 2's, ...  Point to point through host memory (`group`: gloo).  The other ranks send without blocking and
+    keep up to `max_in_flight` pieces posted (bounded memory), so that they format and copy their text while rank 0 is still
+    busy with its own instead of stalling at their first piece."""
 
-    def __init__(self, dist, group, sink):
+    def __init__(self, dist, group, sink, max_in_flight=8):
         self.dist, self.group, self.sink = dist, group, sink
         self.solo = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
         self.rank = 0 if self.solo else dist.get_rank()
+        self.max_in_flight = max_in_flight
+        self._posted = []           # (work handle, tensor kept alive) of the sends not yet known to be complete
+
+    def _post(self, t):
+        self._posted.append((self.dist.isend(t, dst=0, group=self.group), t))
+        while len(self._posted) > 2 * self.max_in_flight:        # (two sends per piece: its length and its bytes)
+            w, _ = self._posted.pop(0)
+            w.wait()
 
     def begin(self):
         pass
@@ -223,15 +233,18 @@ class TextFunnel:
             return
         if not len(chunk):
             return
-        self.dist.send(torch.tensor([len(chunk)], dtype=torch.int64), dst=0, group=self.group)
-        self.dist.send(torch.frombuffer(bytearray(chunk), dtype=torch.uint8), dst=0, group=self.group)
+        self._post(torch.tensor([len(chunk)], dtype=torch.int64))
+        self._post(torch.frombuffer(bytearray(chunk), dtype=torch.uint8))
 
     def end(self):
         import torch
         if self.solo:
             return
         if self.rank != 0:
-            self.dist.send(torch.tensor([-1], dtype=torch.int64), dst=0, group=self.group)
+            self._post(torch.tensor([-1], dtype=torch.int64))
+            for w, _ in self._posted:
+                w.wait()
+            self._posted = []
             return
         for src in range(1, self.dist.get_world_size()):
             while True:

@@ -52,7 +52,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("level", [0, 6])
+@pytest.mark.parametrize("level", [0, 6, -1])
 def test_host_encoder_round_trips_through_zlib(host_encoder, tmp_path, name, level):
     data = CASES[name]
     if name == "bam_like":

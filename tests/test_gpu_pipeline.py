@@ -57,8 +57,8 @@ def test_pipeline_reports_errors(tmp_path, bam):
 @pytest.mark.parametrize("mode_args", [["base"], ["window", "-w", "500"], ["base", "-L", "c1:1000-90000"]])
 def test_detached_and_single_process_print_the_same(bam, mode_args):
     want = run_oracle(mode_args + [bam])
-    a = subprocess.run([cli_path()] + mode_args + [bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    b = subprocess.run([cli_path()] + mode_args + [bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, SBX_NO_DETACH="1"))
+    a = subprocess.run([cli_path()] + mode_args + [bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, SBX_DETACH="1"))
+    b = subprocess.run([cli_path()] + mode_args + [bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
     assert a.stdout == want and b.stdout == want
 
@@ -68,15 +68,16 @@ def test_output_is_complete_when_the_command_returns(bam, tmp_path):
     subprocess.run returns (only the parent is waited for), and a consumer on a pipe sees the whole text and end-of-file."""
     want = run_oracle(["base", bam])
     out = str(tmp_path / "o.txt")
+    det = dict(os.environ, SBX_DETACH="1")
     for k in range(3):
-        r = subprocess.run([cli_path(), "base", "-o", out, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run([cli_path(), "base", "-o", out, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=det)
         assert r.returncode == 0
         assert open(out, "rb").read() == want
         os.unlink(out)
-    sh = subprocess.run("%s base %s | md5sum" % (cli_path(), bam), shell=True, stdout=subprocess.PIPE, check=True)
+    sh = subprocess.run("%s base %s | md5sum" % (cli_path(), bam), shell=True, stdout=subprocess.PIPE, check=True, env=det)
     import hashlib
     assert sh.stdout.split()[0].decode() == hashlib.md5(want).hexdigest()
-    env = dict(os.environ, SBX_FORCE_PIPELINE="1", SBX_SLICE_POSITIONS="50000")
+    env = dict(os.environ, SBX_DETACH="1", SBX_FORCE_PIPELINE="1", SBX_SLICE_POSITIONS="50000")
     sh = subprocess.run("%s base %s | md5sum" % (cli_path(), bam), shell=True, stdout=subprocess.PIPE, check=True, env=env)
     assert sh.stdout.split()[0].decode() == hashlib.md5(want).hexdigest()
 
@@ -88,8 +89,8 @@ def test_failures_keep_their_status_and_message(tmp_path, bam):
     raw[len(raw) // 2 + 1] ^= 0xFF
     open(bad, "wb").write(raw)
     open(bad + ".bai", "wb").write(open(bam + ".bai", "rb").read())
-    a = subprocess.run([cli_path(), "base", bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    b = subprocess.run([cli_path(), "base", bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, SBX_NO_DETACH="1"))
+    a = subprocess.run([cli_path(), "base", bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, SBX_DETACH="1"))
+    b = subprocess.run([cli_path(), "base", bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == b.returncode
     assert a.stderr == b.stderr
     if a.returncode:

@@ -179,7 +179,7 @@ def _one(seed):
 def test_cli_equals_oracle_on_random_bams():
     fails = []          # every differing example is reported, not only the first (no shrinking: an example is a GPU process)
 
-    @settings(max_examples=60, deadline=None, derandomize=True, database=None, phases=[Phase.generate],
+    @settings(max_examples=300, deadline=None, derandomize=True, database=None, phases=[Phase.generate],
               suppress_health_check=list(HealthCheck))
     @given(seed=st.integers(0, 2 ** 31 - 1))
     def body(seed):

@@ -41,7 +41,7 @@ WRITER_CASES = {
 
 
 @pytest.mark.parametrize("name", sorted(WRITER_CASES))
-@pytest.mark.parametrize("level", [6, 0])
+@pytest.mark.parametrize("level", [6, 0, -1])
 def test_device_bgzf_stream_inflates_and_equals_the_host_encoder(host_encoder, tmp_path, name, level):
     data = WRITER_CASES[name]()
     comp = sambamba_amd.bgzf_compress(data, level=level, with_eof=True)
@@ -53,6 +53,16 @@ def test_device_bgzf_stream_inflates_and_equals_the_host_encoder(host_encoder, t
     assert comp[:-28] == open(dst, "rb").read()          # the same bytes on the device and on the host
     if level and name in ("run", "bam_like"):
         assert len(comp) < 0.7 * len(data)
+
+
+def test_default_level_compresses_and_bad_levels_are_rejected():
+    """-1 is zlib's Z_DEFAULT_COMPRESSION and the reference's default (bgzfCompress(chunk, level = -1)): it must compress."""
+    data = bam_like(400000, 11)
+    assert len(sambamba_amd.bgzf_compress(data, level=-1)) == len(sambamba_amd.bgzf_compress(data, level=6)) < 0.7 * len(data)
+    for bad in (-2, 10, 100):
+        with pytest.raises(sambamba_amd.SbxError) as ei:
+            sambamba_amd.bgzf_compress(data, level=bad)
+        assert ei.value.code == -1        # SBX_EINVAL
 
 
 def test_many_blocks_in_several_pieces():
