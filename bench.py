@@ -651,7 +651,8 @@ def main():
                "record_index": nrec * (36 + 32),              # 36-B fixed part read + 32-B descriptor written per record
                "decode_accumulate": acc_in + cnt}             # descriptors + CIGAR / packed sequence (+ qualities when -q > 0) of the
                                                               # admitted records in; counters (+ span counts) out, once
-        pmc = pmc_table() if (args.config == 2 and args.length == CHR1_LEN and world == 1) else {}
+        full_size = (args.config == 2 and args.length == CHR1_LEN) or (args.config != 2 and args.scale == 1.0)
+        pmc = pmc_table(args.config) if (full_size and world == 1) else {}
         per_kernel = {}
         bad_frac = []
         for k in kern:
@@ -672,7 +673,7 @@ def main():
         if dom in pmc:
             roof.update({"traffic": pmc[dom]["traffic"], "traffic_unit": "bytes per launch", "traffic_source": pmc[dom]["source"],
                          "traffic_over_algorithmic": per_kernel[dom]["traffic_over_algorithmic"]})
-            if dom == "huffman_decode" and os.environ.get("SBX_K1A_BURST", "1") == "1":
+            if dom == "huffman_decode" and os.environ.get("SBX_K1A", "2") == "1" and os.environ.get("SBX_K1A_BURST", "1") == "1":
                 roof["traffic_note"] = ("K1a is issue / latency bound (the memory system moves 1.5 of its 8 TB/s under it); its default writes the "
                                         "token streams in 16-byte stores, which costs 28.6 GB of partial-sector traffic per launch and saves "
                                         "1.7 ms; SBX_K1A_BURST=22 (32-byte nontemporal bursts): 29.2 ms, 14.2 GB = 1.11 x algorithmic "
@@ -738,20 +739,21 @@ def main():
         sys.exit(3)
 
 
-PMC_KERNELS = {"huffman_decode": ["k_huffman_decode"],
+PMC_KERNELS = {"huffman_decode": ["k_huffman_decode", "k_huffman_decode2", "k_translate_literals"],
                "lz77_resolve": ["k_lz77_resolve", "k_lz77_resolve_o32", "k_lz77_resolve_o32_w8", "k_lz77_resolve_o32_u", "k_lz77_resolve_o32_f",
                                 "k_lz77_resolve_o32_uf", "k_lz77_resolve_o32_uf_w8"],
                "record_index": ["k_walk_blocks", "k_check_scan", "k_describe_blocks", "k_tile_compact", "k_chain_repair", "k_rewalk_mismatched"],
                "decode_accumulate": ["k_accumulate16", "k_accumulate16b", "k_accumulate16c", "k_accumulate"]}
 
 
-def pmc_table():
+def pmc_table(config=2):
     """HBM bytes per launch of every kernel group from the committed PMC passes of this same workload
     (tools/profile_round.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, KiB).
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is.  The file is measured
     by the builder on the code of the commit named in profiles/<round>/README.md; the driver's run does not re-measure it."""
-    for rnd in ("round3", "round2"):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_fetch_write_chr1_30x.csv")
+    names = ["pmc_fetch_write_config%d.csv" % config] + (["pmc_fetch_write_chr1_30x.csv"] if config == 2 else [])
+    for rnd, name in [(r, n) for r in ("round4", "round3", "round2") for n in names]:
+        path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             break
     else:
@@ -761,15 +763,16 @@ def pmc_table():
         next(fh)
         for ln in fh:
             k, c, v, _ = ln.strip().split(",")
-            best[(k, c)] = max(best.get((k, c), 0.0), float(v))     # the full-size launch
+            best[(k, c)] = best.get((k, c), 0.0) + float(v)          # all launches of the ONE pass the PMC run makes (a pass over a whole
+                                                                      # genome is several device batches; the launches at open time are tiny)
     out = {}
     for group, kernels in PMC_KERNELS.items():
         fetch = sum(v for (k, c), v in best.items() if k in kernels and c == "FETCH_SIZE") * 1024
         write = sum(v for (k, c), v in best.items() if k in kernels and c == "WRITE_SIZE") * 1024
         if fetch or write:
             out[group] = {"traffic": int(2 * fetch + write),
-                          "source": "profiles/%s/pmc_fetch_write_chr1_30x.csv (rocprofv3 PMC, separate passes; FETCH_SIZE raw %.2f GB "
-                                    "doubled, WRITE_SIZE %.2f GB)" % (rnd, fetch / 1e9, write / 1e9)}
+                          "source": "profiles/%s/%s (rocprofv3 PMC, separate passes; FETCH_SIZE raw %.2f GB "
+                                    "doubled, WRITE_SIZE %.2f GB)" % (rnd, name, fetch / 1e9, write / 1e9)}
     return out
 
 
