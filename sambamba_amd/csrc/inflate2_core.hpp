@@ -13,8 +13,8 @@
 //    symbol permutation per lane that capped the kernel at 7 waves per CU is gone: per code length l the lane keeps
 //    aux[l] = {litend_l, E_l} (first canonical index behind the literals of length l; number of non-literal symbols with
 //    shorter codes) -- canonical index idx is a literal iff idx < litend_l, its rank is idx - E_l, and otherwise it is the
-//    (idx - litend_l + E_l)-th non-literal symbol, looked up in a 32-byte list.  164 bytes of LDS per lane, laid out
-//    lane-interleaved (dword j of lane i in bank i whatever j is): 15 waves per CU instead of 7.
+//    (idx - litend_l + E_l)-th non-literal symbol, looked up in a 30-byte list.  176 bytes of LDS per lane, laid out
+//    lane-interleaved (dword j of lane i in bank i whatever j is): 14 waves per CU instead of 7.
 //  * Bits come from a window fetched at the absolute bit position (two ring dwords + v_alignbit / v_lshrrev_b64) instead of a
 //    64-bit buffer with a refill test in front of every symbol; literals are pushed into a 64-bit shift register (two
 //    v_alignbit per literal) and leave through a 16-byte staging area in LDS, match entries likewise: no register FIFOs.
@@ -51,11 +51,14 @@ constexpr int kScratchBytes = kScratchTabs + kMaxSeg * 256;    // 1792
 constexpr int kRingDw = 9;                  // 8 dwords of input + a copy of dword 0 behind them (a window is read as dwords t, t + 1)
 constexpr int kOffRing = 0;
 constexpr int kOffLitStage = kOffRing + 256 * kRingDw;     // 4 dwords: the 16-byte group of literal ranks being filled
-constexpr int kOffEntStage = kOffLitStage + 256 * 4;       // 4 dwords: the group of match entries being filled
-constexpr int kOffAux = kOffEntStage + 256 * 4;            // u16[16]: per code length {litend : 9, E : 6} (counters while a code is built)
-constexpr int kOffLenSym = kOffAux + 128 * 16;             // u8[32]: non-literal symbols - 256 in canonical order (dist counters during the build)
-constexpr int kOffDistSym = kOffLenSym + 64 * 32;          // u8[32]: distance symbols in canonical order
-constexpr int kWaveLds = kOffDistSym + 64 * 32;            // 10496 bytes
+constexpr int kOffEntStage = kOffLitStage + 256 * 4;       // 8 dwords: a ring of match entries, two 16-byte groups (a finished group may wait for its store
+                                                           // while the next one fills: the symbol loop stores every second iteration only)
+constexpr int kOffAux = kOffEntStage + 256 * 8;            // u16[16]: per code length {litend : 9, E : 6} (counters while a code is built)
+constexpr int kSymEntries = 30;                            // entries of the two symbol lists (the fixed code's 31st and 32nd non-literal symbols, 286 and
+                                                           // 287, are invalid: an index beyond the list is an error, nothing is kept for it)
+constexpr int kOffLenSym = kOffAux + 128 * 16;             // u8[30]: non-literal symbols - 256 in canonical order (dist counters during the build)
+constexpr int kOffDistSym = kOffLenSym + 64 * kSymEntries; // u8[30]: distance symbols in canonical order
+constexpr int kWaveLds = kOffDistSym + 64 * kSymEntries;   // 11264 bytes = 44 dwords per lane: 14 wavefronts per CU
 constexpr int kLenTabBytes = 64, kDistTabBytes = 128;      // RFC 1951 3.2.5 tables shared by the workgroup, behind the waves' areas
 
 constexpr uint32_t kNone = 0xFFu, kStop = 0x1FFu;
@@ -266,24 +269,54 @@ struct Lane {
         }
     }
     SBX_HD void stage_entry(uint32_t e) {
-        dw(kOffEntStage, n_ent & 3u) = e;
+        dw(kOffEntStage, n_ent & 7u) = e;
         ++n_ent;
     }
-    // at the top of an iteration: the groups completed by the previous one (a staging area is not written again before that)
+    SBX_HD u32x4h lit_group() const {
+        u32x4h g;
+        g.x = dw(kOffLitStage, 0); g.y = dw(kOffLitStage, 1); g.z = dw(kOffLitStage, 2); g.w = dw(kOffLitStage, 3);
+        return g;
+    }
+    SBX_HD u32x4h ent_group(uint32_t grp) const {           // group `grp` of the entry stream sits in half grp & 1 of the ring
+        const uint32_t b = 4u * (grp & 1u);
+        u32x4h g;
+        g.x = dw(kOffEntStage, b); g.y = dw(kOffEntStage, b + 1u); g.z = dw(kOffEntStage, b + 2u); g.w = dw(kOffEntStage, b + 3u);
+        return g;
+    }
+    // every finished group goes to its stream (outside the symbol loop)
     SBX_HD void flush_groups() {
         if ((n_lit >> 4) != lit_flushed) {
-            u32x4h g;
-            g.x = dw(kOffLitStage, 0); g.y = dw(kOffLitStage, 1); g.z = dw(kOffLitStage, 2); g.w = dw(kOffLitStage, 3);
-            store16(lit + 16u * lit_flushed, g);
+            store16(lit + 16u * lit_flushed, lit_group());
             ++lit_flushed;
         }
-        if ((n_ent >> 2) != ent_flushed) {
-            u32x4h g;
-            g.x = dw(kOffEntStage, 0); g.y = dw(kOffEntStage, 1); g.z = dw(kOffEntStage, 2); g.w = dw(kOffEntStage, 3);
-            store16(ent + 4u * ent_flushed, g);
+        while ((n_ent >> 2) != ent_flushed) {
+            store16(ent + 4u * ent_flushed, ent_group(ent_flushed));
             ++ent_flushed;
         }
     }
+    // The symbol loop: ONE store instruction every second iteration for both streams.  A vector memory instruction costs a
+    // wavefront of this kernel ~1.2 us of its CU's memory pipeline whatever its execution mask says (profiles/round4: without its
+    // two stores per iteration the kernel took 17.9 instead of 24.9 ms, with the two merged into one 20.1), so the loop issues its
+    // input load in one iteration and this store in the next.  A lane writes its finished literal group if it has one, else its oldest
+    // finished entry group.  Nothing is overwritten while it waits: the literal staging area is written again when four more literals
+    // have been decoded (two iterations), the entry ring holds a finished group and four more entries -- literal groups take at
+    // most every fourth store, entry groups are finished at most every fourth iteration.
+    SBX_HD void flush_one() {
+        const bool rl = (n_lit >> 4) != lit_flushed, re = (n_ent >> 2) != ent_flushed;
+        if (rl || re) {
+            const uint32_t b = rl ? 0u : 4u * (ent_flushed & 1u);
+            const int off = rl ? kOffLitStage : kOffEntStage;
+            u32x4h g;
+            g.x = dw(off, b); g.y = dw(off, b + 1u); g.z = dw(off, b + 2u); g.w = dw(off, b + 3u);
+            uint8_t* const p = rl ? lit + 16u * lit_flushed : (uint8_t*)(ent + 4u * ent_flushed);
+            store16(p, g);
+            lit_flushed += rl ? 1u : 0u;
+            ent_flushed += rl ? 0u : 1u;
+        }
+    }
+    // enough input in the ring for one iteration's windows (two literal/length symbols, then a 64-bit window)?  With the input
+    // served every second iteration only a lane can, in principle, run short: it then sits an iteration out.
+    SBX_HD bool have_input() const { return (wr_dw << 5) - bitpos >= 96u; }
 
     // ---- one block ------------------------------------------------------------------------------------------------------
     SBX_HD LaneResult run(const LaneIo& io, uint8_t* W_, uint32_t lane, const uint16_t* len_tab_, const uint32_t* dist_tab_) {
@@ -481,7 +514,7 @@ struct Lane {
                             if (s >= nlit && s < nlit + ndist && l != 0u) {
                                 const uint32_t idx = b8(kOffLenSym, l);
                                 b8(kOffLenSym, l) = (uint8_t)(idx + 1u);
-                                b8(kOffDistSym, idx & 31u) = (uint8_t)(s - nlit);
+                                if (idx < (uint32_t)kSymEntries) b8(kOffDistSym, idx) = (uint8_t)(s - nlit);
                             }
                         }
                     }
@@ -537,7 +570,7 @@ struct Lane {
                             if (s < nlit && l != 0u) {
                                 const uint32_t p = h16(kOffAux, l);
                                 if (s < 256u) { h16(kOffAux, l) = (uint16_t)(p + 1u); tab[p & 0xFFu] = (uint8_t)s; }
-                                else { h16(kOffAux, l) = (uint16_t)(p + 512u); b8(kOffLenSym, (p >> 9) & 31u) = (uint8_t)(s - 256u); }
+                                else { h16(kOffAux, l) = (uint16_t)(p + 512u); if ((p >> 9) < (uint32_t)kSymEntries) b8(kOffLenSym, p >> 9) = (uint8_t)(s - 256u); }
                             }
                         }
                     }
@@ -573,11 +606,14 @@ struct Lane {
             // st: kNone = decoding, nothing pending; < 32 = a non-literal symbol is pending (its index in the canonical list); kStop = the lane
             // is not (any longer) in this deflate block
             uint32_t st = huff ? kNone : kStop;
+            // (two iterations per turn of the loop: the input is served in the first, the token store issued in the second)
             if (wave_any(st != kStop)) do {
-                service();
-                flush_groups();
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                if (half == 0) service(); else flush_one();
+                const bool input = have_input();
                 const uint32_t n_lit0 = n_lit;
-                if (st == kNone) {
+                if (st == kNone && input) {
                     // both symbols are decoded back to back -- the second one speculatively: it counts only if the first was a literal -- so that
                     // their table reads are in flight together and nothing below is control flow
                     const uint32_t w = window32(bitpos);
@@ -611,11 +647,11 @@ struct Lane {
                 const uint32_t opos_now = opos + n_lit;
                 const uint32_t run_len = n_lit - lit_mark;
                 const bool split = run_len >= 255u;              // (also for a lane that waits for the others: they are 255 literals all the same)
-                const bool do_d = !split && st < 32u;
+                const bool do_d = !split && st < 32u && input;
                 bool eob = false, m_ok = false;
                 uint32_t m_e = 0, m_bits = 0, m_len = 0;
                 if (do_d) {
-                    const uint32_t s5 = b8(kOffLenSym, st);         // symbol - 256: 0 end of block, 1..29 length codes, 30 / 31 invalid
+                    const uint32_t s5 = b8(kOffLenSym, st < (uint32_t)kSymEntries ? st : 0u);   // symbol - 256: 0 end of block, 1..29 length codes
                     const uint32_t lt = len_tab[(s5 - 1u) & 31u];
                     uint64_t w64 = window64(bitpos);
                     const uint32_t le = lt >> 9, lb = lt & 0x1FFu;
@@ -626,14 +662,14 @@ struct Lane {
                     const uint32_t dm1 = acc >> 13;                           // 15: no such code
                     const uint32_t dl = dm1 + 1u;
                     const uint32_t didx = ((dv >> ((14u - (dm1 & 15u)) & 31u)) + acc) & 0x1FFu;
-                    const uint32_t dsym = b8(kOffDistSym, didx & 31u);
+                    const uint32_t dsym = b8(kOffDistSym, didx < (uint32_t)kSymEntries ? didx : 0u);
                     const uint32_t dt = dist_tab[dsym & 31u];
                     w64 >>= dl;
                     const uint32_t de = dt >> 16, db = dt & 0xFFFFu;
                     const uint32_t dist = db + bfe((uint32_t)w64, 0, de);
-                    eob = s5 == 0u;
+                    eob = s5 == 0u && st < (uint32_t)kSymEntries;
                     // (a distance code that exists has an index below the number of codes, its symbol is below 30 by construction)
-                    m_ok = s5 - 1u < 29u && dm1 <= 14u && dist <= opos_now && opos_now + mlen <= io.osize;
+                    m_ok = st < (uint32_t)kSymEntries && s5 - 1u < 29u && dm1 <= 14u && didx < (uint32_t)kSymEntries && dist <= opos_now && opos_now + mlen <= io.osize;
                     m_e = make_entry2(run_len, mlen, dist);
                     m_bits = le + dl + de;
                     m_len = mlen;
@@ -645,6 +681,7 @@ struct Lane {
                 opos += m_ok ? m_len : 0u;
                 st = do_d ? (eob ? kStop : kNone) : st;
                 if (bad) { err = 1; st = kStop; active = false; }
+                }
             } while (wave_any(st != kStop));
             if (active && bitpos - lead_bits > io.in_bits) { err = 1; active = false; }
             if (active && last) active = false;
@@ -663,16 +700,8 @@ struct Lane {
             }
         }
         if (n_lit & 3u) dw(kOffLitStage, (n_lit >> 2) & 3u) = hi >> (8u * (4u - (n_lit & 3u)));
-        if (n_lit & 15u) {
-            u32x4h g;
-            g.x = dw(kOffLitStage, 0); g.y = dw(kOffLitStage, 1); g.z = dw(kOffLitStage, 2); g.w = dw(kOffLitStage, 3);
-            store16(lit + 16u * (n_lit >> 4), g);
-        }
-        if (n_ent & 3u) {
-            u32x4h g;
-            g.x = dw(kOffEntStage, 0); g.y = dw(kOffEntStage, 1); g.z = dw(kOffEntStage, 2); g.w = dw(kOffEntStage, 3);
-            store16(ent + 4u * (n_ent >> 2), g);
-        }
+        if (n_lit & 15u) store16(lit + 16u * (n_lit >> 4), lit_group());
+        if (n_ent & 3u) store16(ent + 4u * (n_ent >> 2), ent_group(n_ent >> 2));
         if (err == 0u && opos + n_lit != io.osize) err = 1;
         if (err == 0u && bitpos - lead_bits > io.in_bits) err = 1;
         if (io.live) {

@@ -106,13 +106,13 @@ def test_lanes_use_disjoint_lds():
         spans = []
         for j in range(consts["kRingDw"]):
             spans.append((consts["kOffRing"] + 256 * j + 4 * lane, 4))
-        for off in ("kOffLitStage", "kOffEntStage"):
-            for j in range(4):
+        for off, n in (("kOffLitStage", 4), ("kOffEntStage", 8)):
+            for j in range(n):
                 spans.append((consts[off] + 256 * j + 4 * lane, 4))
         for e in range(16):
             spans.append((consts["kOffAux"] + 128 * e + 2 * lane, 2))
         for off in ("kOffLenSym", "kOffDistSym"):
-            for e in range(32):
+            for e in range(consts["kSymEntries"]):
                 spans.append((consts[off] + 64 * e + lane, 1))
         for a, n in spans:
             assert a + n <= wave
