@@ -130,42 +130,15 @@ SBX_HD uint32_t decode_pairs(const Code& C, uint32_t v, uint32_t acc) {
     return acc;
 }
 
-// flags of a wavefront's current codes (wave-uniform, scalar registers on the device): pairs nobody needs are skipped
-struct CodeFlags {
-    uint32_t lit_no12;      // no lane's literal/length code has codes of 1 or 2 bits: pair 0 is a constant
-    uint32_t lit_in14;      // every lane's literal/length code is complete within 14 bits: pair 7 adds nothing
-    uint32_t dist_no12;
-    uint32_t dist_in12;     // ... distance code complete within 12 bits: pairs 6 and 7 add nothing
-};
-
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SBX_NO_SCALAR_FLAG)
-#define SBX_SCALAR_FLAG(x) asm volatile("" : "+s"(x))
-#else
-#define SBX_SCALAR_FLAG(x) (void)(x)
-#endif
-
-// (the flags are re-read from their scalar registers at every use -- hoisted out of the loop a comparison becomes a lane mask that
-// costs two vector instructions per test -- and the branches are real ones: the compiler would otherwise compute the pairs and select)
-SBX_HD uint32_t decode_lit(const Code& C, uint32_t v, const CodeFlags& F) {
-    uint32_t acc, no12 = F.lit_no12, in14 = F.lit_in14;
-    SBX_SCALAR_FLAG(no12);
-    acc = C.d1_lo;
-    if (no12 == 0u) { SBX_KEEP_BRANCH(); acc = decode_pairs<0, 1>(C, v, C.d1); }
-    acc = decode_pairs<1, 7>(C, v, acc);
-    SBX_SCALAR_FLAG(in14);
-    if (in14 == 0u) { SBX_KEEP_BRANCH(); acc = decode_pairs<7, 8>(C, v, acc); }
-    return acc;
-}
-SBX_HD uint32_t decode_dist(const Code& C, uint32_t v, const CodeFlags& F) {
-    uint32_t acc, no12 = F.dist_no12, in12 = F.dist_in12;
-    SBX_SCALAR_FLAG(no12);
-    acc = C.d1_lo;
-    if (no12 == 0u) { SBX_KEEP_BRANCH(); acc = decode_pairs<0, 1>(C, v, C.d1); }
-    acc = decode_pairs<1, 6>(C, v, acc);
-    SBX_SCALAR_FLAG(in12);
-    if (in12 == 0u) { SBX_KEEP_BRANCH(); acc = decode_pairs<6, 8>(C, v, acc); }
-    return acc;
-}
+// kPlain: every lane's codes of the current deflate blocks are "plain" -- no codes of 1 or 2 bits (pair 0 of the sum is a constant,
+// folded into d1_lo), the literal/length code complete within 14 bits and the distance code within 12 (the pairs above add nothing) --
+// which is what zlib emits for a BAM (tools/token_stats.cpp: the literal/length code reaches 14 bits in 97 % of the blocks and never
+// 15, the distance code 12 at most).  The symbol loop exists in both forms and a wavefront picks one per round of deflate blocks:
+// no flag is tested inside the loop (round 3 tested scalar flags per symbol: two instructions to skip three).
+template <bool kPlain>
+SBX_HD uint32_t decode_lit(const Code& C, uint32_t v) { return kPlain ? decode_pairs<1, 7>(C, v, C.d1_lo) : decode_pairs<0, 8>(C, v, C.d1); }
+template <bool kPlain>
+SBX_HD uint32_t decode_dist(const Code& C, uint32_t v) { return kPlain ? decode_pairs<1, 6>(C, v, C.d1_lo) : decode_pairs<0, 8>(C, v, C.d1); }
 
 // order of the code-length code lengths (RFC 1951 3.2.7), 5 bits each: entry i at bit 5 i
 constexpr uint64_t kClOrderLo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
@@ -317,6 +290,94 @@ struct Lane {
     // enough input in the ring for one iteration's windows (two literal/length symbols, then a 64-bit window)?  With the input
     // served every second iteration only a lane can, in principle, run short: it then sits an iteration out.
     SBX_HD bool have_input() const { return (wr_dw << 5) - bitpos >= 96u; }
+
+    template <bool kPlain>
+    SBX_HD void symbol_loop(const Code& CL, const Code& CD, const LaneIo& io, bool huff, uint32_t& err, bool& active) {
+    // ---- symbol loop --------------------------------------------------------------------------------------------
+    // An iteration: up to two literal/length symbols per lane (literals are pushed on the spot, the first other symbol stops the
+    // lane's run and stays pending), then for the pending one at most one entry: the match (length extra bits, distance code,
+    // distance extra bits), or -- when 255 literals have piled up -- a literal-run entry, the match waiting one more iteration.
+    // st: kNone = decoding, nothing pending; < 32 = a non-literal symbol is pending (its index in the canonical list); kStop = the lane
+    // is not (any longer) in this deflate block
+    uint32_t st = huff ? kNone : kStop;
+    // (two iterations per turn of the loop: the input is served in the first, the token store issued in the second)
+    if (wave_any(st != kStop)) do {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+        if (half == 0) service(); else flush_one();
+        const bool input = have_input();
+        const uint32_t n_lit0 = n_lit;
+        if (st == kNone && input) {
+            // both symbols are decoded back to back -- the second one speculatively: it counts only if the first was a literal -- so that
+            // their table reads are in flight together and nothing below is control flow
+            const uint32_t w = window32(bitpos);
+            const uint32_t v1 = brev32(w) >> 17;
+            const uint32_t acc1 = decode_lit<kPlain>(CL, v1);
+            const uint32_t len1 = (acc1 >> 13) + 1u;                        // complete code: <= 15
+            const uint32_t a1 = h16(kOffAux, len1);
+            const uint32_t v2 = brev32(w >> len1) >> 17;
+            const uint32_t acc2 = decode_lit<kPlain>(CL, v2);
+            const uint32_t len2 = (acc2 >> 13) + 1u;
+            const uint32_t a2 = h16(kOffAux, len2);
+            const uint32_t idx1 = ((v1 >> (15u - len1)) + acc1) & 0x1FFu, idx2 = ((v2 >> (15u - len2)) + acc2) & 0x1FFu;
+            const uint32_t litend1 = a1 & 0x1FFu, E1 = a1 >> 9, litend2 = a2 & 0x1FFu, E2 = a2 >> 9;
+            const bool lit1 = idx1 < litend1, lit2 = lit1 && idx2 < litend2;
+            {
+                const uint32_t nlo = alignbit(hi, lo, 8), nhi = alignbit(idx1 - E1, hi, 8);
+                lo = lit1 ? nlo : lo;
+                hi = lit1 ? nhi : hi;
+            }
+            {
+                const uint32_t nlo = alignbit(hi, lo, 8), nhi = alignbit(idx2 - E2, hi, 8);
+                lo = lit2 ? nlo : lo;
+                hi = lit2 ? nhi : hi;
+            }
+            n_lit += (lit1 ? 1u : 0u) + (lit2 ? 1u : 0u);
+            bitpos += len1 + (lit1 ? len2 : 0u);
+            const uint32_t j1 = (idx1 - litend1 + E1) & 31u, j2 = (idx2 - litend2 + E2) & 31u;
+            st = !lit1 ? j1 : !lit2 ? j2 : kNone;
+        }
+        stage_lit_dword(n_lit0);
+        const uint32_t opos_now = opos + n_lit;
+        const uint32_t run_len = n_lit - lit_mark;
+        const bool split = run_len >= 255u;              // (also for a lane that waits for the others: they are 255 literals all the same)
+        const bool do_d = !split && st < 32u && input;
+        bool eob = false, m_ok = false;
+        uint32_t m_e = 0, m_bits = 0, m_len = 0;
+        if (do_d) {
+            const uint32_t s5 = b8(kOffLenSym, st < (uint32_t)kSymEntries ? st : 0u);   // symbol - 256: 0 end of block, 1..29 length codes
+            const uint32_t lt = len_tab[(s5 - 1u) & 31u];
+            uint64_t w64 = window64(bitpos);
+            const uint32_t le = lt >> 9, lb = lt & 0x1FFu;
+            const uint32_t mlen = lb + bfe((uint32_t)w64, 0, le);
+            w64 >>= le;
+            const uint32_t dv = brev32((uint32_t)w64) >> 17;
+            const uint32_t acc = decode_dist<kPlain>(CD, dv);
+            const uint32_t dm1 = acc >> 13;                           // 15: no such code
+            const uint32_t dl = dm1 + 1u;
+            const uint32_t didx = ((dv >> ((14u - (dm1 & 15u)) & 31u)) + acc) & 0x1FFu;
+            const uint32_t dsym = b8(kOffDistSym, didx < (uint32_t)kSymEntries ? didx : 0u);
+            const uint32_t dt = dist_tab[dsym & 31u];
+            w64 >>= dl;
+            const uint32_t de = dt >> 16, db = dt & 0xFFFFu;
+            const uint32_t dist = db + bfe((uint32_t)w64, 0, de);
+            eob = s5 == 0u && st < (uint32_t)kSymEntries;
+            // (a distance code that exists has an index below the number of codes, its symbol is below 30 by construction)
+            m_ok = st < (uint32_t)kSymEntries && s5 - 1u < 29u && dm1 <= 14u && didx < (uint32_t)kSymEntries && dist <= opos_now && opos_now + mlen <= io.osize;
+            m_e = make_entry2(run_len, mlen, dist);
+            m_bits = le + dl + de;
+            m_len = mlen;
+        }
+        const bool bad = (do_d && !eob && !m_ok) || (st != kStop && opos_now > io.osize);
+        if (split || m_ok) stage_entry(split ? make_entry2(255, 0, 1) : m_e);
+        lit_mark = split ? lit_mark + 255u : m_ok ? n_lit : lit_mark;
+        bitpos += m_ok ? m_bits : 0u;
+        opos += m_ok ? m_len : 0u;
+        st = do_d ? (eob ? kStop : kNone) : st;
+        if (bad) { err = 1; st = kStop; active = false; }
+        }
+    } while (wave_any(st != kStop));
+    }
 
     // ---- one block ------------------------------------------------------------------------------------------------------
     SBX_HD LaneResult run(const LaneIo& io, uint8_t* W_, uint32_t lane, const uint16_t* len_tab_, const uint32_t* dist_tab_) {
@@ -587,102 +648,13 @@ struct Lane {
                 info[2 + n_seg] = n_lit;
                 ++n_seg;
             }
-            // wave-uniform: which pairs of code lengths nobody needs
-            CodeFlags F;
+            // wave-uniform: can the whole wavefront run the plain form of the loop?
+            bool plain = lit_no12 && lit_in14 && dist_no12 && dist_in12;
 #if defined(__HIP_DEVICE_COMPILE__)
-            F.lit_no12 = __builtin_amdgcn_readfirstlane(__all(!huff || lit_no12) ? 1u : 0u);
-            F.lit_in14 = __builtin_amdgcn_readfirstlane(__all(!huff || lit_in14) ? 1u : 0u);
-            F.dist_no12 = __builtin_amdgcn_readfirstlane(__all(!huff || dist_no12) ? 1u : 0u);
-            F.dist_in12 = __builtin_amdgcn_readfirstlane(__all(!huff || dist_in12) ? 1u : 0u);
-            // (opaque scalar values from here on: the compiler would otherwise turn them back into lane masks and select)
-            SBX_SCALAR_FLAG(F.lit_no12); SBX_SCALAR_FLAG(F.lit_in14); SBX_SCALAR_FLAG(F.dist_no12); SBX_SCALAR_FLAG(F.dist_in12);
-#else
-            F.lit_no12 = lit_no12; F.lit_in14 = lit_in14; F.dist_no12 = dist_no12; F.dist_in12 = dist_in12;
+            plain = __builtin_amdgcn_readfirstlane(__all(!huff || plain) ? 1u : 0u) != 0u;
 #endif
-            // ---- symbol loop --------------------------------------------------------------------------------------------
-            // An iteration: up to two literal/length symbols per lane (literals are pushed on the spot, the first other symbol stops the
-            // lane's run and stays pending), then for the pending one at most one entry: the match (length extra bits, distance code,
-            // distance extra bits), or -- when 255 literals have piled up -- a literal-run entry, the match waiting one more iteration.
-            // st: kNone = decoding, nothing pending; < 32 = a non-literal symbol is pending (its index in the canonical list); kStop = the lane
-            // is not (any longer) in this deflate block
-            uint32_t st = huff ? kNone : kStop;
-            // (two iterations per turn of the loop: the input is served in the first, the token store issued in the second)
-            if (wave_any(st != kStop)) do {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                if (half == 0) service(); else flush_one();
-                const bool input = have_input();
-                const uint32_t n_lit0 = n_lit;
-                if (st == kNone && input) {
-                    // both symbols are decoded back to back -- the second one speculatively: it counts only if the first was a literal -- so that
-                    // their table reads are in flight together and nothing below is control flow
-                    const uint32_t w = window32(bitpos);
-                    const uint32_t v1 = brev32(w) >> 17;
-                    const uint32_t acc1 = decode_lit(CL, v1, F);
-                    const uint32_t len1 = (acc1 >> 13) + 1u;                        // complete code: <= 15
-                    const uint32_t a1 = h16(kOffAux, len1);
-                    const uint32_t v2 = brev32(w >> len1) >> 17;
-                    const uint32_t acc2 = decode_lit(CL, v2, F);
-                    const uint32_t len2 = (acc2 >> 13) + 1u;
-                    const uint32_t a2 = h16(kOffAux, len2);
-                    const uint32_t idx1 = ((v1 >> (15u - len1)) + acc1) & 0x1FFu, idx2 = ((v2 >> (15u - len2)) + acc2) & 0x1FFu;
-                    const uint32_t litend1 = a1 & 0x1FFu, E1 = a1 >> 9, litend2 = a2 & 0x1FFu, E2 = a2 >> 9;
-                    const bool lit1 = idx1 < litend1, lit2 = lit1 && idx2 < litend2;
-                    {
-                        const uint32_t nlo = alignbit(hi, lo, 8), nhi = alignbit(idx1 - E1, hi, 8);
-                        lo = lit1 ? nlo : lo;
-                        hi = lit1 ? nhi : hi;
-                    }
-                    {
-                        const uint32_t nlo = alignbit(hi, lo, 8), nhi = alignbit(idx2 - E2, hi, 8);
-                        lo = lit2 ? nlo : lo;
-                        hi = lit2 ? nhi : hi;
-                    }
-                    n_lit += (lit1 ? 1u : 0u) + (lit2 ? 1u : 0u);
-                    bitpos += len1 + (lit1 ? len2 : 0u);
-                    const uint32_t j1 = (idx1 - litend1 + E1) & 31u, j2 = (idx2 - litend2 + E2) & 31u;
-                    st = !lit1 ? j1 : !lit2 ? j2 : kNone;
-                }
-                stage_lit_dword(n_lit0);
-                const uint32_t opos_now = opos + n_lit;
-                const uint32_t run_len = n_lit - lit_mark;
-                const bool split = run_len >= 255u;              // (also for a lane that waits for the others: they are 255 literals all the same)
-                const bool do_d = !split && st < 32u && input;
-                bool eob = false, m_ok = false;
-                uint32_t m_e = 0, m_bits = 0, m_len = 0;
-                if (do_d) {
-                    const uint32_t s5 = b8(kOffLenSym, st < (uint32_t)kSymEntries ? st : 0u);   // symbol - 256: 0 end of block, 1..29 length codes
-                    const uint32_t lt = len_tab[(s5 - 1u) & 31u];
-                    uint64_t w64 = window64(bitpos);
-                    const uint32_t le = lt >> 9, lb = lt & 0x1FFu;
-                    const uint32_t mlen = lb + bfe((uint32_t)w64, 0, le);
-                    w64 >>= le;
-                    const uint32_t dv = brev32((uint32_t)w64) >> 17;
-                    const uint32_t acc = decode_dist(CD, dv, F);
-                    const uint32_t dm1 = acc >> 13;                           // 15: no such code
-                    const uint32_t dl = dm1 + 1u;
-                    const uint32_t didx = ((dv >> ((14u - (dm1 & 15u)) & 31u)) + acc) & 0x1FFu;
-                    const uint32_t dsym = b8(kOffDistSym, didx < (uint32_t)kSymEntries ? didx : 0u);
-                    const uint32_t dt = dist_tab[dsym & 31u];
-                    w64 >>= dl;
-                    const uint32_t de = dt >> 16, db = dt & 0xFFFFu;
-                    const uint32_t dist = db + bfe((uint32_t)w64, 0, de);
-                    eob = s5 == 0u && st < (uint32_t)kSymEntries;
-                    // (a distance code that exists has an index below the number of codes, its symbol is below 30 by construction)
-                    m_ok = st < (uint32_t)kSymEntries && s5 - 1u < 29u && dm1 <= 14u && didx < (uint32_t)kSymEntries && dist <= opos_now && opos_now + mlen <= io.osize;
-                    m_e = make_entry2(run_len, mlen, dist);
-                    m_bits = le + dl + de;
-                    m_len = mlen;
-                }
-                const bool bad = (do_d && !eob && !m_ok) || (st != kStop && opos_now > io.osize);
-                if (split || m_ok) stage_entry(split ? make_entry2(255, 0, 1) : m_e);
-                lit_mark = split ? lit_mark + 255u : m_ok ? n_lit : lit_mark;
-                bitpos += m_ok ? m_bits : 0u;
-                opos += m_ok ? m_len : 0u;
-                st = do_d ? (eob ? kStop : kNone) : st;
-                if (bad) { err = 1; st = kStop; active = false; }
-                }
-            } while (wave_any(st != kStop));
+            if (plain) symbol_loop<true>(CL, CD, io, huff, err, active);
+            else symbol_loop<false>(CL, CD, io, huff, err, active);
             if (active && bitpos - lead_bits > io.in_bits) { err = 1; active = false; }
             if (active && last) active = false;
         }
