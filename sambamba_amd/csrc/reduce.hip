@@ -130,20 +130,50 @@ __device__ bool has_good_base(const uint8_t* U, const RecDesc& d, uint32_t min_b
 }
 
 // window mode: windows [k*w, (k+1)*w), k < n_win[ref]; id = win_base[ref] + k
+// One lane per record.  The records are sorted by position, so the 64 records of a wavefront fall into two or three windows and a plain
+// atomicAdd per record hammers the same few counters from every lane (617 M records: 73 ms of a whole-genome pass, profiles/round4
+// call L).  The lanes of a wavefront therefore add up runs of equal counter addresses among themselves -- leaders by comparing with the
+// previous lane, run lengths out of the leaders' ballot -- and only the leader of a run touches memory: a few atomics per wavefront.
+// The first window of a record goes this way, and so does the second one of a record that straddles a window edge; whatever is left
+// (alignments longer than a window) is counted record by record.
+__device__ __forceinline__ void add_runs(uint32_t* base, uint64_t slot, bool on, uint32_t lane) {
+    // slot: index of the counter this lane adds 1 to (when on)
+    const uint64_t prev = __shfl_up(slot, 1, 64);
+    const bool prev_on = __shfl_up(on ? 1 : 0, 1, 64) != 0;
+    const bool leader = on && (lane == 0 || !prev_on || prev != slot);
+    const uint64_t lead = __ballot(leader), act = __ballot(on);
+    if (leader) {
+        // the run ends in front of the next leader or the first inactive lane above this one
+        const uint64_t above = ~0ull << lane << 1;                    // lanes > lane (lane 63: 0)
+        const uint64_t stop = (lead | ~act) & above;
+        const uint32_t end = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+        atomicAdd(base + slot, end - lane);
+    }
+}
 __global__ __launch_bounds__(kRedThreads) void k_count_reads_windows(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, uint64_t n_records, const int32_t* __restrict__ rec_ref,
     uint32_t window, const uint64_t* __restrict__ win_base, const uint64_t* __restrict__ n_win, uint32_t S, uint32_t min_bq,
     uint32_t* n_reads /*[id][S]*/) {
     const uint64_t i = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x;
-    if (i >= n_records) return;
-    const RecDesc d = desc[i];
-    if (d.kind == 0) return;
-    const int32_t ref = rec_ref[i];
-    const uint64_t k0 = (uint64_t)d.pos / window, k1 = (uint64_t)(d.end - 1) / window;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool live = i < n_records;
+    RecDesc d{};
+    if (live) d = desc[i];
+    const bool adm = live && d.kind != 0;
+    const int32_t ref = adm ? rec_ref[i] : 0;
+    const uint64_t k0 = adm ? (uint64_t)d.pos / window : 0, k1 = adm ? (uint64_t)(d.end - 1) / window : 0;
+    const uint64_t nw = adm ? n_win[ref] : 0, wb = adm ? win_base[ref] : 0;
     const uint32_t s = S > 1 ? d.sample : 0u;
-    for (uint64_t k = k0; k <= k1 && k < n_win[ref]; ++k)
-        if (has_good_base(U, d, min_bq, (int64_t)(k * window), (int64_t)((k + 1) * window)))
-            atomicAdd(&n_reads[(size_t)(win_base[ref] + k) * S + s], 1u);
+    // first window, second window: wave-aggregated
+    const bool on0 = adm && k0 < nw && has_good_base(U, d, min_bq, (int64_t)(k0 * window), (int64_t)((k0 + 1) * window));
+    add_runs(n_reads, (wb + k0) * S + s, on0, lane);
+    const bool on1 = adm && k1 > k0 && k0 + 1 < nw && has_good_base(U, d, min_bq, (int64_t)((k0 + 1) * window), (int64_t)((k0 + 2) * window));
+    if (__any(adm && k1 > k0)) add_runs(n_reads, (wb + k0 + 1) * S + s, on1, lane);
+    // further windows of a long alignment
+    if (adm)
+        for (uint64_t k = k0 + 2; k <= k1 && k < nw; ++k)
+            if (has_good_base(U, d, min_bq, (int64_t)(k * window), (int64_t)((k + 1) * window)))
+                atomicAdd(&n_reads[(size_t)(wb + k) * S + s], 1u);
 }
 
 // region mode: regions sorted by (ref, start); pmax_end[j] = max end over the contig's regions 0..j
