@@ -266,8 +266,14 @@ def allreduce_base_counters(d, dist, world, rank, red_dev, windows=(), steps=3, 
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms_run, ms_red = float(t[0].item()) * 1e3, float(t[1].item()) * 1e3
-    return {"ms_owned_run": round(ms_run, 3), "ms_export_and_allreduce": round(ms_red, 3), "ms_per_step": round(ms_run + ms_red, 3),
-            "allreduce_bytes_per_rank": int(nbytes), "allreduce_GBps_per_rank": round(nbytes / max(1e-9, ms_red * 1e-3) / 1e9, 2),
+    # the collective's time means something over RCCL (device tensors over xGMI) only: through gloo the counters travel through host
+    # memory and a loopback socket -- the results are still checked, the time is not reported
+    on_rccl = str(red_dev).startswith("cuda")
+    return {"ms_owned_run": round(ms_run, 3), "ms_export_and_allreduce": round(ms_red, 3) if on_rccl else None,
+            "ms_per_step": round(ms_run + ms_red, 3) if on_rccl else None,
+            "allreduce_bytes_per_rank": int(nbytes),
+            "allreduce_GBps_per_rank": round(nbytes / max(1e-9, ms_red * 1e-3) / 1e9, 2) if on_rccl else None,
+            "collective_backend": "rccl" if on_rccl else "gloo (host memory: not timed)",
             "steps": steps, "piece_positions": piece, "windows": picked,
             "what": "reads partitioned between the ranks by start position (sbx_run_interval_owned), every rank counts all positions its "
                     "reads cover, int32 all-reduce (SUM) of the u32[L][S][7] counter array in pieces, device to device"}

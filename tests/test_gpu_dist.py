@@ -113,10 +113,30 @@ def test_bench_multi_rank_line(tmp_path, mode):
         ar = d["allreduce_option"]
         assert ar and "error" not in ar, ar
         assert ar["parity_ok"] and ar["allreduce_bytes_per_rank"] > 0
+        assert ar["ms_export_and_allreduce"] is None and "gloo" in ar["collective_backend"]      # a collective through host memory is not a number
     elif mode == "strong":
         assert d["scaling"] == "strong" and d["strong_one_contig"] is None and d["reads_total"] == 600000
     else:
         assert d["scaling"] == "weak" and d["reads_total"] == 2 * 600000
+
+
+@pytest.mark.parametrize("cfg", ["3", "4"])
+def test_bench_multi_rank_whole_genome(tmp_path, cfg):
+    """The north star's scaling input: `bench.py --gpus N --config 3` (whole genome, window mode) and `--config 4` (exome regions on
+    it) -- ONE BAM sharded by position over the ranks (here two ranks on the box's GPU over gloo, a 1/500 genome)."""
+    import json
+    env = dict(os.environ, SBX_BENCH_BACKEND="gloo", PYTHONPATH=ROOT, TMPDIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "2987" + str(3 + int(cfg)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", cfg, "--scale", "0.002", "--no-cpu-baseline", "--no-e2e", "--parity-windows", "4"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_checked"]["ok"] and d["parity_checked"]["ok_all_ranks"]
+    assert "accounting_error" not in d and "sharded over the ranks" in d["config"]["sharding"]
+    assert d["metric"] == ("depth_window_Mreads_per_s" if cfg == "3" else "depth_region_Mreads_per_s")
 
 
 # ---- round 3: per-rank output ranges, the all-reduce form, RCCL at world size 1, data-driven mate slack ------------------
