@@ -261,6 +261,8 @@ def cli_e2e(bam, mode_args, reads):
     try:
         runs, det = [], []
         for k in range(3):
+            if k:
+                time.sleep(3.0)      # (a process started right behind another one's teardown waits for the driver to scrub the freed memory)
             runs.append(once(dict(os.environ, SBX_TIMING="1")))
         for k in range(2):
             time.sleep(3.0)
