@@ -745,7 +745,8 @@ PMC_KERNELS = {"huffman_decode": ["k_huffman_decode", "k_huffman_decode2", "k_tr
                "lz77_resolve": ["k_lz77_resolve", "k_lz77_resolve_o32", "k_lz77_resolve_o32_w8", "k_lz77_resolve_o32_u", "k_lz77_resolve_o32_f",
                                 "k_lz77_resolve_o32_uf", "k_lz77_resolve_o32_uf_w8"],
                "record_index": ["k_walk_blocks", "k_check_scan", "k_describe_blocks", "k_tile_compact", "k_chain_repair", "k_rewalk_mismatched"],
-               "decode_accumulate": ["k_accumulate16", "k_accumulate16b", "k_accumulate16c", "k_accumulate"]}
+               "decode_accumulate": ["k_accumulate16", "k_accumulate16b", "k_accumulate16c", "k_accumulate", "k_accumulate_mates", "k_find_mates",
+                                     "k_find_partners", "k_mates_columns", "k_max_u32"]}
 
 
 def pmc_table(config=2):
