@@ -137,6 +137,69 @@ __global__ __launch_bounds__(kMateThreads) void k_find_mates(const uint8_t* __re
         }
 }
 
+// The same links through a hash JOIN (round 4): the scan above reads a few hundred window entries per record at
+// 300x to find the one or two with its hash.  Here the workgroup puts the admitted records of its window into an open-addressing
+// table in LDS keyed by the half hash (2,048 slots for <= 1,024 entries: mates share a key and sit in neighbouring slots), and a
+// record probes for its own key: two or three slots instead of three hundred entries.  A candidate links under the scan's conditions
+// -- it lies behind the record in the file, on the same reference, and starts inside the record's span (the scan stops at the first
+// entry that does not; the file is sorted, so that is the same set) -- and a span that reaches beyond the window is finished in
+// global memory as before.
+constexpr uint32_t kJoinSlots = 2048;
+__global__ __launch_bounds__(kMateThreads) void k_find_mates_join(const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc,
+                                                                   const uint64_t* __restrict__ hash, const int32_t* __restrict__ rec_ref,
+                                                                   uint64_t n, uint32_t* mate, uint32_t* n_partners) {
+    __shared__ int32_t s_pos[kFindWin];
+    __shared__ uint32_t s_h[kFindWin], s_ref[kFindWin];
+    __shared__ uint32_t t_key[kJoinSlots], t_val[kJoinSlots];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kMateThreads;
+    for (uint32_t k = threadIdx.x; k < kJoinSlots; k += kMateThreads) t_val[k] = 0xFFFFFFFFu;
+    for (uint32_t k = threadIdx.x; k < kFindWin; k += kMateThreads) {
+        const uint64_t j = i0 + k;
+        if (j < n) {
+            const RecDesc d = desc[j];
+            s_pos[k] = d.pos;
+            s_h[k] = (uint32_t)hash[j];
+            s_ref[k] = ((uint32_t)rec_ref[j] & 0x7FFFFFFFu) | (d.kind == 0 ? 0x80000000u : 0u);
+        } else {
+            s_pos[k] = 0x7FFFFFFF;
+            s_h[k] = 0;
+            s_ref[k] = 0x7FFFFFFEu;      // no reference has this id
+        }
+    }
+    __syncthreads();
+    // insert: entry k of the window (k >= 1: entry 0 can only be somebody's predecessor, never a partner behind a record)
+    for (uint32_t k = threadIdx.x; k < kFindWin; k += kMateThreads) {
+        if (k == 0u || (s_ref[k] >> 31) || s_ref[k] == 0x7FFFFFFEu) continue;
+        const uint32_t key = s_h[k];
+        uint32_t slot = (key * 0x9E3779B1u) >> 21;
+        for (;;) {
+            if (atomicCAS(&t_val[slot], 0xFFFFFFFFu, k) == 0xFFFFFFFFu) { t_key[slot] = key; break; }
+            slot = (slot + 1u) & (kJoinSlots - 1u);
+        }
+    }
+    __syncthreads();
+    const uint64_t i = i0 + threadIdx.x;
+    if (i >= n) return;
+    const RecDesc a = desc[i];
+    if (a.kind == 0) return;
+    const uint64_t h = hash[i];
+    const int32_t ref = rec_ref[i];
+    const uint32_t ref_tag = (uint32_t)ref & 0x7FFFFFFFu, h32 = (uint32_t)h;
+    for (uint32_t slot = (h32 * 0x9E3779B1u) >> 21;; slot = (slot + 1u) & (kJoinSlots - 1u)) {
+        const uint32_t k = t_val[slot];
+        if (k == 0xFFFFFFFFu) break;
+        if (t_key[slot] == h32 && k > threadIdx.x && (s_ref[k] & 0x7FFFFFFFu) == ref_tag && s_pos[k] < a.end)
+            link_if_mates(U, desc, hash, a, h, i, i0 + k, mate, n_partners);
+    }
+    // the span reaches beyond the window: the rest in global memory
+    if ((s_ref[kFindWin - 1] & 0x7FFFFFFFu) == ref_tag && s_pos[kFindWin - 1] < a.end)
+        for (uint64_t j = i0 + kFindWin; j < n; ++j) {
+            const RecDesc b = desc[j];
+            if (rec_ref[j] != ref || b.pos >= a.end) break;
+            if (hash[j] == h) link_if_mates(U, desc, hash, a, h, i, j, mate, n_partners);
+        }
+}
+
 // Second pass, only when some record has more than one partner: up to three partners per record in ext[3 i ..],
 // in no particular order (n_partners is counted again; a fourth partner only raises the count).
 __global__ __launch_bounds__(kMateThreads) void k_find_partners(const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc,
@@ -645,8 +708,14 @@ __global__ __launch_bounds__(kMateThreads) void k_mates_columns(
 void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
                        uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream) {
     if (!n_records) return;
-    hipLaunchKernelGGL(k_find_mates, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
-                       d_U, d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
+    // SBX_K7_FIND=0: round 3's window scan; default: the hash join
+    static const int find = [] { const char* e = getenv("SBX_K7_FIND"); return e ? atoi(e) : 1; }();
+    if (find == 0)
+        hipLaunchKernelGGL(k_find_mates, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
+                           d_U, d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
+    else
+        hipLaunchKernelGGL(k_find_mates_join, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
+                           d_U, d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
     SBX_HIP(hipGetLastError());
 }
 
