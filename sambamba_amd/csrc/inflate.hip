@@ -8,22 +8,22 @@
 // Design (MI355X-first, not a zlib translation).  A BAM is hundreds of thousands of independent
 // small deflate streams, and DEFLATE has two very different halves, so it is split in two kernels:
 //
-//  K1a `huffman_decode`  -- entropy decoding is a serial dependency chain per stream, so the
+//  K1a `huffman_decode2` (round 4; the lane program lives in inflate2_core.hpp) + `huffman_decode` (round 3's kernel, now the
+//      GENERAL kernel for the blocks the fast one hands over) -- entropy decoding is a serial dependency chain per stream, so the
 //      mapping is ONE LANE PER BGZF BLOCK: 64 independent decoders per wavefront, every VALU
 //      instruction doing useful work in all lanes.  No lookup tables in memory for the code
 //      lengths: the 15 left-justified limits of the literal/length and the distance code live in
 //      VGPRs (two 16-bit limits per register) next to per-length deltas, and ONE accumulator of
 //      v_dot2_u32_u16 products yields both the code length (1 + sum_l (peek >= limit[l])) and the
 //      symbol-index delta -- 3 VALU ops per pair of lengths, branch-free, identical in every lane.
-//      Only the literal/length symbol permutation (288 x 9 bits, bit-packed: 324 B) and a
-//      32-byte ring of the lane's compressed input are in LDS: 356 B per lane at an 89-dword stride
-//      (odd => conflict-free for equal offsets), 7 waves per CU; distance symbols and the table-build
-//      counters are packed into VGPRs; base values and extra-bit counts of length / distance symbols come
-//      from two tables shared by the workgroup.  The ring is topped up by the whole wave in synchronous events,
-//      so that the decode loop never waits on a global load.  The decoder does NOT touch the LZ77
-//      window: it emits the literal bytes (16-byte stores out of a byte shift register) and one 32-bit
-//      entry {literals-before:8, distance-1:15, length:9} per match.  Nothing it loads depends on
-//      anything it stored, so the lane never waits on the LZ77 window's memory latency.
+//      The general kernel keeps the literal/length symbol permutation (288 x 9 bits, bit-packed: 324 B) and a
+//      32-byte ring of the lane's compressed input in LDS: 356 B per lane, 7 waves per CU.  The fast kernel decodes literal
+//      RANKS instead of literal bytes (k_translate_literals maps them afterwards) and needs 176 B per lane and <= 128 VGPRs:
+//      14 waves per CU, every wavefront of a chromosome resident at once; it issues ONE vector memory instruction per loop
+//      iteration (what such an instruction costs).  Neither decoder touches the LZ77
+//      window: they emit the literals (16-byte stores) and one 32-bit
+//      entry {literals-before:8, distance-1:15, length:9} per match.  Nothing a lane loads depends on
+//      anything it stored, so it never waits on the LZ77 window's memory latency.
 //
 //  K1b `lz77_resolve`    -- copying matches is data-parallel once positions are known, so the
 //      mapping is ONE WAVE PER BGZF BLOCK: 64 entries at a time, output offsets by a DPP prefix sum.
@@ -34,9 +34,9 @@
 //      FAR matches and literal runs come from global memory with every load of the batch in flight
 //      before the first store, and the finished span is written to HBM once, contiguously.
 //
-// Roofline: K1a is bound by the instruction issue of the serial decode chain, K1b by VALU issue;
-// neither is HBM-bandwidth bound and their GB/s are reported separately from the HBM-bound
-// accumulate kernel.
+// Roofline: both kernels are bound by instruction issue (K1b: the VALU port 91 % busy and 0.51 instructions per cycle and SIMD;
+// K1a: one instruction per four cycles with three to four waves per SIMD); neither is HBM-bandwidth bound and their GB/s are
+// reported for completeness (DESIGN.md sections 3 and 4).
 #include <cstdlib>
 
 #include "common.hpp"
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
 
 // ---- K1a, round 4: the fast kernel -------------------------------------------------------------------------------------
 // One lane per BGZF block, the lane program of inflate2_core.hpp (literal ranks instead of literal bytes, windows instead of a
-// bit buffer, build state in LDS): 164 bytes of LDS per lane and <= 128 VGPRs, so that 15 wavefronts share a CU (round 3's
+// bit buffer, build state in LDS): 176 bytes of LDS per lane and <= 128 VGPRs, so that 14 wavefronts share a CU (round 3's
 // kernel: 7) and the 3,379 wavefronts of a chromosome-sized file are resident at once.  Blocks it does not decode are flagged
 // kNeedsGeneral and decoded by k_huffman_decode in a second launch.
 constexpr int kInf2Threads = 64;

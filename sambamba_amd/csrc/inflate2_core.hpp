@@ -17,11 +17,14 @@
 //    lane-interleaved (dword j of lane i in bank i whatever j is): 14 waves per CU instead of 7.
 //  * Bits come from a window fetched at the absolute bit position (two ring dwords + v_alignbit / v_lshrrev_b64) instead of a
 //    64-bit buffer with a refill test in front of every symbol; literals are pushed into a 64-bit shift register (two
-//    v_alignbit per literal) and leave through a 16-byte staging area in LDS, match entries likewise: no register FIFOs.
+//    v_alignbit per literal) and leave through a 16-byte staging area in LDS, match entries through a ring of two groups: no register
+//    FIFOs.  ONE vector memory instruction per iteration: the input load and a store that serves both token streams alternate
+//    (flush_one, have_input) -- what such an instruction costs this kernel is in DESIGN.md section 3.
+//  * The symbol loop exists in a plain and a general form (decode_lit / decode_dist), picked per wavefront: no flag tests per symbol.
 //  * Everything the table build indexes dynamically (counters, insert positions) lives in LDS, not in compare-select chains
 //    over registers, so the build does not set the kernel's register budget (<= 128 VGPRs: 4 waves per SIMD).
 //  * Anything unusual -- stored blocks, over-subscribed or incomplete literal/length codes, more than kMaxSeg deflate blocks in a
-//    BGZF block, any error -- ends the lane with INF2_NEEDS_GENERAL and the block is decoded again by the general kernel, which
+//    BGZF block, any error -- ends the lane with kNeedsGeneral and the block is decoded again by the general kernel, which
 //    also produces the authoritative error status.  The fast kernel has to be exact on valid streams and has to NOTICE invalid
 //    ones; it never has to explain them.
 #pragma once
