@@ -4,9 +4,10 @@
 // <= 0xFF00-byte piece of the uncompressed BAM stream (bgzf/outputstream.d, bam/writer.d:67-287): one deflate stream +
 // CRC32 + ISIZE per block.  Like inflate, a BAM is hundreds of thousands of independent blocks, and LZ77 matching +
 // entropy coding of ONE block is a serial chain (every match decides where the next token starts), so the mapping is
-// again ONE LANE PER BGZF BLOCK -- 64 independent encoders per wavefront running sbx::deflate_fixed (deflate_core.hpp:
-// fixed Huffman code, greedy matches through a 4 KiB hash table of last positions kept in a per-block slice of global
-// scratch).  Every block is written into a 64 KiB slot; a scan of the block lengths and a coalesced copy (one
+// again ONE LANE PER BGZF BLOCK -- 64 independent encoders per wavefront running sbx::bgzf_block (deflate_core.hpp:
+// greedy matches through a 4 KiB hash table of last positions kept in a per-block slice of global scratch; by `level` stored, the
+// fixed Huffman code in one pass, or a dynamic Huffman code -- symbol counts, code construction and a second pass over the
+// input, its tables in a second 4 KiB slice per block).  Every block is written into a 64 KiB slot; a scan of the block lengths and a coalesced copy (one
 // workgroup per block) then pack the slots into the BGZF stream.
 // Bound: memory latency (every hash probe and window compare of a lane is its own cache line); it is a writer for
 // harness-sized and production files alike, not a roofline kernel -- DESIGN.md reports its GB/s next to zlib's.
@@ -22,7 +23,7 @@ constexpr int kDefThreads = 64;
 
 __global__ __launch_bounds__(kDefThreads) void k_bgzf_deflate(const uint8_t* __restrict__ in, uint64_t n_bytes, uint32_t n_blocks, int level,
                                                               uint8_t* __restrict__ slots, uint16_t* __restrict__ tables,
-                                                              uint32_t* __restrict__ block_len) {
+                                                              uint8_t* __restrict__ work, uint32_t* __restrict__ block_len) {
     __shared__ uint32_t crc_table[256];
     for (uint32_t k = threadIdx.x; k < 256; k += kDefThreads) crc32_make_entry(crc_table, k);
     __syncthreads();
@@ -30,7 +31,8 @@ __global__ __launch_bounds__(kDefThreads) void k_bgzf_deflate(const uint8_t* __r
     if (b >= n_blocks) return;
     const uint64_t off = (uint64_t)b * kBgzfPayload;
     const uint32_t n = (uint32_t)(n_bytes - off < kBgzfPayload ? n_bytes - off : kBgzfPayload);
-    block_len[b] = bgzf_block(in + off, n, level, slots + (size_t)b * kBgzfSlot, tables + ((size_t)b << kHashBits), crc_table);
+    block_len[b] = bgzf_block(in + off, n, level, slots + (size_t)b * kBgzfSlot, tables + ((size_t)b << kHashBits),
+                              (DynWork*)(work + (size_t)b * kWorkBytes), crc_table);
 }
 
 // block b: block_len[b] bytes from its slot to out + offset[b]
@@ -64,13 +66,14 @@ __global__ __launch_bounds__(256) void k_gather_bins(const uint8_t* __restrict__
 }  // namespace
 
 size_t deflate_table_entries(uint32_t n_blocks) { return (size_t)n_blocks << kHashBits; }
+size_t deflate_work_bytes(uint32_t n_blocks) { return (size_t)n_blocks * kWorkBytes; }
 
 void launch_bgzf_deflate(const uint8_t* d_in, uint64_t n_bytes, uint32_t n_blocks, int level, uint8_t* d_slots, uint16_t* d_tables,
-                         uint32_t* d_block_len, hipStream_t stream) {
+                         uint8_t* d_work, uint32_t* d_block_len, hipStream_t stream) {
     if (!n_blocks) return;
     SBX_HIP(hipMemsetAsync(d_tables, 0, deflate_table_entries(n_blocks) * 2, stream));
     hipLaunchKernelGGL(k_bgzf_deflate, dim3((n_blocks + kDefThreads - 1) / kDefThreads), dim3(kDefThreads), 0, stream, d_in, n_bytes,
-                       n_blocks, level, d_slots, d_tables, d_block_len);
+                       n_blocks, level, d_slots, d_tables, d_work, d_block_len);
     SBX_HIP(hipGetLastError());
 }
 

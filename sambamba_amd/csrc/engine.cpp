@@ -1460,6 +1460,7 @@ void bgzf_compress_stream(const uint8_t* in, size_t n, int level, Sink&& sink) {
     const uint32_t cap_blocks = (uint32_t)std::min<size_t>(piece_blocks, std::max<size_t>(1, n_blocks_total));
     DevBuf<uint8_t> d_in((size_t)cap_blocks * kBgzfPayload + 64), d_slots((size_t)cap_blocks * kBgzfSlot), d_out((size_t)cap_blocks * kBgzfSlot);
     DevBuf<uint16_t> d_tab(deflate_table_entries(cap_blocks));
+    DevBuf<uint8_t> d_work(deflate_work_bytes(cap_blocks));
     DevBuf<uint32_t> d_len(cap_blocks + 1);
     DevBuf<uint64_t> d_off((size_t)cap_blocks + 2);
     std::vector<uint8_t> host;
@@ -1475,7 +1476,7 @@ void bgzf_compress_stream(const uint8_t* in, size_t n, int level, Sink&& sink) {
         if (timing) SBX_HIP(hipStreamSynchronize(s));
         const double w1 = wall_now();
         t_def.start(s);
-        launch_bgzf_deflate(d_in.p, bytes, nb, level, d_slots.p, d_tab.p, d_len.p, s);
+        launch_bgzf_deflate(d_in.p, bytes, nb, level, d_slots.p, d_tab.p, d_work.p, d_len.p, s);
         t_def.stop(s);
         t_pack.start(s);
         launch_count_scan(d_len.p, nb, d_off.p, nullptr, 0, s);

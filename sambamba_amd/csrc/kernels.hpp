@@ -220,8 +220,9 @@ void launch_merge_tiles(const uint32_t* d_src, const uint32_t* d_src_active, uin
 
 // ---- BGZF writer (deflate.hip): one lane per <= 0xFF00-byte block -> 64 KiB slots -> packed stream; record bins for the BAI
 size_t deflate_table_entries(uint32_t n_blocks);
+size_t deflate_work_bytes(uint32_t n_blocks);          // the dynamic-Huffman tables of the blocks in flight (deflate_core.hpp DynWork)
 void launch_bgzf_deflate(const uint8_t* d_in, uint64_t n_bytes, uint32_t n_blocks, int level, uint8_t* d_slots, uint16_t* d_tables,
-                         uint32_t* d_block_len, hipStream_t stream);
+                         uint8_t* d_work, uint32_t* d_block_len, hipStream_t stream);
 void launch_pack_blocks(const uint8_t* d_slots, const uint32_t* d_block_len, const uint64_t* d_offset, uint32_t n_blocks, uint8_t* d_out,
                         hipStream_t stream);
 void launch_gather_bins(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, uint16_t* d_bins, hipStream_t stream);

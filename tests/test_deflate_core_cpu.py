@@ -1,7 +1,9 @@
-"""The BGZF block encoder the device runs one lane per block (sambamba_amd/csrc/deflate_core.hpp: fixed Huffman code, greedy
-LZ77, CRC32, stored fallback), compiled for the host with g++ and checked against zlib: every stream must inflate to its
-input with correct CRC32 / ISIZE trailers (gzip.decompress verifies both) -- no GPU needed."""
+"""The BGZF block encoder the device runs one lane per block (sambamba_amd/csrc/deflate_core.hpp: stored / fixed Huffman code /
+dynamic Huffman code by level, hash-table LZ77, CRC32, stored fallback), compiled for the host with g++ and checked against
+zlib: every stream must inflate to its input with correct CRC32 / ISIZE trailers (gzip.decompress verifies both) -- no GPU
+needed."""
 import gzip
+import heapq
 import os
 import random
 import struct
@@ -48,13 +50,34 @@ CASES = {
     "block_plus_one": None,
     "all_bytes": bytes(range(256)) * 600,
     "long_matches": (bytes(range(200)) * 2 + b"x") * 400,
+    "two_symbols": b"ab" * 5,                               # shorter than a match: literals only, no distance code in use
+    "nibbles": None,                                        # 16 equally likely literals, hardly a match: the dynamic code's home ground
+    "skewed": None,                                         # literal counts like Fibonacci numbers: code lengths hit the 15-bit limit
+    "zeros_then_noise": None,
 }
+LEVELS = [0, 1, 3, 4, 6, 7, 9, -1]
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("level", [0, 6, -1])
+def skewed(seed):
+    rng = random.Random(seed)
+    fib = [1, 1]
+    while len(fib) < 22:
+        fib.append(fib[-1] + fib[-2])
+    pool = b"".join(bytes([40 + k]) * f for k, f in enumerate(fib))     # 46367 bytes, 22 symbols, the rarest once
+    return bytes(rng.sample(pool, len(pool)))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("level", LEVELS)
 def test_host_encoder_round_trips_through_zlib(host_encoder, tmp_path, name, level):
     data = CASES[name]
+    if name == "nibbles":
+        data = bytes(random.Random(7).choices(range(16), k=150000))
+    elif name == "skewed":
+        data = skewed(8)
+    elif name == "zeros_then_noise":
+        data = bytes(30000) + random.Random(9).randbytes(30000) + bytes(30000)
     if name == "bam_like":
         data = bam_like(300000, 3)
     elif name == "random":
@@ -80,5 +103,101 @@ def test_host_encoder_round_trips_through_zlib(host_encoder, tmp_path, name, lev
     assert (gzip.decompress(comp) if comp else b"") == data
     if level and name in ("run", "period3", "text", "bam_like", "long_matches"):
         assert len(comp) < len(data) * (0.75 if name == "bam_like" else 0.2), (len(comp), len(data))
+    if name == "nibbles" and (level >= 4 or level == -1):
+        assert len(comp) < len(data) * 0.52                 # 4 bits of entropy per byte; the fixed code spends 8 on a literal
     if name == "random" or level == 0:
         assert len(comp) <= len(data) + n_blocks * 31       # stored fallback: 5 + 26 bytes per block
+
+
+def test_levels_trade_work_for_bytes(host_encoder, tmp_path):
+    """bgzfCompress passes `level` to zlib (compress.d:34-103): here 1..3 = fixed code, 4..6 and -1 = dynamic code, 7..9 = dynamic
+    code over four candidates per position with lazy evaluation; each step must pay on a BAM-like stream."""
+    data = bam_like(400000, 11)
+    src = str(tmp_path / "in")
+    open(src, "wb").write(data)
+    size = {}
+    for level in (0, 1, 3, 4, 6, -1, 7, 9):
+        dst = str(tmp_path / ("out%d" % level))
+        subprocess.check_call([host_encoder, src, dst, str(level)])
+        comp = open(dst, "rb").read()
+        assert gzip.decompress(comp) == data
+        size[level] = len(comp)
+    assert size[1] == size[3] and size[4] == size[6] == size[-1] and size[7] == size[9]
+    assert size[0] > size[1] > size[4] > size[7]
+    assert size[4] < 0.85 * size[1]
+
+
+def _optimal_cost(freqs):
+    heap = [f for f in freqs if f]
+    heapq.heapify(heap)
+    cost = 0
+    while len(heap) > 1:
+        a, b = heapq.heappop(heap), heapq.heappop(heap)
+        cost += a + b
+        heapq.heappush(heap, a + b)
+    return cost
+
+
+def _lengths(host_encoder, max_len, freqs):
+    out = subprocess.check_output([host_encoder, "--lengths", str(max_len)] + [str(f) for f in freqs]).decode().split()
+    return [tuple(int(x) for x in t.split(":")) for t in out]
+
+
+def test_code_lengths_are_minimum_redundancy_and_limited(host_encoder):
+    """huffman_lengths: without the limit in play the cost equals Huffman's; with it the code stays complete (Kraft sum 1), within
+    the limit, and prefix-free as canonical codes."""
+    rng = random.Random(5)
+    cases = [[1, 1], [5, 1, 1, 2, 3, 0, 8], [1] * 19, [1] * 286, [65280, 1], [0, 0, 7, 0, 0, 9]]
+    fib = [1, 1]
+    while len(fib) < 30:
+        fib.append(fib[-1] + fib[-2])
+    cases.append(fib[:22])                                                 # depth 21 without a limit
+    for _ in range(40):
+        n = rng.choice((2, 3, 19, 30, 286))
+        cases.append([rng.choice((0, 0, 1, 2, 5, 40, 300, 5000)) for _ in range(n)])
+    for freqs in cases:
+        if sum(1 for f in freqs if f) < 2:
+            continue
+        for max_len in (15, 7):
+            used = sum(1 for f in freqs if f)
+            if used > (1 << max_len):
+                continue
+            res = _lengths(host_encoder, max_len, freqs)
+            lens = [l for l, _ in res]
+            assert all((l > 0) == (f > 0) for l, f in zip(lens, freqs))
+            assert max(lens) <= max_len
+            assert sum(2.0 ** -l for l in lens if l) == 1.0
+            cost = sum(l * f for l, f in zip(lens, freqs))
+            opt = _optimal_cost(freqs)
+            assert cost >= opt
+            unlimited = _lengths(host_encoder, 15, freqs) if max_len != 15 else res
+            if max(l for l, _ in unlimited) < 15 and max_len == 15:
+                assert cost == opt, (freqs, lens)
+            # canonical codes (stored bit-reversed): no code is a prefix of another
+            words = sorted(format(c, "0%db" % l)[::-1] for l, c in res if l)
+            assert all(not b.startswith(a) for a, b in zip(words, words[1:]))
+
+
+def test_random_mixtures_round_trip_at_every_level(host_encoder, tmp_path):
+    rng = random.Random(2026)
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    for trial in range(24):
+        parts = []
+        for _ in range(rng.randrange(1, 12)):
+            kind = rng.randrange(5)
+            if kind == 0:
+                parts.append(rng.randbytes(rng.randrange(1, 30000)))
+            elif kind == 1:
+                parts.append(bytes([rng.randrange(256)]) * rng.randrange(1, 40000))
+            elif kind == 2:
+                unit = rng.randbytes(rng.randrange(1, 600))
+                parts.append(unit * rng.randrange(1, 80))
+            elif kind == 3:
+                parts.append(bytes(rng.choices(range(rng.randrange(1, 40)), k=rng.randrange(1, 30000))))
+            else:
+                parts.append(bam_like(rng.randrange(1, 60000), trial))
+        data = b"".join(parts)
+        open(src, "wb").write(data)
+        for level in (1, 6, 9):
+            subprocess.check_call([host_encoder, src, dst, str(level)])
+            assert gzip.decompress(open(dst, "rb").read()) == data, (trial, level)

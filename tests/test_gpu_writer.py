@@ -16,7 +16,7 @@ import pytest
 
 import sambamba_amd
 from tests import bamgen as bg
-from tests.test_deflate_core_cpu import SRC as HOST_SRC, bam_like
+from tests.test_deflate_core_cpu import SRC as HOST_SRC, bam_like, skewed
 from tests.util import ROOT, gen_bam, run_cli, run_oracle
 
 pytestmark = pytest.mark.gpu
@@ -37,11 +37,13 @@ WRITER_CASES = {
     "random": lambda: random.Random(2).randbytes(300_000),
     "exact_blocks": lambda: bam_like(2 * 0xFF00, 12),
     "one_over": lambda: bam_like(0xFF00 + 1, 13),
+    "nibbles": lambda: bytes(random.Random(3).choices(range(16), k=200_000)),        # literals only: the dynamic code's home ground
+    "skewed": lambda: skewed(4) * 3,                                                  # code lengths hit the 15-bit limit
 }
 
 
 @pytest.mark.parametrize("name", sorted(WRITER_CASES))
-@pytest.mark.parametrize("level", [6, 0, -1])
+@pytest.mark.parametrize("level", [1, 6, 9, 0, -1])
 def test_device_bgzf_stream_inflates_and_equals_the_host_encoder(host_encoder, tmp_path, name, level):
     data = WRITER_CASES[name]()
     comp = sambamba_amd.bgzf_compress(data, level=level, with_eof=True)
@@ -63,6 +65,16 @@ def test_default_level_compresses_and_bad_levels_are_rejected():
         with pytest.raises(sambamba_amd.SbxError) as ei:
             sambamba_amd.bgzf_compress(data, level=bad)
         assert ei.value.code == -1        # SBX_EINVAL
+
+
+def test_levels_trade_work_for_bytes():
+    """compress.d:34-103 hands `level` to zlib; here 1..3 = fixed code, 4..6 / -1 = dynamic code, 7..9 = dynamic code over four
+    candidates per position with lazy evaluation (deflate_core.hpp)."""
+    data = bam_like(2_000_000, 31)
+    size = {lv: len(sambamba_amd.bgzf_compress(data, level=lv)) for lv in (0, 1, 3, 4, 6, 7, 9)}
+    assert size[1] == size[3] and size[4] == size[6] and size[7] == size[9]
+    assert size[0] > size[1] > size[4] > size[7]
+    assert size[4] < 0.85 * size[1]
 
 
 def test_many_blocks_in_several_pieces():

@@ -90,6 +90,24 @@ def test_bench_like_bam_every_block(harness, tmp_path):
     assert blocks > 600 and general == 0
 
 
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_streams_of_the_device_encoder_are_the_fast_kernels(harness, tmp_path, level):
+    """What sbx_write_bam / sbx_bgzf_compress write (deflate_core.hpp: fixed code at level 1, dynamic codes from level 4, complete
+    codes with at least two symbols each) is read back by the fast kernel alone -- a BAM written by the device encoder costs the read
+    path no detour through the general kernel."""
+    import gzip
+    enc = str(tmp_path / "deflate_host")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", enc, os.path.join(ROOT, "tests", "native", "deflate_host.cpp")])
+    bam = gen_bam(str(tmp_path / "b.bam"), "chrB:120000", coverage=30, seed=9)
+    raw = gzip.decompress(open(bam, "rb").read())
+    src, dst = str(tmp_path / "raw"), str(tmp_path / "enc.bgzf")
+    for data in (raw, b"ab" * 5 + bytes(70000), bytes(np.random.default_rng(1).integers(0, 16, 100000, dtype=np.uint8))):
+        open(src, "wb").write(data)
+        subprocess.check_call([enc, src, dst, str(level)])
+        blocks, fast, general = _run(harness, dst, lane=11)
+        assert blocks == (len(data) + 0xFF00 - 1) // 0xFF00 and general == 0
+
+
 def test_lanes_use_disjoint_lds():
     """The lane-interleaved layout: no two lanes' bytes overlap, every lane's area lies inside the wavefront's."""
     import re
