@@ -142,10 +142,12 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
 
 /* The write side of the same seam: bgzfCompress (BioD/bio/core/bgzf/compress.d:34-103) for a whole buffer at once.  in[0, n) is
  * cut into 0xFF00-byte pieces (bgzf/constants.d:33), every piece becomes one BGZF block -- 18-byte header with the BC
- * subfield, raw deflate, CRC32, ISIZE -- compressed on the device (one lane per block; fixed Huffman code + greedy LZ77:
- * any RFC 1951 stream is valid for every BGZF reader, the reference's included; level 0 = stored blocks, every other level of
- * zlib's range -- 1 .. 9 and -1, Z_DEFAULT_COMPRESSION, which is the reference's default (bgzfCompress(chunk, level = -1),
- * BamWriter(compression_level = -1)) -- = the one compressing mode; anything else: SBX_EINVAL).  with_eof != 0 appends the 28-byte EOF block (constants.d:37-49).  All pointers are host
+ * subfield, raw deflate, CRC32, ISIZE -- compressed on the device (one lane per block; any RFC 1951 stream is valid for every
+ * BGZF reader, the reference's included).  level is zlib's, as bgzfCompress hands it on: 0 = stored blocks; 1 .. 3 = the fixed
+ * Huffman code over greedy hash-table matches; 4 .. 9 and -1 -- Z_DEFAULT_COMPRESSION, the reference's default
+ * (bgzfCompress(chunk, level = -1), BamWriter(compression_level = -1)) -- = a dynamic Huffman code per block, from level 7 on over
+ * four match candidates per position with lazy evaluation; anything else: SBX_EINVAL.  with_eof != 0 appends the 28-byte EOF
+ * block (constants.d:37-49).  All pointers are host
  * memory; *out_len receives the size of the stream (also on SBX_ENOMEM, when cap is too small: n + n / 2048 + 64 is
  * always enough).  device: HIP ordinal or -1. */
 int sbx_bgzf_compress(const uint8_t* in, size_t n, int level, int with_eof, int device, uint8_t* out, size_t cap, size_t* out_len,
@@ -158,7 +160,9 @@ int sbx_write_bam(const char* path, const uint8_t* stream, size_t n, int level, 
  * The file goes through the device pipeline once (inflate, record chain, field decode: position, basesCovered(), stored
  * bin, virtual offsets); chunks per bin, the 16 kbp linear index, the metadata pseudo-bin 37450 and the no-coordinate count
  * are assembled on the host as IndexBuilder.put / finish do.  Bins are written in ascending id order (the reference's order
- * is that of a D associative array).  The whole file must fit the device in one pass (SBX_ENOMEM otherwise).
+ * is that of a D associative array).  Like IndexBuilder (one pass over a stream of records, indexing.d:262-316) it does not
+ * need the file resident: the blocks go through the device in batches sized by the free device memory, a batch ends in front
+ * of the record that straddles its last block boundary, the next one starts with it.
  * SBX_ENOTSORTED when the reads are not coordinate-sorted. */
 int sbx_build_index(const char* bam_path, const char* bai_path, int device, char* err, size_t errlen);
 

@@ -49,7 +49,8 @@ static uint32_t floor_pow2(uint32_t x) {
 struct FileRun {
     uint32_t blk0, blk1;
     uint64_t ub, ue;
-    bool operator==(const FileRun& o) const { return blk0 == o.blk0 && blk1 == o.blk1 && ub == o.ub && ue == o.ue; }
+    bool open_end = false;        // ue is a block boundary in the middle of the record stream (ChainRun::open_end)
+    bool operator==(const FileRun& o) const { return blk0 == o.blk0 && blk1 == o.blk1 && ub == o.ub && ue == o.ue && open_end == o.open_end; }
 };
 
 // The work list of a launch: file runs, and the per-block tables of the launch in compacted coordinates
@@ -74,6 +75,7 @@ struct HostResults {
     uint64_t last_state;
     uint32_t max_partners, n_rewalked;
     unsigned long long tok_bytes[64];
+    uint64_t straddler;           // open-ended run: start of the record that continues behind it (kOffUnknown: none)
 };
 
 }  // namespace sbx
@@ -134,6 +136,7 @@ struct sbx_ctx {
 
     DevBuf<uint8_t> d_U, d_scratch, d_lit;
     uint64_t primary_records = 0;   // records of THIS file in the last run (stats.n_records is the sum over files after a merge)
+    uint64_t index_straddler = kOffUnknown;      // index mode, open-ended batch: work-list offset of the record the next batch starts with
     const uint8_t* U() const { return d_U.p; }
     DevBuf<uint32_t> d_ent, d_nent;
     DevBuf<uint64_t> d_entry, d_exit, d_state;
@@ -328,7 +331,7 @@ void build_worklist(const sbx_ctx* c, std::vector<FileRun> runs, bool file_resid
             w->out_off.push_back(uo + (c->blocks.out_off[b] - c->blocks.out_off[r.blk0]));
         }
         const uint64_t ubase = c->blocks.out_off[r.blk0];
-        w->chain.push_back({uo + (r.ub - ubase), uo + (r.ue - ubase), first_local, (uint32_t)w->file_blk.size() - 1});
+        w->chain.push_back({uo + (r.ub - ubase), uo + (r.ue - ubase), first_local, (uint32_t)w->file_blk.size() - 1, r.open_end ? 1u : 0u, 0u});
         uo += c->blocks.out_off[r.blk1] - ubase;
         co += (cend - cbase + 15) & ~15ull;
     }
@@ -946,7 +949,7 @@ static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool r
 }
 
 // The whole device pipeline for the reads selected by `sel` (restricted == false: every read of the file).
-static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
+static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted, const std::vector<FileRun>* given_runs = nullptr) {
     if (!c->index_mode) {
         if (c->hdr.sorting_order != "coordinate") throw Error(SBX_ENOTSORTED, "All files must be coordinate-sorted");
         if (!c->has_index) throw Error(SBX_ENOINDEX, "All files must be indexed");
@@ -959,7 +962,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     HostResults& R = *c->res;
 
     // ---- work list, tables, compressed bytes ----
-    make_resident(c, build_runs(c, sel, restricted));
+    make_resident(c, given_runs ? *given_runs : build_runs(c, sel, restricted));
     c->stats.ms_h2d = c->upload_ms.load(std::memory_order_relaxed);      // (the upload may have been a prefetch on another thread)
     const WorkList& w = c->wl;
     const uint32_t nb = (uint32_t)w.n_blocks();
@@ -988,7 +991,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     c->d_exit.ensure(nb + 1);
     c->d_state.ensure(nb + 1);
     c->d_count.ensure(nb + 1);
-    c->d_flag.ensure(8);
+    c->d_flag.ensure(12);
     c->d_tile_lo.ensure((size_t)nt + 1);
     c->d_tile_hi.ensure((size_t)nt + 1);
     c->d_active.ensure((size_t)nt + 1);
@@ -1025,7 +1028,8 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats) * kIndexStatSlots, s));
         SBX_HIP(hipMemsetAsync(c->d_state.p, 0, ((size_t)nb + 1) * 8, s));
         SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 8, s));           // [0] first inconsistent block, [1] first failed inflate
-        SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 24, s));         // [2] overflow, [3] ticket, [4] rewalked, [5] max partners
+        SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 24, s));         // [2] overflow, [3] ticket, [4] rewalked, [5] max partners, [6] K3 -m overflow
+        SBX_HIP(hipMemsetAsync(c->d_flag.p + 8, 0xFF, 8, s));       // [8..9] start of the record behind an open-ended run (64 bits)
         IndexArgs a{};
         a.U = c->d_U.p;
         a.u_alloc = (w.u_bytes + 15) & ~15ull;
@@ -1049,6 +1053,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         SBX_HIP(hipMemcpyAsync(R.st, c->d_stats.p, sizeof(IndexStats) * kIndexStatSlots, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipMemcpyAsync(R.tok_bytes, c->d_tok.p, 64 * 8, hipMemcpyDeviceToHost, s));
         if (nb) SBX_HIP(hipMemcpyAsync(&R.last_state, c->d_state.p + (nb - 1), 8, hipMemcpyDeviceToHost, s));
+        if (c->index_mode) SBX_HIP(hipMemcpyAsync(&R.straddler, c->d_flag.p + 8, 8, hipMemcpyDeviceToHost, s));
         SBX_HIP(hipStreamSynchronize(s));                            // ---- host synchronisation 1 of 2 ----
         if (R.flags[1] != 0xFFFFFFFFu) {
             uint32_t st = 0;
@@ -1122,6 +1127,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
                                      std::to_string(ist.n_records) + ") disagree on the number of records");
     if (c->index_mode) {              // the descriptors are the result
         c->primary_records = n_records;
+        c->index_straddler = R.straddler;
         c->stats.n_records = ist.n_records;
         c->stats.n_bgzf_blocks = nb;
         c->stats.ms_inflate = t1.ms();
@@ -1540,51 +1546,72 @@ int sbx_build_index(const char* bam_path, const char* bai_path, int device, char
         memset(&c->filter, 0, sizeof c->filter);         // no filter: every record is described
         c->mode = SBX_MODE_BASE;
         c->fix_mate = false;
-        // one pass over the whole file (files whose working set exceeds the device are rejected by the allocation: SBX_ENOMEM)
-        run_impl(c, {}, false);
-        const uint64_t nrec = c->primary_records;
-        hipStream_t s = c->stream;
-        DevBuf<uint16_t> d_bins((size_t)nrec + 1);
-        launch_gather_bins(c->U(), c->d_desc.p, nrec, d_bins.p, s);
-        std::vector<RecDesc> desc((size_t)nrec);
-        std::vector<int32_t> ref((size_t)nrec);
-        std::vector<uint16_t> bins((size_t)nrec);
-        SBX_HIP(hipStreamSynchronize(s));
-        if (nrec) {
-            SBX_HIP(hipMemcpy(desc.data(), c->d_desc.p, (size_t)nrec * sizeof(RecDesc), hipMemcpyDeviceToHost));
-            SBX_HIP(hipMemcpy(ref.data(), c->d_rec_ref.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
-            SBX_HIP(hipMemcpy(bins.data(), d_bins.p, (size_t)nrec * 2, hipMemcpyDeviceToHost));
-        }
-        // block table of the stream the record offsets refer to: the blocks of the work list (it starts at the block of the
-        // first record -- a header that fills its blocks exactly is not part of it), then whatever blocks follow it in the file
-        // (the EOF block)
+        // IndexBuilder is one pass over a stream of records (bai/indexing.d:262-316), and so is this: the file goes through the
+        // device in batches of whole BGZF blocks -- inflate, record chain, descriptors --, a batch ends in front of the record that
+        // straddles its last block boundary (ChainRun::open_end) and the next batch starts with that record.  The batch size follows
+        // the free device memory (a batch holds its compressed bytes, its inflated bytes, the token streams and the descriptors: about
+        // five times its inflated size); SBX_INDEX_BATCH_BYTES overrides it (tests).
         const BlockTable& bt = c->blocks;
-        const WorkList& wl = c->wl;
         const size_t nbk = bt.size();
-        const uint64_t file_end_coff = nbk ? bt.coffset[nbk - 1] + (bt.comp_off[nbk - 1] - bt.coffset[nbk - 1]) + bt.comp_len[nbk - 1] + 8 : 0;
-        std::vector<uint64_t> v_coff, v_ustart;
-        for (size_t i = 0; i < wl.n_blocks(); ++i) { v_coff.push_back(bt.coffset[wl.file_blk[i]]); v_ustart.push_back(wl.out_off[i]); }
-        uint64_t u_end = wl.out_off.empty() ? 0 : wl.out_off.back();
-        for (size_t j = wl.n_blocks() ? (size_t)wl.file_blk.back() + 1 : 0; j < nbk; ++j) {
-            v_coff.push_back(bt.coffset[j]);
-            v_ustart.push_back(u_end);
-            u_end += bt.isize[j];
+        const uint64_t total = bt.out_off.back(), first = c->hdr.first_record_off;
+        const uint64_t file_end_coff = nbk ? bt.comp_off[nbk - 1] + bt.comp_len[nbk - 1] + 8 : 0;
+        uint64_t batch_u = 0;
+        if (const char* e = getenv("SBX_INDEX_BATCH_BYTES")) batch_u = strtoull(e, nullptr, 10);
+        if (!batch_u) {
+            size_t free_b = 0, total_b = 0;
+            SBX_HIP(hipMemGetInfo(&free_b, &total_b));
+            batch_u = std::max<uint64_t>(64ull << 20, (uint64_t)((double)free_b * 0.7 / 5.0));
         }
-        v_ustart.push_back(u_end);
-        VoffCursor vc(v_coff.data(), v_ustart.data(), v_coff.size(), file_end_coff);
+        hipStream_t s = c->stream;
+        VoffCursor vc(bt.coffset.data(), bt.out_off.data(), nbk, file_end_coff);
         BaiBuilder bb((int)c->hdr.refs.size());
-        const uint64_t total = wl.out_off.empty() ? 0 : wl.out_off.back();
-        for (uint64_t i = 0; i < nrec; ++i) {
-            BaiRecord r;
-            r.ref_id = ref[(size_t)i];
-            r.position = desc[(size_t)i].pos;
-            r.end_position = desc[(size_t)i].end;
-            r.bin = bins[(size_t)i];
-            r.is_unmapped = (desc[(size_t)i].flag & 0x4) != 0;
-            r.start_vo = vc.of_byte(desc[(size_t)i].rec_off);
-            r.end_vo = vc.behind(i + 1 < nrec ? desc[(size_t)i + 1].rec_off : total);
-            bb.put(r);
+        BaiRecord held;                 // the last record of the batch before: it ends where the next batch starts
+        bool have_held = false;
+        DevBuf<uint16_t> d_bins;
+        std::vector<RecDesc> desc;
+        std::vector<int32_t> ref;
+        std::vector<uint16_t> bins;
+        uint32_t n_batches = 0;
+        for (uint64_t cur = first; cur < total;) {
+            const uint32_t b0 = (uint32_t)(std::upper_bound(bt.out_off.begin(), bt.out_off.end(), cur) - bt.out_off.begin()) - 1;
+            uint32_t b1 = (uint32_t)(std::lower_bound(bt.out_off.begin() + b0, bt.out_off.end(), bt.out_off[b0] + batch_u) - bt.out_off.begin());
+            b1 = std::min<uint32_t>(std::max(b1, b0 + 1), (uint32_t)nbk);
+            if (bt.out_off[b1] >= total) b1 = (uint32_t)nbk;          // (whatever follows holds no bytes: EOF blocks)
+            const bool last = b1 == nbk;
+            const std::vector<FileRun> runs{FileRun{b0, b1, cur, last ? total : bt.out_off[b1], !last}};
+            run_impl(c, {}, false, &runs);
+            const uint64_t nrec = c->primary_records;
+            const uint64_t base = bt.out_off[b0];            // work-list offsets count from the batch's first block
+            const uint64_t next = last ? total : c->index_straddler != kOffUnknown ? base + c->index_straddler : bt.out_off[b1];
+            if (!last && next == cur) {                      // not one whole record in the batch: a longer batch
+                batch_u *= 2;
+                continue;
+            }
+            ++n_batches;
+            d_bins.ensure((size_t)nrec + 1);
+            launch_gather_bins(c->U(), c->d_desc.p, nrec, d_bins.p, s);
+            desc.resize((size_t)nrec); ref.resize((size_t)nrec); bins.resize((size_t)nrec);
+            SBX_HIP(hipStreamSynchronize(s));
+            if (nrec) {
+                SBX_HIP(hipMemcpy(desc.data(), c->d_desc.p, (size_t)nrec * sizeof(RecDesc), hipMemcpyDeviceToHost));
+                SBX_HIP(hipMemcpy(ref.data(), c->d_rec_ref.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
+                SBX_HIP(hipMemcpy(bins.data(), d_bins.p, (size_t)nrec * 2, hipMemcpyDeviceToHost));
+            }
+            for (uint64_t i = 0; i < nrec; ++i) {
+                const uint64_t at = base + desc[(size_t)i].rec_off;
+                if (have_held) { held.end_vo = vc.behind(at); bb.put(held); }
+                held.ref_id = ref[(size_t)i];
+                held.position = desc[(size_t)i].pos;
+                held.end_position = desc[(size_t)i].end;
+                held.bin = bins[(size_t)i];
+                held.is_unmapped = (desc[(size_t)i].flag & 0x4) != 0;
+                held.start_vo = vc.of_byte(at);
+                have_held = true;
+            }
+            cur = next;
         }
+        if (have_held) { held.end_vo = vc.behind(total); bb.put(held); }
+        if (getenv("SBX_TIMING")) fprintf(stderr, "[sbx] build_index: %u batch(es) of <= %llu inflated bytes\n", n_batches, (unsigned long long)batch_u);
         const std::vector<uint8_t>& bytes = bb.finish();
         FILE* f = fopen(bai_path, "wb");
         if (!f) throw Error(SBX_EIO, std::string("cannot write ") + bai_path);

@@ -123,13 +123,14 @@ __device__ bool plausible_chain(const uint8_t* W, uint64_t limit, uint64_t o, co
 
 // walk the chain from `entry` through global memory until it leaves [.., block_end); returns the exit offset or
 // kOffInvalid (repair path only)
-__device__ uint64_t walk_block(const uint8_t* U, uint64_t limit, uint64_t entry, uint64_t block_end, uint32_t* count) {
+__device__ uint64_t walk_block(const uint8_t* U, uint64_t limit, bool open_end, uint64_t entry, uint64_t block_end, uint32_t* count) {
     uint64_t o = entry;
     uint32_t n = 0;
     while (o < block_end) {
-        if (o + 36 > limit) { *count = n; return kOffInvalid; }
+        if (o + 36 > limit) { *count = n; return open_end ? limit : kOffInvalid; }      // (open end: the record belongs to the next batch)
         int64_t bs = (int32_t)ld32(U + o);
-        if (bs < 32 || o + 4 + (uint64_t)bs > limit) { *count = n; return kOffInvalid; }
+        if (bs < 32) { *count = n; return kOffInvalid; }
+        if (o + 4 + (uint64_t)bs > limit) { *count = n; return open_end ? limit : kOffInvalid; }
         ++n;
         o += 4 + (uint64_t)bs;
     }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
     for (uint32_t b0 = from; b0 < n_blocks; b0 += 64) {
         const uint32_t b = b0 + lane;
         uint64_t e = kOffUnknown, x = kOffUnknown, end = 0, rbeg = 0, rend = 0;
-        uint32_t n = 0, first = 0;
+        uint32_t n = 0, first = 0, open = 0;
         if (b < n_blocks) {
             e = entry[b]; x = exit_[b]; n = count[b];
             const ChainRun r = runs[run_of[b]];
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
             if (end > r.u_end) end = r.u_end;
             rbeg = r.u_beg; rend = r.u_end;
             first = r.blk_first == b ? 1u : 0u;
+            open = r.open_end;
         }
         const uint32_t lim = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
         bool dirty = false;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64) void k_chain_repair(const uint8_t* __restrict__
                 ne = e_i; nx = x_i; nn = (uint32_t)__builtin_amdgcn_readlane((int)n, i);     // recorded walk confirmed
             } else {
                 uint32_t c = 0;
-                nx = walk_block(U, rend_i, cur, end_i, &c);     // wave-uniform re-walk
+                nx = walk_block(U, rend_i, __builtin_amdgcn_readlane((int)open, i) != 0, cur, end_i, &c);     // wave-uniform re-walk
                 ne = cur;
                 nn = c;
                 ++rewalked;
@@ -617,19 +619,22 @@ __device__ void walk_block_from(const IndexArgs& a, uint32_t b, uint64_t E) {
     const ChainRun run = a.runs[a.run_of[b]];
     const uint64_t lo = beg > run.u_beg ? beg : run.u_beg, hi0 = blk_end < run.u_end ? blk_end : run.u_end;
     const uint64_t hi = hi0 > lo ? hi0 : lo;
-    const bool last_of_run = b == run.blk_last;
+    const bool last_of_run = b == run.blk_last, open_end = run.open_end != 0;
     uint32_t n = 0;
     uint64_t X = E;
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
     u32x4v grp = {0, 0, 0, 0};                  // the last 8 offsets, oldest in the low half of .x
     uint16_t* list = rec_list(a.scratch, beg, b);
     if (E != kOffUnknown && E != kOffInvalid && E >= lo) {
-        uint64_t o = E;
+        uint64_t o = E, straddler = kOffUnknown;
         bool okc = true;
         while (o < hi) {
-            if (o + 36 > run.u_end) { okc = false; break; }
+            // a record that does not end inside the run: an error -- except in an open-ended run (ChainRun), where it belongs to the
+            // next batch: its start is left in flags[8..9] and the chain leaves the run at its end
+            if (o + 36 > run.u_end) { okc = open_end; straddler = o; break; }
             const int64_t bs = (int32_t)ld32(a.U + o);
-            if (bs < 32 || o + 4 + (uint64_t)bs > run.u_end) { okc = false; break; }
+            if (bs < 32) { okc = false; break; }
+            if (o + 4 + (uint64_t)bs > run.u_end) { okc = open_end; straddler = o; break; }
             grp.x = (grp.x >> 16) | (grp.y << 16);
             grp.y = (grp.y >> 16) | (grp.z << 16);
             grp.z = (grp.z >> 16) | (grp.w << 16);
@@ -639,6 +644,10 @@ __device__ void walk_block_from(const IndexArgs& a, uint32_t b, uint64_t E) {
             o += 4 + (uint64_t)bs;
         }
         X = okc ? o : kOffInvalid;
+        if (okc && straddler != kOffUnknown) {
+            X = run.u_end;
+            atomicMin((unsigned long long*)(a.flags + 8), (unsigned long long)straddler);
+        }
         if (n & 7u) {
             for (uint32_t k = n & 7u; k < 8; ++k) {
                 grp.x = (grp.x >> 16) | (grp.y << 16);

@@ -95,9 +95,12 @@ const char* inflate_status_string(uint32_t s);
 // One run of the device work list: a stretch [u_beg, u_end) of the (compacted) inflated stream that holds a
 // whole number of BAM records -- the whole file from its first record on, or a group of merged BAI chunks
 // (chunk boundaries are record boundaries, randomaccessmanager.d:247-294).  Blocks are launch-local indices.
+// open_end != 0 (the batches of sbx_build_index): u_end is a block boundary, not a record boundary -- the chain stops in front
+// of the first record that does not end inside the run, and the exit of the run's last block is where the next batch starts.
 struct ChainRun {
     uint64_t u_beg, u_end;
     uint32_t blk_first, blk_last;      // inclusive
+    uint32_t open_end, reserved;
 };
 
 constexpr uint32_t kIndexStatSlots = 64;     // IndexArgs.stats points at this many accumulators (power of two); the host adds them up

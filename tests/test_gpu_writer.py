@@ -213,11 +213,56 @@ def test_generator_with_the_device_codec_writes_the_same_reads(tmp_path):
     a = gen_bam(str(tmp_path / "zlib.bam"), "chrA:400000,chrB:90000", coverage=20, seed=17)
     b = gen_bam(str(tmp_path / "dev.bam"), "chrA:400000,chrB:90000", coverage=20, seed=17, extra=["--codec", "device"])
     assert gzip.decompress(open(a, "rb").read()) == gzip.decompress(open(b, "rb").read())
-    assert os.path.getsize(b) > os.path.getsize(a)            # fixed Huffman code: a larger file
+    assert os.path.getsize(b) > os.path.getsize(a)            # greedy matches from one candidate per position: a larger file than zlib-6's
     want = run_oracle(["base", a])
     assert run_oracle(["base", b]) == want and run_cli(["base", b]) == want
     reg = ["base", "-L", "chrA:100000-101000"]
     assert run_cli(reg + [b]) == run_oracle(reg + [a])
+
+
+@pytest.mark.parametrize("batch", ["1", "70000", "300000"])
+def test_index_is_built_in_batches_of_blocks(small_bam, tmp_path, monkeypatch, batch):
+    """IndexBuilder consumes a stream (bai/indexing.d:262-316); sbx_build_index sends the file through the device in batches of
+    whole BGZF blocks, each ending in front of the record that straddles its last block boundary.  Whatever the batch size -- one
+    block at a time (records longer than a batch make it grow), a few blocks, the whole file --, the index is the same file."""
+    one = str(tmp_path / "one.bam")
+    shutil.copy(small_bam, one)
+    sambamba_amd.build_index(one)                       # (default: the batch follows the free device memory -- one batch here)
+    many = str(tmp_path / "many.bam")
+    shutil.copy(small_bam, many)
+    monkeypatch.setenv("SBX_INDEX_BATCH_BYTES", batch)
+    sambamba_amd.build_index(many)
+    assert open(many + ".bai", "rb").read() == open(one + ".bai", "rb").read()
+
+
+def test_index_batches_with_records_longer_than_a_block(tmp_path, monkeypatch):
+    """Records of ~100 kB (long reads) span two BGZF blocks each: a batch of one block holds no whole record and has to grow;
+    batch boundaries fall inside records, block boundaries inside the 36 fixed bytes of a record."""
+    rng = np.random.default_rng(5)
+    recs = []
+    pos = 100
+    for i in range(40):
+        n = int(rng.integers(90_000, 140_000)) if i % 3 else int(rng.integers(30, 200))
+        recs.append(bg.make_record(0, pos, "%dM" % n, "ACGT"[i % 4] * n, 30, name="long%d" % i))
+        pos += int(rng.integers(1, 5000))
+    path = str(tmp_path / "long.bam")
+    bg.write_bam(path, [("chrL", 5_000_000)], recs, write_index=False)
+    whole = str(tmp_path / "whole.bam")
+    shutil.copy(path, whole)
+    sambamba_amd.build_index(whole)
+    for batch in ("1", "65280", "200000"):
+        part = str(tmp_path / ("part%s.bam" % batch))
+        shutil.copy(path, part)
+        monkeypatch.setenv("SBX_INDEX_BATCH_BYTES", batch)
+        sambamba_amd.build_index(part)
+        monkeypatch.delenv("SBX_INDEX_BATCH_BYTES")
+        assert open(part + ".bai", "rb").read() == open(whole + ".bai", "rb").read(), batch
+    # ... and it is the index the host build of the same IndexBuilder restatement writes from a zlib reader (tests/native/bai_host.cpp)
+    from tests.test_bai_cpu import SRC as BAI_SRC
+    exe = str(tmp_path / "bai_host")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe, BAI_SRC, "-lz"])
+    subprocess.check_call([exe, path, str(tmp_path / "host.bai")])
+    assert open(str(tmp_path / "host.bai"), "rb").read() == open(whole + ".bai", "rb").read()
 
 
 @pytest.mark.parametrize("name", ["issue225", "issue_193", "issue_204", "mate_overlaps_1_3M_4M"])
