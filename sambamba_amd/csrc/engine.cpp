@@ -136,6 +136,10 @@ struct sbx_ctx {
 
     DevBuf<uint8_t> d_U, d_scratch, d_lit;
     uint64_t primary_records = 0;   // records of THIS file in the last run (stats.n_records is the sum over files after a merge)
+    // several BAMs whose dictionaries differ (merge_dictionaries, host_io.hpp): hdr.refs is the MERGED dictionary in every file's
+    // context; the records and the BAI of a file speak its own ids.  Empty: the file's own dictionary is the merged one.
+    std::vector<int32_t> own_to_merged, merged_to_own;
+    DevBuf<int32_t> d_own_to_merged;
     uint64_t index_straddler = kOffUnknown;      // index mode, open-ended batch: work-list offset of the record the next batch starts with
     const uint8_t* U() const { return d_U.p; }
     DevBuf<uint32_t> d_ent, d_nent;
@@ -286,7 +290,11 @@ std::vector<FileRun> build_runs(const sbx_ctx* c, const std::vector<sbx_region>&
             else group.push_back(regs[j]);
             ++j;
         }
-        if (regs[i].ref_id < c->bai.refs.size())
+        // (the index of a file speaks the file's own reference ids)
+        int64_t own = regs[i].ref_id;
+        if (!c->merged_to_own.empty()) own = regs[i].ref_id < c->merged_to_own.size() ? c->merged_to_own[regs[i].ref_id] : -1;
+        for (auto& g : group) g.ref_id = (uint32_t)std::max<int64_t>(own, 0);
+        if (own >= 0 && (size_t)own < c->bai.refs.size())
             for (auto& ch : group_chunks(c->bai, group)) {
                 if (ch.beg >= ch.end) continue;
                 uint32_t bb = 0, be = 0;
@@ -644,14 +652,30 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
             sbx_ctx* m = sbx_open(one, 1, c->device, e2, sizeof e2);
             if (!m) throw Error(SBX_EIO, e2);
             c->members.push_back(m);
-            if (m->hdr.refs.size() != c->hdr.refs.size()) throw Error(SBX_EUNSUPPORTED, "the BAM files have different reference dictionaries");
-            for (size_t r = 0; r < m->hdr.refs.size(); ++r)
-                if (m->hdr.refs[r].name != c->hdr.refs[r].name || m->hdr.refs[r].length != c->hdr.refs[r].length)
-                    throw Error(SBX_EUNSUPPORTED, "the BAM files have different reference dictionaries");
             if (m->hdr.sorting_order != "coordinate") c->hdr.sorting_order = m->hdr.sorting_order;
             if (!m->has_index) c->has_index = false;
         }
         if (!c->members.empty()) {
+            // the reference dictionary of the merged header (SamHeaderMerger); files whose own dictionary differs from it translate
+            // the reference ids of their records on the device (RefTable::own_to_merged) and the ids of BAI queries on the host
+            {
+                const auto files = files_of(c.get());
+                std::vector<const std::vector<RefSeq>*> dicts;
+                for (sbx_ctx* f : files) dicts.push_back(&f->hdr.refs);
+                std::vector<RefSeq> merged;
+                std::vector<std::vector<int32_t>> maps;
+                merge_dictionaries(dicts, &merged, &maps);
+                for (size_t k = 0; k < files.size(); ++k) {
+                    sbx_ctx* f = files[k];
+                    bool same = f->hdr.refs.size() == merged.size();
+                    for (size_t r = 0; same && r < merged.size(); ++r) same = maps[k][r] == (int32_t)r;
+                    if (same) continue;
+                    f->own_to_merged = maps[k];
+                    f->merged_to_own.assign(merged.size(), -1);
+                    for (size_t r = 0; r < maps[k].size(); ++r) f->merged_to_own[(size_t)maps[k][r]] = (int32_t)r;
+                    f->hdr.refs = merged;
+                }
+            }
             std::vector<std::string> names;
             auto id_of = [&](const std::string& sm) -> uint16_t {
                 for (size_t k = 0; k < names.size(); ++k) if (names[k] == sm) return (uint16_t)k;
@@ -893,7 +917,13 @@ static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool r
         if (!c->h_sel.empty()) SBX_HIP(hipMemcpyAsync(c->d_sel.p, c->h_sel.data(), c->h_sel.size() * sizeof(SortedRegion), hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(c->d_sel_first.p, c->h_sel_first.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
     }
-    *refs_out = RefTable{c->d_ref_len.p, c->d_tile_base.p, n_ref, restricted ? c->d_sel.p : nullptr, restricted ? c->d_sel_first.p : nullptr};
+    if (!c->own_to_merged.empty() && !c->d_own_to_merged.n) {
+        c->d_own_to_merged.alloc(c->own_to_merged.size() + 1);
+        SBX_HIP(hipMemcpyAsync(c->d_own_to_merged.p, c->own_to_merged.data(), c->own_to_merged.size() * 4, hipMemcpyHostToDevice, s));
+    }
+    *refs_out = RefTable{c->d_ref_len.p, c->d_tile_base.p, n_ref, restricted ? c->d_sel.p : nullptr, restricted ? c->d_sel_first.p : nullptr,
+                         c->own_to_merged.empty() ? nullptr : c->d_own_to_merged.p,
+                         c->own_to_merged.empty() ? n_ref : (int32_t)c->own_to_merged.size()};
     // filter
     c->d_filter.ensure(1);
     DeviceFilter& df = c->h_df;
@@ -1318,6 +1348,10 @@ int sbx_run(sbx_ctx* c) {
 // BGZF block range [b0, b1) holding every read of contig r (from the BAI; empty contigs: b0 == b1)
 static void contig_blocks(sbx_ctx* c, uint32_t r, uint32_t* b0, uint32_t* b1) {
     *b0 = *b1 = 0;
+    if (!c->merged_to_own.empty()) {       // (the index speaks the file's own reference ids)
+        if (r >= c->merged_to_own.size() || c->merged_to_own[r] < 0) return;
+        r = (uint32_t)c->merged_to_own[r];
+    }
     if (r >= c->bai.refs.size()) return;
     std::vector<sbx_region> whole{{r, 0u, 0x7FFFFFFFu}};
     uint64_t vbeg = ~0ull, vend = 0;

@@ -207,6 +207,58 @@ struct BamHeaderInfo {
     }
 };
 
+// SamHeaderMerger.mergeSequenceDictionaries (BioD/bio/std/hts/utils/samheadermerger.d:127-177) for MultiBamReader
+// (multireader.d:218-236): the dictionaries of the files become a directed graph -- one node per name in order of first
+// appearance, one edge from every @SQ line to the next one of the same file, repeated edges kept -- and the merged dictionary
+// is its topological order as DirectedGraph.topologicalSort produces it (utils/graph.d:57-87: Kahn's algorithm with a FIFO
+// queue seeded with the nodes without predecessor in node order, successors visited in edge order).  Two lines with one name
+// and different lengths cannot be merged; a cycle (two files listing two contigs in opposite orders) sends the reference to a
+// strategy MultiBamReader does not implement ("NYI").  own_to_merged[f][id of file f] = id in the merged dictionary.
+inline void merge_dictionaries(const std::vector<const std::vector<RefSeq>*>& dicts, std::vector<RefSeq>* merged,
+                               std::vector<std::vector<int32_t>>* own_to_merged) {
+    std::vector<RefSeq> nodes;
+    std::map<std::string, size_t> index;
+    std::vector<std::vector<size_t>> edges;
+    auto node = [&](const RefSeq& r) -> size_t {
+        auto it = index.find(r.name);
+        if (it != index.end()) {
+            if (nodes[it->second].length != r.length)
+                throw Error(SBX_EINVAL, "can't merge SAM headers: one of references with name " + r.name + " has length " +
+                                            std::to_string(nodes[it->second].length) + " while another one with the same name has length " +
+                                            std::to_string(r.length));
+            return it->second;
+        }
+        nodes.push_back(r);
+        edges.emplace_back();
+        return index[r.name] = nodes.size() - 1;
+    };
+    for (const std::vector<RefSeq>* d : dicts) {
+        if (d->empty()) continue;
+        size_t prev = node((*d)[0]);
+        for (size_t k = 1; k < d->size(); ++k) {
+            const size_t cur = node((*d)[k]);
+            edges[prev].push_back(cur);
+            prev = cur;
+        }
+    }
+    std::vector<size_t> pred(nodes.size(), 0), queue;
+    for (auto& e : edges) for (size_t v : e) ++pred[v];
+    for (size_t v = 0; v < nodes.size(); ++v) if (!pred[v]) queue.push_back(v);
+    std::vector<int32_t> new_id(nodes.size(), -1);
+    merged->clear();
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const size_t v = queue[head];
+        new_id[v] = (int32_t)merged->size();
+        merged->push_back(nodes[v]);
+        for (size_t w : edges[v]) if (--pred[w] == 0) queue.push_back(w);
+    }
+    if (merged->size() < nodes.size())
+        throw Error(SBX_EUNSUPPORTED, "the BAM files list their reference sequences in orders that contradict each other (the reference: NYI)");
+    own_to_merged->assign(dicts.size(), {});
+    for (size_t f = 0; f < dicts.size(); ++f)
+        for (const RefSeq& r : *dicts[f]) (*own_to_merged)[f].push_back(new_id[index[r.name]]);
+}
+
 // Parses from the head of the inflated stream; returns false if `n` bytes were not enough
 // (caller fetches more and retries).
 inline bool parse_bam_header(const uint8_t* u, uint64_t n, uint64_t total, BamHeaderInfo* h) {

@@ -63,10 +63,10 @@ __device__ bool plausible_record(const uint8_t* U, uint64_t limit, uint64_t o, c
     int64_t bs = (int32_t)ld32(p);
     if (bs < 32 || bs > (int64_t)(1 << 29)) return false;
     int32_t ref = (int32_t)ld32(p + 4);
-    if (ref < -1 || ref >= refs.n_ref) return false;
+    if (ref < -1 || ref >= refs.n_ref_own) return false;
     int32_t pos = (int32_t)ld32(p + 8);
     if (pos < -1) return false;
-    if (ref >= 0 && pos > refs.ref_len[ref]) return false;
+    if (ref >= 0 && pos > refs.ref_len[refs.own_to_merged ? refs.own_to_merged[ref] : ref]) return false;
     uint32_t bmn = ld32(p + 12);
     uint32_t l_name = bmn & 0xFFu;
     if (l_name < 1) return false;
@@ -75,7 +75,7 @@ __device__ bool plausible_record(const uint8_t* U, uint64_t limit, uint64_t o, c
     int32_t l_seq = (int32_t)ld32(p + 20);
     if (l_seq < 0) return false;
     int32_t nref = (int32_t)ld32(p + 24);
-    if (nref < -1 || nref >= refs.n_ref) return false;
+    if (nref < -1 || nref >= refs.n_ref_own) return false;
     int32_t npos = (int32_t)ld32(p + 28);
     if (npos < -1) return false;
     int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 + (int64_t)l_seq;
@@ -508,7 +508,9 @@ __device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexAr
     Described R;
     const int64_t bs = (int32_t)ld32(p);
     const uint8_t* r = p + 4;
-    const int32_t ref = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+    const int32_t ref_own = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+    // (adjustTagsInRange, multireader.d:174-190: the id of the merged dictionary is what every later stage sees)
+    const int32_t ref = (a.refs.own_to_merged && ref_own >= 0 && ref_own < a.refs.n_ref_own) ? a.refs.own_to_merged[ref_own] : ref_own;
     const uint32_t bmn = ld32(r + 8), fnc = ld32(r + 12);
     const uint32_t l_name = bmn & 0xFF, mapq = (bmn >> 8) & 0xFF;
     const uint32_t n_cigar = fnc & 0xFFFF, flag = fnc >> 16;
@@ -531,7 +533,7 @@ __device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexAr
     R.t0 = R.t1 = 0;
     R.urg = false;
     const int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
-    const bool sane = l_seq >= 0 && bs >= fixed && ref >= -1 && ref < a.refs.n_ref;
+    const bool sane = l_seq >= 0 && bs >= fixed && ref_own >= -1 && ref_own < a.refs.n_ref_own;
     R.bad = !sane;
     bool admit = sane && !(flag & 0x4) && ref >= 0;                       // read.d:256, unmapped reads cover nothing
     if (admit) admit = eval_filter(a.filt, r, ref, pos, bmn, fnc, l_seq, r + fixed, r + bs);      // filtering.d:36-38

@@ -63,6 +63,11 @@ struct RefTable {           // per-reference device arrays
     // sel_first[ref] .. sel_first[ref + 1]; sel == nullptr: every read
     const SortedRegion* sel;
     const uint32_t* sel_first;
+    // several BAMs with compatible but different @SQ dictionaries (MultiBamReader, multireader.d:174-215): the arrays above are
+    // those of the MERGED dictionary, a record's reference id is translated when it is read: own_to_merged[id], id < n_ref_own.
+    // nullptr: the file's own dictionary is the merged one (n_ref_own == n_ref).
+    const int32_t* own_to_merged;
+    int32_t n_ref_own;
 };
 
 struct RgTable {            // read-group id strings -> sample id (depth.d:1170-1181)
