@@ -197,7 +197,7 @@ def test_unsorted_input_is_rejected(tmp_path):
 
 
 def test_product_reads_device_written_bam_at_scale(tmp_path):
-    """A few hundred thousand reads through gen_bam -> inflate -> device writer: fixed-Huffman blocks through K1a / K1b at scale."""
+    """A few hundred thousand reads through gen_bam -> inflate -> device writer (default level: dynamic-code blocks) -> K1a / K1b."""
     src = gen_bam(str(tmp_path / "g.bam"), "chrA:3000000", coverage=20, seed=5)
     stream = gzip.decompress(open(src, "rb").read())
     out = str(tmp_path / "dev.bam")
