@@ -9,11 +9,13 @@
 // fixed Huffman code in one pass, or a dynamic Huffman code -- symbol counts, code construction and a second pass over the
 // input, its tables in a second 4 KiB slice per block).  Every block is written into a 64 KiB slot; a scan of the block lengths and a coalesced copy (one
 // workgroup per block) then pack the slots into the BGZF stream.
+// The index of the file written (or of any coordinate-sorted BAM) is built here too: k_bai_records, one lane per record.
 // Bound: memory latency (every hash probe and window compare of a lane is its own cache line); it is a writer for
 // harness-sized and production files alike, not a roofline kernel -- DESIGN.md reports its GB/s next to zlib's.
 #include "common.hpp"
 #include "deflate_core.hpp"
 #include "kernels.hpp"
+#include "bai_parallel.hpp"
 
 namespace sbx {
 
@@ -63,7 +65,25 @@ __global__ __launch_bounds__(256) void k_gather_bins(const uint8_t* __restrict__
     bins[i] = v;
 }
 
+// the index of a BAM, one lane per record (bai_parallel.hpp: what IndexBuilder's loop computes, as sums, minima, maxima and run heads)
+__global__ __launch_bounds__(256) void k_bai_records(BaiArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n) bai_record_step(a, i);
+}
+__global__ void k_bai_carry(BaiArgs a, BaiCarry* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) bai_carry_out(a, out);
+}
+
 }  // namespace
+
+void launch_bai_records(const BaiArgs& a, BaiCarry* d_carry_out, hipStream_t stream) {
+    if (a.n) {
+        hipLaunchKernelGGL(k_bai_records, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+        SBX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_bai_carry, dim3(1), dim3(64), 0, stream, a, d_carry_out);
+    SBX_HIP(hipGetLastError());
+}
 
 size_t deflate_table_entries(uint32_t n_blocks) { return (size_t)n_blocks << kHashBits; }
 size_t deflate_work_bytes(uint32_t n_blocks) { return (size_t)n_blocks * kWorkBytes; }

@@ -18,6 +18,7 @@
 #include <thread>
 
 #include "bai_writer.hpp"
+#include "bai_parallel.hpp"
 #include "common.hpp"
 #include "deflate_core.hpp"
 #include "host_io.hpp"
@@ -1597,56 +1598,137 @@ int sbx_build_index(const char* bam_path, const char* bai_path, int device, char
             batch_u = std::max<uint64_t>(64ull << 20, (uint64_t)((double)free_b * 0.7 / 5.0));
         }
         hipStream_t s = c->stream;
-        VoffCursor vc(bt.coffset.data(), bt.out_off.data(), nbk, file_end_coff);
-        BaiBuilder bb((int)c->hdr.refs.size());
-        BaiRecord held;                 // the last record of the batch before: it ends where the next batch starts
-        bool have_held = false;
-        DevBuf<uint16_t> d_bins;
-        std::vector<RecDesc> desc;
-        std::vector<int32_t> ref;
-        std::vector<uint16_t> bins;
+        const int n_ref = (int)c->hdr.refs.size();
+        // What consumes the records of a batch: the device (bai_parallel.hpp -- one lane per record; only the run heads, about one
+        // record in fifty, and a few per-reference arrays come back) or, for input that formulation calls irregular (unsorted reads:
+        // the reference's error is worded by the serial builder; reads far beyond the end of their reference) and with
+        // SBX_BAI_HOST=1, IndexBuilder's loop restated on the host (bai_writer.hpp) over descriptors copied back record by record.
+        std::vector<uint8_t> bytes;
         uint32_t n_batches = 0;
-        for (uint64_t cur = first; cur < total;) {
-            const uint32_t b0 = (uint32_t)(std::upper_bound(bt.out_off.begin(), bt.out_off.end(), cur) - bt.out_off.begin()) - 1;
-            uint32_t b1 = (uint32_t)(std::lower_bound(bt.out_off.begin() + b0, bt.out_off.end(), bt.out_off[b0] + batch_u) - bt.out_off.begin());
-            b1 = std::min<uint32_t>(std::max(b1, b0 + 1), (uint32_t)nbk);
-            if (bt.out_off[b1] >= total) b1 = (uint32_t)nbk;          // (whatever follows holds no bytes: EOF blocks)
-            const bool last = b1 == nbk;
-            const std::vector<FileRun> runs{FileRun{b0, b1, cur, last ? total : bt.out_off[b1], !last}};
-            run_impl(c, {}, false, &runs);
-            const uint64_t nrec = c->primary_records;
-            const uint64_t base = bt.out_off[b0];            // work-list offsets count from the batch's first block
-            const uint64_t next = last ? total : c->index_straddler != kOffUnknown ? base + c->index_straddler : bt.out_off[b1];
-            if (!last && next == cur) {                      // not one whole record in the batch: a longer batch
-                batch_u *= 2;
-                continue;
+        auto pass = [&](bool on_device) -> bool {
+            // serial consumer
+            VoffCursor vc(bt.coffset.data(), bt.out_off.data(), nbk, file_end_coff);
+            BaiBuilder bb(n_ref);
+            BaiRecord held;                 // the last record of the batch before: it ends where the next batch starts
+            bool have_held = false;
+            DevBuf<uint16_t> d_bins;
+            std::vector<RecDesc> desc;
+            std::vector<int32_t> ref;
+            std::vector<uint16_t> bins;
+            // device consumer
+            BaiHostResults R;
+            DevBuf<uint64_t> d_coff, d_ustart, d_lin, d_meta;      // d_meta: meta_end | n_mapped | n_unmapped, n_ref + 1 each
+            DevBuf<uint32_t> d_lin_off, d_lin_len;
+            DevBuf<unsigned long long> d_scalars;
+            DevBuf<BaiRun> d_runs;
+            DevBuf<BaiCarry> d_carry(1);
+            BaiCarry carry{-1, 0, 0, 0, 0};
+            uint64_t rec_base = 0;
+            if (on_device) {
+                R.lin_off.assign((size_t)n_ref + 1, 0);
+                for (int r = 0; r < n_ref; ++r) R.lin_off[(size_t)r + 1] = R.lin_off[(size_t)r] + bai_windows_for(c->hdr.refs[(size_t)r].length);
+                d_coff.alloc(nbk + 1); d_ustart.alloc(nbk + 2);
+                d_lin.alloc((size_t)R.lin_off[(size_t)n_ref] + 1); d_lin_off.alloc((size_t)n_ref + 2); d_lin_len.alloc((size_t)n_ref + 1);
+                d_meta.alloc(3 * ((size_t)n_ref + 1)); d_scalars.alloc(kBaiScalars);
+                if (nbk) SBX_HIP(hipMemcpyAsync(d_coff.p, bt.coffset.data(), nbk * 8, hipMemcpyHostToDevice, s));
+                SBX_HIP(hipMemcpyAsync(d_ustart.p, bt.out_off.data(), (nbk + 1) * 8, hipMemcpyHostToDevice, s));
+                SBX_HIP(hipMemcpyAsync(d_lin_off.p, R.lin_off.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice, s));
+                SBX_HIP(hipMemsetAsync(d_lin.p, 0xFF, d_lin.bytes(), s));
+                SBX_HIP(hipMemsetAsync(d_lin_len.p, 0, d_lin_len.bytes(), s));
+                SBX_HIP(hipMemsetAsync(d_meta.p, 0, d_meta.bytes(), s));
+                SBX_HIP(hipMemsetAsync(d_scalars.p, 0, d_scalars.bytes(), s));
+                SBX_HIP(hipMemsetAsync(d_scalars.p + kBaiFirstVo, 0xFF, 8, s));
             }
-            ++n_batches;
-            d_bins.ensure((size_t)nrec + 1);
-            launch_gather_bins(c->U(), c->d_desc.p, nrec, d_bins.p, s);
-            desc.resize((size_t)nrec); ref.resize((size_t)nrec); bins.resize((size_t)nrec);
-            SBX_HIP(hipStreamSynchronize(s));
-            if (nrec) {
-                SBX_HIP(hipMemcpy(desc.data(), c->d_desc.p, (size_t)nrec * sizeof(RecDesc), hipMemcpyDeviceToHost));
-                SBX_HIP(hipMemcpy(ref.data(), c->d_rec_ref.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
-                SBX_HIP(hipMemcpy(bins.data(), d_bins.p, (size_t)nrec * 2, hipMemcpyDeviceToHost));
+            uint64_t bu = batch_u;
+            n_batches = 0;
+            for (uint64_t cur = first; cur < total;) {
+                const uint32_t b0 = (uint32_t)(std::upper_bound(bt.out_off.begin(), bt.out_off.end(), cur) - bt.out_off.begin()) - 1;
+                uint32_t b1 = (uint32_t)(std::lower_bound(bt.out_off.begin() + b0, bt.out_off.end(), bt.out_off[b0] + bu) - bt.out_off.begin());
+                b1 = std::min<uint32_t>(std::max(b1, b0 + 1), (uint32_t)nbk);
+                if (bt.out_off[b1] >= total) b1 = (uint32_t)nbk;          // (whatever follows holds no bytes: EOF blocks)
+                const bool last = b1 == nbk;
+                const std::vector<FileRun> runs{FileRun{b0, b1, cur, last ? total : bt.out_off[b1], !last}};
+                run_impl(c, {}, false, &runs);
+                const uint64_t nrec = c->primary_records;
+                const uint64_t base = bt.out_off[b0];            // work-list offsets count from the batch's first block
+                const uint64_t next = last ? total : c->index_straddler != kOffUnknown ? base + c->index_straddler : bt.out_off[b1];
+                if (!last && next == cur) {                      // not one whole record in the batch: a longer batch
+                    bu *= 2;
+                    continue;
+                }
+                ++n_batches;
+                if (on_device) {
+                    const uint64_t cap = nrec / 4 + 4096;
+                    d_runs.ensure((size_t)cap);
+                    SBX_HIP(hipMemsetAsync(d_scalars.p + kBaiNumRuns, 0, 8, s));
+                    BaiArgs a{};
+                    a.U = c->U(); a.desc = c->d_desc.p; a.rec_ref = c->d_rec_ref.p; a.n = nrec; a.rec_base = rec_base;
+                    a.u_base = base; a.u_next = next;
+                    a.coff = d_coff.p; a.ustart = d_ustart.p; a.n_blocks = (uint32_t)nbk; a.file_end = file_end_coff;
+                    a.carry = carry; a.n_ref = n_ref;
+                    a.lin = d_lin.p; a.lin_off = d_lin_off.p; a.lin_len = d_lin_len.p;
+                    a.meta_end = d_meta.p; a.n_mapped = d_meta.p + (n_ref + 1); a.n_unmapped = d_meta.p + 2 * ((size_t)n_ref + 1);
+                    a.scalars = d_scalars.p; a.runs = d_runs.p; a.runs_cap = cap;
+                    launch_bai_records(a, d_carry.p, s);
+                    unsigned long long sc[kBaiScalars];
+                    SBX_HIP(hipMemcpyAsync(sc, d_scalars.p, sizeof sc, hipMemcpyDeviceToHost, s));
+                    SBX_HIP(hipMemcpyAsync(&carry, d_carry.p, sizeof carry, hipMemcpyDeviceToHost, s));
+                    SBX_HIP(hipStreamSynchronize(s));
+                    if (sc[kBaiIrregular] || sc[kBaiNumRuns] > cap) return false;
+                    const size_t at = R.runs.size(), nr = (size_t)sc[kBaiNumRuns];
+                    R.runs.resize(at + nr);
+                    if (nr) SBX_HIP(hipMemcpy(R.runs.data() + at, d_runs.p, nr * sizeof(BaiRun), hipMemcpyDeviceToHost));
+                    rec_base += nrec;
+                } else {
+                    d_bins.ensure((size_t)nrec + 1);
+                    launch_gather_bins(c->U(), c->d_desc.p, nrec, d_bins.p, s);
+                    desc.resize((size_t)nrec); ref.resize((size_t)nrec); bins.resize((size_t)nrec);
+                    SBX_HIP(hipStreamSynchronize(s));
+                    if (nrec) {
+                        SBX_HIP(hipMemcpy(desc.data(), c->d_desc.p, (size_t)nrec * sizeof(RecDesc), hipMemcpyDeviceToHost));
+                        SBX_HIP(hipMemcpy(ref.data(), c->d_rec_ref.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
+                        SBX_HIP(hipMemcpy(bins.data(), d_bins.p, (size_t)nrec * 2, hipMemcpyDeviceToHost));
+                    }
+                    for (uint64_t i = 0; i < nrec; ++i) {
+                        const uint64_t at = base + desc[(size_t)i].rec_off;
+                        if (have_held) { held.end_vo = vc.behind(at); bb.put(held); }
+                        held.ref_id = ref[(size_t)i];
+                        held.position = desc[(size_t)i].pos;
+                        held.end_position = desc[(size_t)i].end;
+                        held.bin = bins[(size_t)i];
+                        held.is_unmapped = (desc[(size_t)i].flag & 0x4) != 0;
+                        held.start_vo = vc.of_byte(at);
+                        have_held = true;
+                    }
+                }
+                cur = next;
             }
-            for (uint64_t i = 0; i < nrec; ++i) {
-                const uint64_t at = base + desc[(size_t)i].rec_off;
-                if (have_held) { held.end_vo = vc.behind(at); bb.put(held); }
-                held.ref_id = ref[(size_t)i];
-                held.position = desc[(size_t)i].pos;
-                held.end_position = desc[(size_t)i].end;
-                held.bin = bins[(size_t)i];
-                held.is_unmapped = (desc[(size_t)i].flag & 0x4) != 0;
-                held.start_vo = vc.of_byte(at);
-                have_held = true;
+            if (on_device) {
+                const size_t m = (size_t)n_ref + 1;
+                R.lin.resize(d_lin.n); R.lin_len.resize(m); R.meta_end.resize(m); R.n_mapped.resize(m); R.n_unmapped.resize(m);
+                unsigned long long sc[kBaiScalars];
+                SBX_HIP(hipMemcpy(R.lin.data(), d_lin.p, d_lin.n * 8, hipMemcpyDeviceToHost));
+                SBX_HIP(hipMemcpy(R.lin_len.data(), d_lin_len.p, m * 4, hipMemcpyDeviceToHost));
+                SBX_HIP(hipMemcpy(R.meta_end.data(), d_meta.p, m * 8, hipMemcpyDeviceToHost));
+                SBX_HIP(hipMemcpy(R.n_mapped.data(), d_meta.p + m, m * 8, hipMemcpyDeviceToHost));
+                SBX_HIP(hipMemcpy(R.n_unmapped.data(), d_meta.p + 2 * m, m * 8, hipMemcpyDeviceToHost));
+                SBX_HIP(hipMemcpy(sc, d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
+                for (int k = 0; k < (int)kBaiScalars; ++k) R.scalars[k] = sc[k];
+                R.last = carry;
+                bytes = bai_assemble(n_ref, R);
+            } else {
+                if (have_held) { held.end_vo = vc.behind(total); bb.put(held); }
+                bytes = bb.finish();
             }
-            cur = next;
-        }
-        if (have_held) { held.end_vo = vc.behind(total); bb.put(held); }
-        if (getenv("SBX_TIMING")) fprintf(stderr, "[sbx] build_index: %u batch(es) of <= %llu inflated bytes\n", n_batches, (unsigned long long)batch_u);
-        const std::vector<uint8_t>& bytes = bb.finish();
+            return true;
+        };
+        const bool host_only = getenv("SBX_BAI_HOST") != nullptr;
+        bool on_device = !host_only;
+        if (on_device && !pass(true)) on_device = false;
+        if (!on_device) pass(false);
+        if (getenv("SBX_TIMING"))
+            fprintf(stderr, "[sbx] build_index: %u batch(es) of <= %llu inflated bytes, records consumed %s\n", n_batches, (unsigned long long)batch_u,
+                    on_device ? "on the device" : "by the serial builder on the host");
         FILE* f = fopen(bai_path, "wb");
         if (!f) throw Error(SBX_EIO, std::string("cannot write ") + bai_path);
         const bool ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();

@@ -233,6 +233,9 @@ void launch_bgzf_deflate(const uint8_t* d_in, uint64_t n_bytes, uint32_t n_block
                          uint8_t* d_work, uint32_t* d_block_len, hipStream_t stream);
 void launch_pack_blocks(const uint8_t* d_slots, const uint32_t* d_block_len, const uint64_t* d_offset, uint32_t n_blocks, uint8_t* d_out,
                         hipStream_t stream);
+struct BaiArgs;
+struct BaiCarry;
+void launch_bai_records(const BaiArgs& a, BaiCarry* d_carry_out, hipStream_t stream);      // bai_parallel.hpp
 void launch_gather_bins(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, uint16_t* d_bins, hipStream_t stream);
 
 // K6 format_base_rows (format.hip): text of `depth base` for positions [beg, end) of one contig

@@ -3,6 +3,9 @@
 // on the CPU against the .bai files the reference's own test-suite ships.  Virtual offsets come from the same VoffCursor
 // sbx_build_index applies to the device's record offsets (engine.cpp).
 //   g++ -O2 -std=c++17 -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ bai_host.cpp -lz
+// `bai_host in.bam out.bai --parallel SEED`: the same file from bai_parallel.hpp -- the per-record step the device runs one lane
+// per record, called here for the records of random batches in shuffled order, then bai_assemble.  Exit 3: the step called the
+// input irregular (the engine then uses the serial builder).
 #include <zlib.h>
 
 #include <cstdint>
@@ -12,6 +15,9 @@
 #include <vector>
 
 #include "../../sambamba_amd/csrc/bai_writer.hpp"
+#include "../../sambamba_amd/csrc/bai_parallel.hpp"
+
+#include <random>
 
 static uint32_t ld32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint16_t ld16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
@@ -51,6 +57,81 @@ int main(int argc, char** argv) {
     const int n_ref = (int)ld32(&U[o]);
     o += 4;
     for (int r = 0; r < n_ref; ++r) o += 8 + ld32(&U[o]);
+    if (argc >= 5 && std::string(argv[3]) == "--parallel") {
+        std::mt19937_64 rng((uint64_t)atoll(argv[4]));
+        std::vector<int32_t> ref_len;
+        {
+            uint64_t q = 8 + ld32(&U[4]) + 4;
+            for (int r = 0; r < n_ref; ++r) { const uint32_t ln = ld32(&U[q]); ref_len.push_back((int32_t)ld32(&U[q + 4 + ln])); q += 8 + ln; }
+        }
+        // descriptors as index.hip's describe leaves them (rec_off relative to the batch's first inflated byte: here the file's)
+        std::vector<sbx::RecDesc> desc;
+        std::vector<int32_t> refs;
+        uint64_t p = o;
+        while (p + 4 <= U.size()) {
+            const uint32_t bs = ld32(&U[p]);
+            const uint8_t* r = &U[p + 4];
+            sbx::RecDesc d{};
+            d.rec_off = p;
+            d.pos = (int32_t)ld32(r + 4);
+            d.flag = ld16(r + 14);
+            const uint32_t l_name = r[8], n_cigar = ld16(r + 12);
+            int64_t span = 0;
+            for (uint32_t k = 0; k < n_cigar; ++k) {
+                const uint32_t op = ld32(r + 32 + l_name + 4 * k), ty = op & 15u;
+                if (ty == 0 || ty == 2 || ty == 3 || ty == 7 || ty == 8) span += op >> 4;
+            }
+            const int32_t rid = (int32_t)ld32(r);
+            const bool admitted = !(d.flag & 4) && rid >= 0 && span > 0;
+            d.end = admitted ? d.pos + (int32_t)span : d.pos;
+            desc.push_back(d);
+            refs.push_back(rid);
+            p += 4 + (uint64_t)bs;
+        }
+        sbx::BaiHostResults R;
+        R.lin_off.assign((size_t)n_ref + 1, 0);
+        for (int r = 0; r < n_ref; ++r) R.lin_off[(size_t)r + 1] = R.lin_off[(size_t)r] + sbx::bai_windows_for(ref_len[(size_t)r]);
+        R.lin.assign(R.lin_off[(size_t)n_ref] + 1, ~0ull);
+        R.lin_len.assign((size_t)n_ref + 1, 0);
+        R.meta_end.assign((size_t)n_ref + 1, 0);
+        R.n_mapped.assign((size_t)n_ref + 1, 0);
+        R.n_unmapped.assign((size_t)n_ref + 1, 0);
+        unsigned long long scalars[sbx::kBaiScalars] = {0};
+        scalars[sbx::kBaiFirstVo] = ~0ull;
+        sbx::BaiCarry carry{-1, 0, 0, 0, 0};
+        for (uint64_t done = 0; done < desc.size();) {
+            const uint64_t n = std::min<uint64_t>(desc.size() - done, 1 + rng() % (desc.size() < 50 ? 7 : desc.size() / 3 + 1));
+            // a batch: its descriptors count from the batch's first byte, like a work list of the engine
+            const uint64_t u_base = desc[done].rec_off;
+            std::vector<sbx::RecDesc> bd(desc.begin() + done, desc.begin() + done + n);
+            for (auto& d : bd) d.rec_off -= u_base;
+            std::vector<sbx::BaiRun> runs(n + 1);
+            scalars[sbx::kBaiNumRuns] = 0;
+            sbx::BaiArgs a{};
+            a.U = U.data() + u_base; a.desc = bd.data(); a.rec_ref = refs.data() + done; a.n = n; a.rec_base = done;
+            a.u_base = u_base; a.u_next = done + n < desc.size() ? desc[done + n].rec_off : p;
+            a.coff = coff.data(); a.ustart = ustart.data(); a.n_blocks = (uint32_t)coff.size(); a.file_end = file_end;
+            a.carry = carry; a.n_ref = n_ref;
+            a.lin = R.lin.data(); a.lin_off = R.lin_off.data(); a.lin_len = R.lin_len.data();
+            a.meta_end = R.meta_end.data(); a.n_mapped = R.n_mapped.data(); a.n_unmapped = R.n_unmapped.data();
+            a.scalars = scalars; a.runs = runs.data(); a.runs_cap = runs.size();
+            std::vector<uint64_t> order(n);
+            for (uint64_t k = 0; k < n; ++k) order[k] = k;
+            std::shuffle(order.begin(), order.end(), rng);
+            for (uint64_t k : order) sbx::bai_record_step(a, k);
+            sbx::bai_carry_out(a, &carry);
+            R.runs.insert(R.runs.end(), runs.begin(), runs.begin() + scalars[sbx::kBaiNumRuns]);
+            done += n;
+        }
+        if (scalars[sbx::kBaiIrregular]) { fprintf(stderr, "irregular input\n"); return 3; }
+        for (int k = 0; k < sbx::kBaiScalars; ++k) R.scalars[k] = scalars[k];
+        R.last = carry;
+        const std::vector<uint8_t> out = sbx::bai_assemble(n_ref, R);
+        FILE* g = fopen(argv[2], "wb");
+        fwrite(out.data(), 1, out.size(), g);
+        fclose(g);
+        return 0;
+    }
     try {
         sbx::BaiBuilder bb(n_ref);
         while (o + 4 <= U.size()) {

@@ -164,3 +164,94 @@ def test_file_without_eof_block_and_empty_block_in_the_middle(bai_host, tmp_path
     for ln in part.splitlines()[1:]:
         assert rows[ln.split(b"\t")[1]] == ln
     assert len(part.splitlines()) > 100
+
+
+# ---- the data-parallel formulation (csrc/bai_parallel.hpp: what the device runs, one lane per record) against the serial builder ----
+def _quirky_bam(path, seed):
+    """Everything IndexBuilder treats specially, at random: reads with a reference but no position in front of / between / behind the
+    placed ones, placed reads with the unmapped flag, reads without CIGAR, long reference skips across 16 kbp windows, empty
+    references in front, in the middle and at the end, a tail of reads without coordinates, small BGZF blocks and block boundaries
+    that fall on record boundaries."""
+    import random
+
+    from tests import bamgen as bg
+    rng = random.Random(seed)
+    n_ref = rng.randrange(1, 7)
+    refs = [("q%d" % k, rng.choice((300, 20000, 70000, 400000))) for k in range(n_ref)]
+    recs = []
+    for r in range(n_ref):
+        if rng.random() < 0.3:
+            continue                                                            # an empty reference
+        pos = rng.randrange(0, 200)
+        L = refs[r][1]
+        if rng.random() < 0.3:
+            recs.append(bg.make_record(r, -1, "", "ACGT", 30, name="nopos%d" % r, flag=4))       # reference, no position
+        while pos < L - 10:
+            kind = rng.randrange(10)
+            if kind == 0:
+                recs.append(bg.make_record(r, pos, "", "ACGTAC", 30, name="pu%d_%d" % (r, pos), flag=4))      # placed, unmapped
+            elif kind == 1:
+                recs.append(bg.make_record(r, pos, "", "ACGTAC", 30, name="nc%d_%d" % (r, pos)))              # no CIGAR
+            elif kind == 2 and pos + 1100 < L:
+                n = rng.randrange(1000, min(40000, L - pos - 20))
+                recs.append(bg.make_record(r, pos, "10M%dN10M" % n, "A" * 20, 30, name="sk%d_%d" % (r, pos)))
+            elif kind == 3:
+                recs.append(bg.make_record(r, pos, "5S20M2I8M3D10M", "C" * 45, 30, name="x%d_%d" % (r, pos)))
+            else:
+                n = rng.choice((36, 100, 150))
+                recs.append(bg.make_record(r, pos, "%dM" % n, "G" * n, 30, name="m%d_%d" % (r, pos)))
+            pos += rng.choice((0, 0, 1, 7, 40, 300, 5000))
+        if rng.random() < 0.2:
+            recs.append(bg.make_record(r, L - 1, "", "ACGT", 30, name="tail%d" % r, flag=4))
+    for k in range(rng.randrange(0, 9)):
+        recs.append(bg.make_record(-1, -1, "", "ACGT", 30, name="nocoor%d" % k, flag=4))
+    cuts = None
+    if rng.random() < 0.5 and recs:
+        # block boundaries on record boundaries (the "behind the last byte of a block" rule of the virtual offsets)
+        hdr_len = len(bg.bam_header("@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs), refs))
+        offs, o = [], hdr_len
+        for rec in recs:
+            offs.append(o)
+            o += len(rec)
+        cuts = sorted(set(rng.sample(offs, min(len(offs), rng.randrange(1, 6)))))
+    bg.write_bam(path, refs, recs, block_size=rng.choice((600, 3000, 0xFF00)), cuts=cuts, write_index=False)
+    return len(recs)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_parallel_formulation_equals_the_serial_builder_on_the_fixtures(bai_host, tmp_path, name):
+    bam = os.path.join(GOLDEN, name + ".bam")
+    serial = str(tmp_path / "s.bai")
+    subprocess.check_call([bai_host, bam, serial])
+    for seed in (1, 2, 3):                       # other batch sizes, another order of the records
+        par = str(tmp_path / ("p%d.bai" % seed))
+        subprocess.check_call([bai_host, bam, par, "--parallel", str(seed)])
+        assert open(par, "rb").read() == open(serial, "rb").read()
+
+
+def test_parallel_formulation_equals_the_serial_builder_on_quirky_bams(bai_host, tmp_path):
+    n_total = 0
+    for seed in range(60):
+        bam = str(tmp_path / ("q%d.bam" % seed))
+        n_total += _quirky_bam(bam, seed)
+        serial, par = str(tmp_path / "s.bai"), str(tmp_path / "p.bai")
+        subprocess.check_call([bai_host, bam, serial])
+        subprocess.check_call([bai_host, bam, par, "--parallel", str(seed + 100)])
+        assert open(par, "rb").read() == open(serial, "rb").read(), seed
+    assert n_total > 5000
+
+
+def test_parallel_formulation_refuses_what_the_loop_treats_specially(bai_host, tmp_path):
+    """unsorted input: the step raises `irregular` (exit 3 of the harness); the engine then runs the serial builder, which words the
+    reference's error"""
+    from tests import bamgen as bg
+    bam = str(tmp_path / "u.bam")
+    recs = [bg.make_record(0, 500, "10M", "A" * 10, 30, name="a"), bg.make_record(0, 100, "10M", "A" * 10, 30, name="b")]
+    bg.write_bam(bam, [("c", 1000)], recs, write_index=False)
+    assert subprocess.run([bai_host, bam, str(tmp_path / "p.bai"), "--parallel", "1"], stderr=subprocess.DEVNULL).returncode == 3
+    assert subprocess.run([bai_host, bam, str(tmp_path / "s.bai")], stderr=subprocess.DEVNULL).returncode == 1
+    # a read far beyond the end of its reference: more linear-index windows than the reference's length asks for
+    bam = str(tmp_path / "o.bam")
+    bg.write_bam(bam, [("c", 1000)], [bg.make_record(0, 900, "10M90000N10M", "A" * 20, 30, name="a")], write_index=False)
+    assert subprocess.run([bai_host, bam, str(tmp_path / "p.bai"), "--parallel", "1"], stderr=subprocess.DEVNULL).returncode == 3
+    assert subprocess.run([bai_host, bam, str(tmp_path / "s.bai")], stderr=subprocess.DEVNULL).returncode == 0

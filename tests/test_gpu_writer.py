@@ -233,6 +233,65 @@ def test_index_is_built_in_batches_of_blocks(small_bam, tmp_path, monkeypatch, b
     monkeypatch.setenv("SBX_INDEX_BATCH_BYTES", batch)
     sambamba_amd.build_index(many)
     assert open(many + ".bai", "rb").read() == open(one + ".bai", "rb").read()
+    # the records of a batch are consumed on the device (bai_parallel.hpp: one lane per record); IndexBuilder's loop restated on the
+    # host (SBX_BAI_HOST=1: the path of irregular input) writes the same file
+    host = str(tmp_path / "host.bam")
+    shutil.copy(small_bam, host)
+    monkeypatch.setenv("SBX_BAI_HOST", "1")
+    sambamba_amd.build_index(host)
+    assert open(host + ".bai", "rb").read() == open(one + ".bai", "rb").read()
+
+
+def _build_index_in_a_process(bam, **env):
+    """sbx_build_index in a python of its own with SBX_TIMING=1: (stderr, bytes of the index)"""
+    import sys
+    e = dict(os.environ, SBX_TIMING="1", **env)
+    r = subprocess.run([sys.executable, "-c", "import sys, sambamba_amd; sambamba_amd.build_index(sys.argv[1])", bam], env=e, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    return r.stderr, open(bam + ".bai", "rb").read()
+
+
+def test_index_records_are_consumed_on_the_device(small_bam, tmp_path):
+    """Which consumer ran is not visible in the file (they write the same bytes), so the library says it (SBX_TIMING): the device by
+    default; the serial builder with SBX_BAI_HOST=1 and for input the device formulation calls irregular -- here a read that reaches
+    90 kbp beyond the end of its reference (more linear-index windows than the reference's length asks for)."""
+    bam = str(tmp_path / "d.bam")
+    shutil.copy(small_bam, bam)
+    err, dev = _build_index_in_a_process(bam)
+    assert b"records consumed on the device" in err
+    err, host = _build_index_in_a_process(bam, SBX_BAI_HOST="1")
+    assert b"by the serial builder on the host" in err and host == dev
+    odd = str(tmp_path / "odd.bam")
+    bg.write_bam(odd, [("c", 1000), ("d", 50000)], [bg.make_record(0, 900, "10M90000N10M", "A" * 20, 30, name="a"),
+                                                      bg.make_record(1, 5, "20M", "C" * 20, 30, name="b")], write_index=False)
+    err, got = _build_index_in_a_process(odd)
+    assert b"by the serial builder on the host" in err
+    from tests.test_bai_cpu import SRC as BAI_SRC
+    exe = str(tmp_path / "bai_host")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe, BAI_SRC, "-lz"])
+    subprocess.check_call([exe, odd, odd + ".host.bai"])
+    assert got == open(odd + ".host.bai", "rb").read()
+
+
+def test_device_index_of_quirky_bams_equals_the_serial_builder(tmp_path, monkeypatch):
+    """tests/test_bai_cpu.py's random BAMs -- reads with a reference but no position, placed reads with the unmapped flag, reads
+    without CIGAR, long skips, empty references, block boundaries on record boundaries --: the index the device builds in one batch
+    and in batches of a block or two, against the serial builder fed by zlib on the host (tests/native/bai_host.cpp)."""
+    from tests.test_bai_cpu import SRC as BAI_SRC, _quirky_bam
+    exe = str(tmp_path / "bai_host")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe, BAI_SRC, "-lz"])
+    for seed in range(2000, 2016):
+        bam = str(tmp_path / ("q%d.bam" % seed))
+        _quirky_bam(bam, seed)
+        subprocess.check_call([exe, bam, bam + ".host.bai"])
+        want = open(bam + ".host.bai", "rb").read()
+        for batch in (None, "1500"):
+            if batch:
+                monkeypatch.setenv("SBX_INDEX_BATCH_BYTES", batch)
+            sambamba_amd.build_index(bam)
+            monkeypatch.delenv("SBX_INDEX_BATCH_BYTES", raising=False)
+            assert open(bam + ".bai", "rb").read() == want, (seed, batch)
 
 
 def test_index_batches_with_records_longer_than_a_block(tmp_path, monkeypatch):
