@@ -5,8 +5,10 @@
 // (a chunk that starts in the BGZF block the previous chunk of its bin ended in is merged into it, :215-240), the linear
 // index keeps the start offset of the first read of every 16 kbp window a read overlaps (:128-156, empty windows
 // repeat the last non-empty one when written, :158-170), every reference ends with samtools' metadata pseudo-bin 37450
-// (:182-188) and the file with the number of reads without coordinates (:341).  The record fields come from the device
-// (index.hip describe + deflate.hip gather_bins); this part is the small serial bookkeeping, on the host.
+// (:182-188) and the file with the number of reads without coordinates (:341).  sbx_build_index computes all of this on the
+// device (bai_parallel.hpp: one step per record, no loop-carried state); this file is the loop as the reference has it -- the
+// checker of that formulation (tests/native/bai_host.cpp) and the path for input it calls irregular (unsorted reads, whose error is
+// worded here; SBX_BAI_HOST=1), fed record by record from descriptors copied back from the device.
 // Bins are written in ascending id order (the reference iterates a D associative array: its order is unspecified).
 #pragma once
 #include <algorithm>
