@@ -963,7 +963,17 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // by their own lane with a second 16-byte step; and a short self-overlapping match (a run, a dinucleotide repeat: 0.8 per
 // batch, 84 % with a period of at most 8) is no longer expanded byte by byte but with four byte permutes of the period
 // (v_perm_b32, selectors per period from a 128-byte table in LDS).
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32>
+// kJump (variant 2, written at the end of round 4 when the GPU budget was spent: NOT YET RUN ON A DEVICE, off by default; its
+// algorithm is checked on the CPU, tests/cpp/inflate2_host.cpp `--jump`): the rounds of phase B below cost ~2,000 of the ~3,400
+// instructions a wavefront executes per batch (5.6 rounds, every kind of copy predicated in every round).  The near matches are
+// resolved per OUTPUT BYTE instead: every position of the batch gets the position its byte comes from -- itself for literal and
+// far-match bytes, which phase A has already put into the window; q - dist inside a near match (a self-overlapping match
+// simply points into itself) --, the pointers are followed to a byte that is final (the window below the batch, a literal, a
+// far-match byte), and the byte is copied.  Positions are taken 64 at a time in increasing order, so everything a pointer
+// meets below the current group is already final: one lookup resolves a byte whose source lies in an earlier group, bytes that
+// depend on bytes of their own group (short distances, runs) take a few more.  No divergence, no per-kind code paths: ~35
+// instructions per position and group.
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kJump = false>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -1059,6 +1069,57 @@ __device__ __forceinline__ void lz77_resolve_body(
         const uint32_t s_hi = src + (len < dist ? len : dist);
         const uint32_t dsto = dst - base, srco = src - base;
         bool pending = len != 0 && !far;
+        if (kJump) {
+            // origins, one u16 per position of the batch (window coordinates), behind the windows and the selector table
+            uint16_t* org = (uint16_t*)(smem + (kResThreads / 64) * kWaveLds + 128u) + wv * kSpanMax;
+            const uint32_t lo = opos - base;                       // window offset of the batch's first byte
+            if (__any(pending)) {
+                const uint32_t k = (span + 63u) >> 6;              // groups of 64 positions
+                // 1. marks: the lane of every near match at its first byte, 0xFFFF elsewhere
+                for (uint32_t i = 0; i < k; ++i) org[i * 64u + lane] = 0xFFFFu;
+                if (pending) org[dsto - lo] = (uint16_t)lane;
+                // 2. owner of a position = the last mark at or before it: lane L scans positions [L k, L k + k), the last mark of the lanes
+                //    below it comes from a max-scan over the lanes (marks increase with the position)
+                uint32_t last = 0;                                 // lane + 1 of the last mark in this lane's stretch, 0 = none
+                for (uint32_t i = 0; i < k; ++i) { const uint32_t m = org[lane * k + i]; last = m != 0xFFFFu ? m + 1u : last; }
+                uint32_t incl = last;
+                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true));     // row_shr:1
+                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true));     // row_shr:2
+                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true));     // row_shr:4
+                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true));     // row_shr:8
+                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false));    // row_bcast:15
+                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false));    // row_bcast:31
+                uint32_t run = (uint32_t)__shfl_up((int)incl, 1, 64);
+                if (lane == 0) run = 0;
+                for (uint32_t i = 0; i < k; ++i) {
+                    const uint32_t q = lane * k + i, m = org[q];
+                    run = m != 0xFFFFu ? m + 1u : run;
+                    org[q] = (uint16_t)(run ? run - 1u : 0xFFFFu);
+                }
+                // 3. group by group: origin, resolution, the byte
+                const uint32_t cover = pending ? ((dsto - lo + len) << 16) | dist : 0u;      // end of the match (batch-relative) | distance
+                for (uint32_t i = 0; i < k; ++i) {
+                    const uint32_t q = i * 64u + lane, g0 = i * 64u;
+                    const uint32_t e = org[q];
+                    const uint32_t cv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e & 63u) << 2), (int)cover);
+                    const bool cov = q < span && e != 0xFFFFu && q < (cv >> 16);
+                    uint32_t o = cov ? q + lo - (cv & 0xFFFFu) : q + lo;            // (a near match: dist <= window offset of its first byte)
+                    bool open = cov && o >= lo;
+                    org[q] = (uint16_t)o;
+                    while (__any(open)) {
+                        if (open) {
+                            const uint32_t sl = o - lo, o2 = org[sl];
+                            if (sl < g0) { o = o2; open = false; }                 // a finished group's slot holds a final origin
+                            else if (o2 == o) open = false;                        // its own origin: a literal or far-match byte of this group
+                            else { o = o2; open = o >= lo; }
+                            org[q] = (uint16_t)o;
+                        }
+                    }
+                    if (cov) buf[q + lo] = buf[o];
+                }
+            }
+            pending = false;
+        }
         for (uint64_t pm = __ballot(pending); pm; pm = __ballot(pending)) {
             const uint32_t F = __builtin_amdgcn_readlane(dst, __builtin_ctzll(pm));
             const bool ready = pending && s_hi <= F;
@@ -1161,6 +1222,12 @@ template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_o32(SBX_LZ77_ARGS) {
     lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS);
 }
+// variant 2 (see kJump above): phase A of variant 1, near matches by origin pointers; LDS per wave: window + 2 bytes per batch position
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) void k_lz77_resolve_jump(SBX_LZ77_ARGS) {
+    lz77_resolve_body<kHist, kSpanMax, true, true>(SBX_LZ77_PASS);
+}
+constexpr uint32_t kHistJump = 2048, kSpanJump = 1024;
 
 }  // namespace
 
@@ -1237,6 +1304,10 @@ void launch_k1b(const InflateArgs& a, hipStream_t stream) {
     if (variant == 0)
         hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
                            a.n_blocks, a.block0, a.out, a.status);
+    else if (variant == 2)
+        hipLaunchKernelGGL((k_lz77_resolve_jump<kHistJump, kSpanJump>), grid, block,
+                           (size_t)(kResThreads / 64) * (kHistJump + 1024u + kSpanJump + 16u + 2u * kSpanJump) + 128, stream, a.lit, a.ent, a.nent,
+                           a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
     else
         hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, a.lit, a.ent, a.nent, a.out_off,
                            a.isize, a.n_blocks, a.block0, a.out, a.status);

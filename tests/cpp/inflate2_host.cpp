@@ -27,9 +27,101 @@ static std::vector<uint8_t> read_file(const char* path) {
     return v;
 }
 
+// K1b variant 2 (inflate.hip, kJump) step by step on the CPU -- the algorithm, not the HIP code: batches of <= 64 entries and
+// <= kSpan bytes, a window that keeps >= kHist bytes below the batch, literal and far-match bytes put in place first (phase A), then
+// every near-match byte resolved through origin pointers, positions taken 64 at a time in increasing order, the 64 lanes of a
+// group in lockstep (all reads of a step before its writes).  Returns false on an inconsistency.
+static bool resolve_jump(const uint32_t* ent, uint32_t n_ent, const uint8_t* lit, uint32_t isize, std::vector<uint8_t>& out,
+                         long* n_lookups, long* n_positions, long* n_groups = nullptr, long* n_steps = nullptr) {
+    constexpr uint32_t kHist = 2048, kSpan = 1024, kCap = kHist + 1024 + kSpan;
+    out.assign(isize, 0);
+    std::vector<uint8_t> buf(kCap + 64, 0xDD);
+    std::vector<uint16_t> org(kSpan, 0);
+    uint32_t opos = 0, lpos = 0, base = 0;
+    for (uint32_t e0 = 0; e0 < n_ent;) {
+        // the batch: <= 64 entries whose inclusive sums stay <= kSpan (at least one entry: <= 513 bytes)
+        uint32_t take = 0, span = 0, lspan = 0;
+        uint32_t lr[64], len[64], dist[64], eo[64], el[64];
+        while (take < 64 && e0 + take < n_ent) {
+            const uint32_t e = ent[e0 + take], l = e >> 24, n = e & 511u;
+            if (span + l + n > kSpan) break;
+            lr[take] = l; len[take] = n; dist[take] = ((e >> 9) & 0x7FFFu) + 1u;
+            eo[take] = opos + span; el[take] = lpos + lspan;
+            span += l + n; lspan += l;
+            ++take;
+        }
+        if (!take) return false;
+        if (opos + span > isize) return false;
+        // slide
+        if (opos - base + kSpan > kCap) {
+            const uint32_t nb = (opos - kHist) & ~15u, delta = nb - base, keep = opos - nb;
+            memmove(buf.data(), buf.data() + delta, keep);
+            base = nb;
+        }
+        const uint32_t lo = opos - base;
+        // phase A: literals and far matches (source below the window: final output)
+        bool near[64];
+        for (uint32_t t = 0; t < take; ++t) {
+            for (uint32_t i = 0; i < lr[t]; ++i) buf[eo[t] - base + i] = lit[el[t] + i];
+            const uint32_t dst = eo[t] + lr[t];
+            near[t] = false;
+            if (len[t]) {
+                if (dist[t] > dst) return false;
+                const uint32_t src = dst - dist[t];
+                if (src < base) { for (uint32_t i = 0; i < len[t]; ++i) buf[dst - base + i] = out[src + i]; }      // (never self-overlapping: kHist > 258)
+                else near[t] = true;
+            }
+        }
+        // phase B: marks -> owners (last mark at or before a position)
+        const uint32_t k = (span + 63) / 64;
+        for (uint32_t q = 0; q < 64 * k; ++q) org[q] = 0xFFFF;
+        for (uint32_t t = 0; t < take; ++t) if (near[t]) org[eo[t] + lr[t] - opos] = (uint16_t)t;
+        { uint32_t run = 0xFFFF; for (uint32_t q = 0; q < 64 * k; ++q) { if (org[q] != 0xFFFF) run = org[q]; org[q] = (uint16_t)run; } }
+        for (uint32_t g = 0; g < k; ++g) {
+            const uint32_t g0 = 64 * g;
+            uint32_t o[64];
+            bool open[64], cov[64];
+            for (uint32_t l = 0; l < 64; ++l) {
+                const uint32_t q = g0 + l, e = org[q];
+                cov[l] = q < span && e != 0xFFFF && q < eo[e & 63] + lr[e & 63] - opos + len[e & 63];
+                o[l] = cov[l] ? q + lo - dist[e & 63] : q + lo;
+                open[l] = cov[l] && o[l] >= lo;
+            }
+            for (uint32_t l = 0; l < 64; ++l) org[g0 + l] = (uint16_t)o[l];
+            for (int guard = 0;; ++guard) {
+                bool any = false;
+                for (uint32_t l = 0; l < 64; ++l) any |= open[l];
+                if (!any) break;
+                if (guard > 2000) return false;
+                if (n_steps) ++*n_steps;
+                uint32_t o2[64];
+                for (uint32_t l = 0; l < 64; ++l) if (open[l]) { o2[l] = org[o[l] - lo]; ++*n_lookups; }        // reads of the step
+                for (uint32_t l = 0; l < 64; ++l) {                                                              // ... then its writes
+                    if (!open[l]) continue;
+                    const uint32_t sl = o[l] - lo;
+                    if (sl < g0) { o[l] = o2[l]; open[l] = false; }
+                    else if (o2[l] == o[l]) open[l] = false;
+                    else { o[l] = o2[l]; open[l] = o[l] >= lo; }
+                    org[g0 + l] = (uint16_t)o[l];
+                }
+            }
+            if (n_groups) ++*n_groups;
+            uint8_t v[64];
+            for (uint32_t l = 0; l < 64; ++l) if (cov[l]) { v[l] = buf[o[l]]; ++*n_positions; }
+            for (uint32_t l = 0; l < 64; ++l) if (cov[l]) buf[g0 + l + lo] = v[l];
+        }
+        // phase C
+        memcpy(out.data() + opos, buf.data() + lo, span);
+        opos += span; lpos += lspan; e0 += take;
+    }
+    return opos == isize;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s FILE [lane]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s FILE [lane] [--jump]\n", argv[0]); return 2; }
     const uint32_t lane = argc > 2 ? (uint32_t)atoi(argv[2]) : 0u;
+    const bool jump = argc > 3 && !strcmp(argv[3], "--jump");
+    long n_lookups = 0, n_positions = 0, n_groups = 0, n_steps = 0;
     std::vector<uint8_t> file = read_file(argv[1]);
     std::vector<uint8_t> lds(kWaveLds + kLenTabBytes + kDistTabBytes, 0xA5);
     uint16_t* len_tab = (uint16_t*)(lds.data() + kWaveLds);
@@ -101,6 +193,10 @@ int main(int argc, char** argv) {
                 if (got.size() > isize) ok = false;
             }
             ok = ok && lp == n_lit && got.size() == isize && memcmp(got.data(), want.data(), isize) == 0;
+            if (ok && jump) {
+                std::vector<uint8_t> got2;
+                ok = resolve_jump(ent.data(), R.n_ent, lit_al, isize, got2, &n_lookups, &n_positions, &n_groups, &n_steps) && memcmp(got2.data(), want.data(), isize) == 0;
+            }
             if (!ok) {
                 ++n_bad;
                 if (n_bad < 5) fprintf(stderr, "MISMATCH block %ld at file offset %zu (isize %u, n_lit %u, n_ent %u, got %zu bytes)\n", n_blocks - 1, pos, isize, n_lit, R.n_ent, got.size());
@@ -109,5 +205,8 @@ int main(int argc, char** argv) {
         pos += bsize;
     }
     printf("%ld %ld %ld %ld\n", n_blocks, n_fast, n_general, n_bad);
+    if (jump)
+        fprintf(stderr, "jump: %ld near-match bytes, %.2f pointer lookups per byte; %ld groups of 64 positions, %.2f lockstep steps per group\n", n_positions,
+                n_positions ? (double)n_lookups / n_positions : 0.0, n_groups, n_groups ? (double)n_steps / n_groups : 0.0);
     return n_bad == 0 ? 0 : 1;
 }
