@@ -31,9 +31,12 @@ static std::vector<uint8_t> read_file(const char* path) {
 // <= kSpan bytes, a window that keeps >= kHist bytes below the batch, literal and far-match bytes put in place first (phase A), then
 // every near-match byte resolved through origin pointers, positions taken 64 at a time in increasing order, the 64 lanes of a
 // group in lockstep (all reads of a step before its writes).  Returns false on an inconsistency.
+static long g_far_bytes = 0;
 static bool resolve_jump(const uint32_t* ent, uint32_t n_ent, const uint8_t* lit, uint32_t isize, std::vector<uint8_t>& out,
                          long* n_lookups, long* n_positions, long* n_groups = nullptr, long* n_steps = nullptr) {
-    constexpr uint32_t kHist = 2048, kSpan = 1024, kCap = kHist + 1024 + kSpan;
+    static const uint32_t kHist = getenv("SBX_EMU_HIST") ? (uint32_t)atoi(getenv("SBX_EMU_HIST")) : 2048u;     // (the kernel: 2048)
+    constexpr uint32_t kSpan = 1024;
+    const uint32_t kCap = kHist + 1024 + kSpan;
     out.assign(isize, 0);
     std::vector<uint8_t> buf(kCap + 64, 0xDD);
     std::vector<uint16_t> org(kSpan, 0);
@@ -68,7 +71,7 @@ static bool resolve_jump(const uint32_t* ent, uint32_t n_ent, const uint8_t* lit
             if (len[t]) {
                 if (dist[t] > dst) return false;
                 const uint32_t src = dst - dist[t];
-                if (src < base) { for (uint32_t i = 0; i < len[t]; ++i) buf[dst - base + i] = out[src + i]; }      // (never self-overlapping: kHist > 258)
+                if (src < base) { for (uint32_t i = 0; i < len[t]; ++i) buf[dst - base + i] = out[src + i]; g_far_bytes += len[t]; }      // (never self-overlapping: kHist > 258)
                 else near[t] = true;
             }
         }
@@ -205,6 +208,7 @@ int main(int argc, char** argv) {
         pos += bsize;
     }
     printf("%ld %ld %ld %ld\n", n_blocks, n_fast, n_general, n_bad);
+    if (jump) fprintf(stderr, "jump: %ld far-match bytes (phase A, from global memory)\n", g_far_bytes);
     if (jump)
         fprintf(stderr, "jump: %ld near-match bytes, %.2f pointer lookups per byte; %ld groups of 64 positions, %.2f lockstep steps per group\n", n_positions,
                 n_positions ? (double)n_lookups / n_positions : 0.0, n_groups, n_groups ? (double)n_steps / n_groups : 0.0);
