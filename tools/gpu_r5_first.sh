@@ -1,0 +1,25 @@
+#!/bin/bash
+# The first GPU call of the next round: K1b variant 2 (origin-pointer resolve, inflate.hip kJump -- written at the end of round 4,
+# never run on a device).  1. does it inflate correctly (the inflate tests and the depth fixtures with the variant forced);
+# 2. what is it worth (40 Mbp, then the full config 2), each against variant 1 in the same call.
+# Raw output under /tmp on the box; only the summaries go to gpurun_out/ (64 MiB limit).
+set -u
+OUT=gpurun_out/r5_first
+mkdir -p $OUT
+SBX_K1B_VARIANT=2 timeout 240 python -m pytest tests/test_gpu_inflate.py tests/test_gpu_depth.py tests/test_gpu_edge_cases.py -x -q 2>&1 | tail -8 | tee $OUT/tests_variant2.txt
+for v in 1 2; do
+  SBX_K1B_VARIANT=$v timeout 120 python bench.py --length 40000000 --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --parity-windows 12 > $OUT/bench_40Mbp_k1b_variant$v.json 2> /tmp/bench40_$v.err
+  python - $OUT/bench_40Mbp_k1b_variant$v.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(sys.argv[1], "Mreads/s", d["value"], "ms", d["ms_per_step"], {k: v["ms"] for k, v in d["kernels"].items()}, "parity", d["parity_checked"]["ok"], d["parity_checked"].get("text_ok"))
+PY
+done
+for v in 1 2; do
+  SBX_K1B_VARIANT=$v timeout 400 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > $OUT/bench_config2_k1b_variant$v.json 2> /tmp/bench_full_$v.err
+  python - $OUT/bench_config2_k1b_variant$v.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(sys.argv[1], "Mreads/s", d["value"], "ms", d["ms_per_step"], {k: v["ms"] for k, v in d["kernels"].items()}, "parity", d["parity_checked"]["ok"], d["parity_checked"].get("text_ok"))
+PY
+done
