@@ -1304,11 +1304,19 @@ void launch_k1b(const InflateArgs& a, hipStream_t stream) {
     if (variant == 0)
         hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
                            a.n_blocks, a.block0, a.out, a.status);
-    else if (variant == 2)
-        hipLaunchKernelGGL((k_lz77_resolve_jump<kHistJump, kSpanJump>), grid, block,
-                           (size_t)(kResThreads / 64) * (kHistJump + 1024u + kSpanJump + 16u + 2u * kSpanJump) + 128, stream, a.lit, a.ent, a.nent,
-                           a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
-    else
+    else if (variant == 2) {
+        // (history kept in LDS, SBX_K1B_HIST = 2048 | 4096 | 8192: the far-match share of the output falls from 29 % to 20 % to 13 %
+        // -- DESIGN.md 3 K1b -- for 6, 4 and 3 waves per SIMD)
+        static const int hist = [] { const char* e = getenv("SBX_K1B_HIST"); return e ? atoi(e) : (int)kHistJump; }();
+#define SBX_K1B_JUMP(H)                                                                                                                    \
+        hipLaunchKernelGGL((k_lz77_resolve_jump<H, kSpanJump>), grid, block,                                                                \
+                           (size_t)(kResThreads / 64) * (H + 1024u + kSpanJump + 16u + 2u * kSpanJump) + 128, stream, a.lit, a.ent, a.nent, \
+                           a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status)
+        if (hist == 8192) SBX_K1B_JUMP(8192u);
+        else if (hist == 4096) SBX_K1B_JUMP(4096u);
+        else SBX_K1B_JUMP(kHistJump);
+#undef SBX_K1B_JUMP
+    } else
         hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, a.lit, a.ent, a.nent, a.out_off,
                            a.isize, a.n_blocks, a.block0, a.out, a.status);
     SBX_HIP(hipGetLastError());
