@@ -15,6 +15,14 @@ d = json.load(open(sys.argv[1]))
 print(sys.argv[1], "Mreads/s", d["value"], "ms", d["ms_per_step"], {k: v["ms"] for k, v in d["kernels"].items()}, "parity", d["parity_checked"]["ok"], d["parity_checked"].get("text_ok"))
 PY
 done
+for h in 4096 8192; do
+  SBX_K1B_VARIANT=2 SBX_K1B_HIST=$h timeout 120 python bench.py --length 40000000 --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --parity-windows 12 > $OUT/bench_40Mbp_k1b_variant2_hist$h.json 2> /tmp/bench40_h$h.err
+  python - $OUT/bench_40Mbp_k1b_variant2_hist$h.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(sys.argv[1], "Mreads/s", d["value"], "ms", d["ms_per_step"], {k: v["ms"] for k, v in d["kernels"].items()}, "parity", d["parity_checked"]["ok"], d["parity_checked"].get("text_ok"))
+PY
+done
 for v in 1 2; do
   SBX_K1B_VARIANT=$v timeout 400 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > $OUT/bench_config2_k1b_variant$v.json 2> /tmp/bench_full_$v.err
   python - $OUT/bench_config2_k1b_variant$v.json <<'PY'
