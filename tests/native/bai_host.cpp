@@ -22,7 +22,44 @@
 static uint32_t ld32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint16_t ld16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
 
+// `bai_host --vo-selftest SEED`: the stateless virtual-offset searches of bai_parallel.hpp against the cursor of bai_writer.hpp on
+// random block tables with empty blocks (EOF blocks in the middle of a concatenated file, several in a row) and random record
+// boundaries, queried the way the serial loop queries the cursor (start of record i, end of record i = start of record i + 1)
+static int vo_selftest(uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    for (int trial = 0; trial < 2000; ++trial) {
+        const size_t nb = 1 + rng() % 12;
+        std::vector<uint64_t> coff(nb), ustart(nb + 1, 0);
+        uint64_t c = 0;
+        for (size_t b = 0; b < nb; ++b) {
+            coff[b] = c;
+            c += 28 + rng() % 500;
+            const uint64_t isize = rng() % 3 == 0 ? 0 : 1 + rng() % 300;
+            ustart[b + 1] = ustart[b] + isize;
+        }
+        const uint64_t file_end = c, total = ustart[nb];
+        std::vector<uint64_t> cuts{0};
+        for (uint64_t u = 0; u < total;) { u += 1 + rng() % 120; cuts.push_back(std::min(u, total)); }
+        if (cuts.back() != total) cuts.push_back(total);
+        sbx::VoffCursor vc(coff.data(), ustart.data(), nb, file_end);
+        sbx::BaiArgs a{};
+        a.coff = coff.data(); a.ustart = ustart.data(); a.n_blocks = (uint32_t)nb; a.file_end = file_end;
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+            if (cuts[i] == cuts[i + 1]) continue;
+            const uint64_t s1 = vc.of_byte(cuts[i]), s2 = sbx::bai_vo_of(a, cuts[i]);
+            const uint64_t e1 = vc.behind(cuts[i + 1]), e2 = sbx::bai_vo_behind(a, cuts[i + 1]);
+            if (s1 != s2 || e1 != e2) {
+                fprintf(stderr, "trial %d record %zu: start %llx / %llx, end %llx / %llx\n", trial, i, (unsigned long long)s1, (unsigned long long)s2,
+                        (unsigned long long)e1, (unsigned long long)e2);
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 3 && std::string(argv[1]) == "--vo-selftest") return vo_selftest((uint64_t)atoll(argv[2]));
     if (argc < 3) { fprintf(stderr, "usage: bai_host in.bam out.bai\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }

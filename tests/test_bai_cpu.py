@@ -255,3 +255,10 @@ def test_parallel_formulation_refuses_what_the_loop_treats_specially(bai_host, t
     bg.write_bam(bam, [("c", 1000)], [bg.make_record(0, 900, "10M90000N10M", "A" * 20, 30, name="a")], write_index=False)
     assert subprocess.run([bai_host, bam, str(tmp_path / "p.bai"), "--parallel", "1"], stderr=subprocess.DEVNULL).returncode == 3
     assert subprocess.run([bai_host, bam, str(tmp_path / "s.bai")], stderr=subprocess.DEVNULL).returncode == 0
+
+
+def test_stateless_virtual_offsets_equal_the_cursor(bai_host):
+    """bai_parallel.hpp finds the virtual offsets of a record by binary search in the block table; the serial builder moves a cursor
+    (bai_writer.hpp VoffCursor, the rule of inputstream.d:497-530).  Random tables with empty blocks, 2,000 per seed."""
+    for seed in (1, 2, 3):
+        assert subprocess.run([bai_host, "--vo-selftest", str(seed)]).returncode == 0
