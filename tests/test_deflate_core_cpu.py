@@ -201,3 +201,20 @@ def test_random_mixtures_round_trip_at_every_level(host_encoder, tmp_path):
         for level in (1, 6, 9):
             subprocess.check_call([host_encoder, src, dst, str(level)])
             assert gzip.decompress(open(dst, "rb").read()) == data, (trial, level)
+
+
+def test_known_answers(host_encoder, tmp_path):
+    """The encoder's bytes are part of its contract with the device (tests/test_gpu_writer.py compares the device's stream with this
+    build's, byte for byte): a change of the matcher or of the code construction shows up here, on the CPU, as a changed digest --
+    to be updated knowingly, together with a device run."""
+    import hashlib
+    data = bam_like(300000, 3)
+    assert hashlib.md5(data).hexdigest() == "66160ee26db1622e0b86d2730c6efb1e"          # (the input itself is seeded python code)
+    want = {0: (300155, "4bf1d93369de6a09fa6b55f2be383277"), 1: (155479, "57beebc3875118902a333e7e828e2d1c"),
+            6: (110865, "091827342aea044d075a1dbd026ab259"), 9: (107102, "098d10085f80a36b9d64706986a60e06")}
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    open(src, "wb").write(data)
+    for level, (size, digest) in want.items():
+        subprocess.check_call([host_encoder, src, dst, str(level)])
+        comp = open(dst, "rb").read()
+        assert (len(comp), hashlib.md5(comp).hexdigest()) == (size, digest), level
