@@ -241,6 +241,63 @@ def parity_text(d, bam, ref_name, ref, beg, end, extra_args):
     return hashlib.md5(got).hexdigest(), hashlib.md5(want).hexdigest(), len(got)
 
 
+def parity_full_text(d, bam, intervals, extra_args, min_slices=64, share_of_host=1):
+    """WHOLE-share parity of the timed results: every interval [(ref, beg, end)] is cut into position slices (>= `min_slices` in all,
+    at least one per host core), the oracle CLI prints `depth base -L chr:a-b` for every slice on the host cores in parallel, and
+    the md5 of its rows is compared with the md5 of the device-formatted rows (K6 over the counters the LAST timed pass left)
+    of the same slice.  Every position of the share is covered exactly once.  Returns a dict for `parity_checked`."""
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.time()
+    total = sum(e - b for _, b, e in intervals)
+    if total <= 0:
+        return {"coverage": 0.0, "slices": 0, "ok": True}
+    ncpu = max(1, (os.cpu_count() or 8) // max(1, share_of_host))      # (the ranks of a node share its cores)
+    n_slices = max(min_slices, min(ncpu, 256))
+    step = max(1024, -(-total // n_slices) // 1024 * 1024 + 1024)
+    slices = [(r, a, min(e, a + step)) for r, b, e in intervals for a in range(b, e, step)]
+    oracle = os.path.join(ROOT, "oracle", "depth_oracle")
+
+    def want_md5(sl):
+        r, a, b = sl
+        p = subprocess.Popen([oracle, "base"] + extra_args + ["-L", "%s:%d-%d" % (d.ref_names[r], a + 1, b), bam],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=0)
+        h, n, first = hashlib.md5(), 0, True
+        while True:
+            buf = p.stdout.read(1 << 22)
+            if not buf:
+                break
+            if first:                       # drop the header line
+                nl = buf.find(b"\n")
+                if nl < 0:
+                    continue
+                buf, first = buf[nl + 1:], False
+            h.update(buf)
+            n += len(buf)
+        if p.wait() != 0:
+            return None, n
+        return h.hexdigest(), n
+
+    workers = max(1, min(len(slices), ncpu))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        fut = [ex.submit(want_md5, sl) for sl in slices]
+        # the device side next to the oracle processes: format, hash, drop
+        hpool = ThreadPoolExecutor(max_workers=4)
+        got = []
+        for r, a, b in slices:
+            txt = d.format_base_rows(r, a, b)
+            got.append((hpool.submit(lambda t=txt: hashlib.md5(t).hexdigest()), len(txt)))
+        got = [(f.result(), n) for f, n in got]
+        hpool.shutdown()
+        want = [f.result() for f in fut]
+    bad = [list(slices[i]) for i in range(len(slices)) if got[i][0] != want[i][0] or got[i][1] != want[i][1]]
+    allmd5 = hashlib.md5("".join(g[0] for g in got).encode()).hexdigest()
+    return {"coverage": round(sum(b - a for _, a, b in slices) / float(total), 6), "slices": len(slices), "ok": not bad,
+            "mismatching_slices": bad[:4], "text_bytes": int(sum(n for _, n in got)), "md5_of_slice_md5s": allmd5,
+            "host_workers": workers, "seconds": round(time.time() - t0, 1),
+            "what": "md5 of ALL device-formatted rows of this rank's share (K6 over the counters of the last timed pass), slice by slice, "
+                    "against `depth_oracle base -L chr:a-b` run for every slice on the host cores"}
+
+
 def cli_e2e(bam, mode_args, reads):
     """The product CLI end to end: file (page cache) -> device -> text on /dev/null, wall clock of the command as ONE process,
     teardown of the device context included (`seconds`: the like-for-like figure next to cpu_baseline).  Three runs, the best is
@@ -415,6 +472,11 @@ class Job:
                 md_got, md_want, nbytes = parity_text(d, path, d.ref_names[ref], ref, a2, b2, self.mode_args[1:])
                 par.update({"text_slab": [ref, a2, b2], "text_bytes": nbytes, "text_md5": md_got, "text_ok": md_got == md_want})
                 par["ok"] = par["ok"] and md_got == md_want
+                if args.full_parity:
+                    full = parity_full_text(d, path, ivs, self.mode_args[1:], share_of_host=self.world)
+                    par["full_text"] = full
+                    par["coverage"] = full["coverage"]
+                    par["ok"] = par["ok"] and full["ok"]
         if n_windows > 0 and args.config in (3, 4) and my is None:
             # window / region statistics against the oracle's `depth region -L chr:a-b` (a window is the region [k w, (k + 1) w);
             # the reads come through the BAI, seconds per call).  Config 3 streams the genome in batches and only the last one is
@@ -492,6 +554,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="N > 1: skip the strong-scaling / all-reduce side measurements")
     ap.add_argument("--parity-windows", type=int, default=8)
+    ap.add_argument("--no-full-parity", dest="full_parity", action="store_false",
+                    help="skip the whole-share comparison of the device text with the oracle (configs 2 and 5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

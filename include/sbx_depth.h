@@ -172,9 +172,13 @@ int sbx_build_index(const char* bam_path, const char* bai_path, int device, char
  * Several BAMs are processed as the reference's merged stream would be: the pileup of the merge is the union
  * of the files' reads, so every file goes through the device pipeline on its own and the per-position results
  * are added up; samples are the union of the @RG SM values in order of first appearance (depth.d:1170-1181 over
- * the merged header) and every file keeps its own RG-id -> sample table.  The files must have identical
- * reference dictionaries (SBX_EUNSUPPORTED otherwise; the reference also merges compatible, non-identical
- * ones).  With -m, mates are paired within a file only.
+ * the merged header) and every file keeps its own RG-id -> sample table.  Reference dictionaries that differ
+ * but are compatible are merged the way SamHeaderMerger does it (samheadermerger.d:127-177: a topological order
+ * of the union of the @SQ lists; every context then holds the MERGED dictionary, ref_id arguments and results of
+ * this API are ids of the merged dictionary, and the records' own ids are translated when they are read, as
+ * adjustTagsInRange does, multireader.d:174-190).  Dictionaries that cannot be merged -- one name with two
+ * lengths, contradicting orders -- fail with SBX_EUNSUPPORTED and the reference's message.  With -m, mates
+ * are paired within a file only.
  * device = HIP device ordinal (or -1: use LOCAL_RANK / 0). */
 sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* err, size_t errlen);
 void sbx_close(sbx_ctx*);

@@ -33,6 +33,7 @@
 namespace sbx {
 
 constexpr uint32_t kBaiWindows = 37450 - 4681 + 1;     // linear-index windows IndexBuilder keeps per reference (indexing.d:66)
+constexpr uint32_t kBaiBackScan = 256;                   // records bai_record_step looks back for the placed record before its own
 
 struct BaiRun {            // a chunk in the making: its first record
     uint64_t rec;          // index of the record in the file (runs are sorted by it on the host)
@@ -147,10 +148,18 @@ __host__ __device__ inline void bai_record_step(const BaiArgs& a, uint64_t i) {
     int32_t pref = -1, ppos = 0;
     uint32_t pbin = 0;
     uint64_t pevo = 0;
-    for (uint64_t j = i; j-- > 0;) {
-        const BaiFields g = bai_fields(a, j);
-        if (g.placed) { have_p = true; pref = g.ref; ppos = g.pos; pbin = g.bin; pevo = bai_end_vo(a, j); break; }
+    // (a stretch of more than kBaiBackScan records with a reference but no position in front of this one -- O(n^2) loads in one launch
+    // if every record of a long stretch walked all of it -- is irregular input: the serial builder takes the file)
+    bool scan_cut = false;
+    {
+        uint32_t steps = 0;
+        for (uint64_t j = i; j-- > 0;) {
+            const BaiFields g = bai_fields(a, j);
+            if (g.placed) { have_p = true; pref = g.ref; ppos = g.pos; pbin = g.bin; pevo = bai_end_vo(a, j); break; }
+            if (++steps >= kBaiBackScan) { scan_cut = true; break; }
+        }
     }
+    if (scan_cut) { aadd(sc + kBaiIrregular, 1); return; }
     if (!have_p && a.carry.have) { have_p = true; pref = a.carry.ref; ppos = a.carry.pos; pbin = a.carry.bin; pevo = a.carry.end_vo; }
     // checkThatInputIsSorted (:242-257)
     if (have_p && !(pref < f.ref || (pref == f.ref && f.pos >= ppos))) aadd(sc + kBaiIrregular, 1);

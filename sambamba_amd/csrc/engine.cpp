@@ -26,6 +26,14 @@
 
 namespace sbx {
 
+// Padding behind the compressed bytes on the device.  The fast K1a lane (inflate2_core.hpp) prefetches its input 16 bytes at a time and
+// tests the end of the block's payload only between deflate blocks: on a corrupt stream a lane may go on decoding what follows its
+// block until its output position passes ISIZE.  Every literal/length symbol it consumes (<= 15 bits, <= 48 with a match) produces at
+// least one output byte of at most 65536, and it reads at most kMaxSeg block headers (<= 600 bytes each), so it can run at most
+// ~128 KiB beyond its own block -- into the following blocks, or, for the last blocks of a batch, into this padding.  (The general
+// kernel, which re-decodes every block the fast one flags, tests its input per symbol.)
+constexpr size_t kCompPad = 192 * 1024;
+
 void require_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -473,7 +481,7 @@ void make_resident(sbx_ctx* c, std::vector<FileRun> runs) {
     }
     SBX_HIP(hipMemcpyAsync(c->d_out_off.p, w.out_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
     if (!c->preloaded) {
-        c->d_comp.ensure((size_t)w.comp_bytes + 64);
+        c->d_comp.ensure((size_t)w.comp_bytes + kCompPad);
         upload_ranges(c, w.ranges);
         SBX_HIP(hipStreamSynchronize(c->copy_stream));
         clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -502,7 +510,7 @@ void inflate_worklist(sbx_ctx* c, hipEvent_t ev_mid) {
 void inflate_prefix(sbx_ctx* c, uint32_t k, std::vector<uint8_t>* host) {
     const BlockTable& bt = c->blocks;
     const uint64_t in_end = bt.comp_off[k - 1] + bt.comp_len[k - 1], out_end = bt.out_off[k];
-    DevBuf<uint8_t> d_in(in_end + 64), d_out(out_end + 128), d_scr(inflate_scratch_bytes(k)), d_lit(inflate_lit_bytes(out_end, k));
+    DevBuf<uint8_t> d_in(in_end + kCompPad), d_out(out_end + 128), d_scr(inflate_scratch_bytes(k)), d_lit(inflate_lit_bytes(out_end, k));
     DevBuf<uint32_t> d_ent(inflate_ent_words(out_end, k)), d_nent(k), d_clen(k), d_isz(k), d_st(k);
     DevBuf<uint64_t> d_coff(k), d_ooff(k);
     SBX_HIP(hipMemset(d_in.p + in_end, 0, 64));
@@ -571,7 +579,7 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
             in_end = std::max(in_end, comp_off[i] + comp_len[i]);
             out_end = std::max(out_end, out_off[i] + isize[i]);
         }
-        DevBuf<uint8_t> d_in(in_end + 64), d_out(out_end + 64), d_scr(inflate_scratch_bytes(n_blocks));
+        DevBuf<uint8_t> d_in(in_end + kCompPad), d_out(out_end + 64), d_scr(inflate_scratch_bytes(n_blocks));
         DevBuf<uint8_t> d_lit(inflate_lit_bytes(out_end, n_blocks));
         DevBuf<uint32_t> d_ent(inflate_ent_words(out_end, n_blocks)), d_nent(n_blocks);
         DevBuf<uint64_t> d_coff(n_blocks), d_ooff(n_blocks);
@@ -864,7 +872,7 @@ int sbx_preload(sbx_ctx* c) {
             if (m->preloaded) continue;
             struct timespec t0, t1;
             clock_gettime(CLOCK_MONOTONIC, &t0);
-            m->d_comp.alloc(m->file.size + 64);
+            m->d_comp.alloc(m->file.size + kCompPad);
             SBX_HIP(hipMemsetAsync(m->d_comp.p + m->file.size, 0, 64, m->copy_stream));
             upload_ranges(m, {{0, m->file.size, 0}});
             SBX_HIP(hipStreamSynchronize(m->copy_stream));

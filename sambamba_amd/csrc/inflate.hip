@@ -1106,7 +1106,8 @@ __device__ __forceinline__ void lz77_resolve_body(
                     uint32_t o = cov ? q + lo - (cv & 0xFFFFu) : q + lo;            // (a near match: dist <= window offset of its first byte)
                     bool open = cov && o >= lo;
                     org[q] = (uint16_t)o;
-                    while (__any(open)) {
+                    // (origins strictly decrease, so a chain inside a group ends within 64 steps; the cap keeps a corrupted table from spinning)
+                    for (uint32_t it = 0; it < 72u && __any(open); ++it) {
                         if (open) {
                             const uint32_t sl = o - lo, o2 = org[sl];
                             if (sl < g0) { o = o2; open = false; }                 // a finished group's slot holds a final origin

@@ -31,3 +31,20 @@ d = json.load(open(sys.argv[1]))
 print(sys.argv[1], "Mreads/s", d["value"], "ms", d["ms_per_step"], {k: v["ms"] for k, v in d["kernels"].items()}, "parity", d["parity_checked"]["ok"], d["parity_checked"].get("text_ok"))
 PY
 done
+# SQ instruction counts of both variants on the 40-Mbp input (own PMC passes, no traces)
+export TMPDIR=/tmp
+REPO=$(pwd)
+for v in 1 2; do
+  ( cd /tmp && SBX_K1B_VARIANT=$v timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d /tmp/sq_v$v -o s -- \
+      python $REPO/bench.py --length 40000000 --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --parity-windows 0 > /dev/null 2> /tmp/sq_v$v.err )
+  python - $v <<'PY' | tee -a $OUT/sq_insts_40Mbp.txt
+import csv, glob, collections, re, sys
+acc = collections.defaultdict(float)
+for f in glob.glob("/tmp/sq_v%s/**/*counter_collection.csv" % sys.argv[1], recursive=True):
+    for row in csv.DictReader(open(f)):
+        m = re.search(r"(k_[a-z0-9_]+)", row["Kernel_Name"])
+        acc[(m.group(1) if m else row["Kernel_Name"][:30], row["Counter_Name"])] += float(row["Counter_Value"])
+for (k, c), v in sorted(acc.items()):
+    if v > 1e6: print("variant", sys.argv[1], k, c, "%.4g" % v)
+PY
+done
