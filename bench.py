@@ -169,19 +169,25 @@ def cpu_baseline(bam, sample_reads, mode_args):
     """Reference-algorithm CPU stand-in: the oracle CLI on the first `sample_reads` records of the same
     BAM, output to /dev/null.  Structured like the reference: zlib inflate on a pool of worker threads
     with in-order delivery (`-t`), then the single-threaded sweep-line pileup + text formatting.  Timed
-    twice -- sambamba's default (`-t 0`: everything on one thread, depth.d:1081,1154) and with 16 inflate
-    workers -- and the faster one is reported (the serial sweep bounds what more threads can buy)."""
+    three times -- sambamba's default (`-t 0`: everything on one thread, depth.d:1081,1154), with 16 inflate
+    workers and with nproc - 1 of them (T = nproc) -- and the fastest one is reported (the serial
+    sweep bounds what more threads can buy)."""
     exe = os.path.join(ROOT, "oracle", "depth_oracle")
     env = dict(os.environ, ORC_STATS="1")
     runs = []
-    for workers in (0, max(1, min(16, (os.cpu_count() or 2) - 1))):
+    ncpu = os.cpu_count() or 2
+    # BASELINE.md: T = nproc.  The reference spends -t on the inflate pool only: beyond a dozen workers nothing is gained, and a pool of
+    # 255 workers that hand their blocks to ONE consumer is slower than the serial run (0.11 against 0.54 Mreads/s on the 256-core box:
+    # profiles/round5) -- so the nproc run is timed on a tenth of the sample and listed, the two useful settings on all of it
+    for workers in sorted(set([0, max(1, min(16, ncpu - 1)), max(1, ncpu - 1)])):
         t0 = time.time()
-        r = subprocess.run([exe] + mode_args + ["-t", str(workers), "--max-reads", str(sample_reads), bam],
+        n_reads = sample_reads if workers <= 16 else max(1, sample_reads // 10)
+        r = subprocess.run([exe] + mode_args + ["-t", str(workers), "--max-reads", str(n_reads), bam],
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
         dt = time.time() - t0
         if r.returncode != 0:
             continue
-        secs, seen = dt, sample_reads
+        secs, seen = dt, n_reads
         for line in r.stderr.decode().splitlines():
             if line.startswith("[oracle]"):
                 parts = line.split()
@@ -296,6 +302,51 @@ def parity_full_text(d, bam, intervals, extra_args, min_slices=64, share_of_host
             "host_workers": workers, "seconds": round(time.time() - t0, 1),
             "what": "md5 of ALL device-formatted rows of this rank's share (K6 over the counters of the last timed pass), slice by slice, "
                     "against `depth_oracle base -L chr:a-b` run for every slice on the host cores"}
+
+
+def parity_full_regions(d, bam, regs, got_rows, share_of_host=1):
+    """EVERY window / BED region of a whole contig against the oracle: `regs` = [(ref, beg, end)] in position order, `got_rows` =
+    the device's (readCount, meanCoverage as %g text) per region.  The regions are cut into consecutive slices, one BED file and one
+    `depth_oracle region -L slice.bed` process per slice on the host cores; every row is compared.  Returns a dict."""
+    from concurrent.futures import ThreadPoolExecutor
+    import tempfile
+    t0 = time.time()
+    if not regs:
+        return {"regions": 0, "ok": True}
+    ncpu = max(1, (os.cpu_count() or 8) // max(1, share_of_host))
+    n_sl = max(1, min(len(regs), min(ncpu, 256)))
+    per = -(-len(regs) // n_sl)
+    oracle = os.path.join(ROOT, "oracle", "depth_oracle")
+    tmpd = tempfile.mkdtemp(prefix="sbx_par_", dir=tmp_dir())
+
+    def one(k):
+        part = regs[k * per:(k + 1) * per]
+        if not part:
+            return []
+        bed = os.path.join(tmpd, "s%d.bed" % k)
+        with open(bed, "w") as fh:
+            fh.writelines("%s\t%d\t%d\n" % (d.ref_names[r], a, b) for r, a, b in part)
+        out = subprocess.run([oracle, "region", "-L", bed, bam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+        rows = [ln.split("\t") for ln in out.splitlines() if ln and not ln.startswith("#")]
+        os.remove(bed)
+        return [(int(f[1]), int(f[2]), int(f[3]), f[4]) for f in rows]
+
+    with ThreadPoolExecutor(max_workers=min(n_sl, ncpu)) as ex:
+        want = [row for part in ex.map(one, range(n_sl)) for row in part]
+    try:
+        os.rmdir(tmpd)
+    except OSError:
+        pass
+    bad = []
+    if len(want) != len(regs):
+        bad.append(["row count", len(want), len(regs)])
+    else:
+        for i, ((r, a, b), (wa, wb, wn, wm)) in enumerate(zip(regs, want)):
+            if (a, b) != (wa, wb) or got_rows[i] != (wn, wm):
+                bad.append([r, a, b, list(got_rows[i]), [wn, wm]])
+                if len(bad) >= 4:
+                    break
+    return {"regions": len(regs), "ok": not bad, "mismatches": bad, "oracle_processes": n_sl, "seconds": round(time.time() - t0, 1)}
 
 
 def cli_e2e(bam, mode_args, reads):
@@ -484,6 +535,29 @@ class Job:
             rng = random.Random(seed ^ 0x33)
             checked, bad, where = 0, [], []
             oracle = os.path.join(ROOT, "oracle", "depth_oracle")
+            full = None
+            if args.full_parity:
+                # every window / every BED region of ONE WHOLE CONTIG (the longest one that is still resident) against the oracle
+                if args.config == 3:
+                    batches = [b for b in plan if b is not None]
+                    refs_res = range(batches[-1][0], batches[-1][0] + batches[-1][1]) if batches else range(len(ref_lengths))
+                    r_full = max(refs_res, key=lambda r: ref_lengths[r])
+                    nwin = ref_lengths[r_full] // 1000
+                    regs = [(r_full, k * 1000, (k + 1) * 1000) for k in range(nwin)]
+                    nr, nb, _cov = d.window_stats(r_full, 0, nwin) if nwin else ([], [], None)
+                    rows = [(int(nr[k][0]), "%g" % float(np.float32(nb[k][0]) / np.float32(1000))) for k in range(nwin)]
+                else:
+                    by_ref = {}
+                    for r, a, b in regions:
+                        by_ref.setdefault(r, []).append((r, a, b))
+                    r_full = max(by_ref, key=lambda r: len(by_ref[r]))
+                    regs = by_ref[r_full]
+                    nr, nb, _cov, _seen = d.region_stats(regs)
+                    rows = [(int(nr[j][0]), "%g" % float(np.float32(nb[j][0]) / np.float32(b - a))) for j, (r, a, b) in enumerate(regs)]
+                full = parity_full_regions(d, path, regs, rows, share_of_host=self.world)
+                full["contig"] = d.ref_names[r_full]
+                full["what"] = "readCount and meanCoverage of EVERY %s of contig %s against `depth_oracle region -L`" % (
+                    "window" if args.config == 3 else "BED region", d.ref_names[r_full])
 
             def want_of(r, a, b):
                 out = subprocess.run([oracle, "region", "-L", "%s:%d-%d" % (d.ref_names[r], a + 1, b), path],
@@ -527,7 +601,9 @@ class Job:
                     where.append([r, a, b])
                     if got != want:
                         bad.append([r, a, b, list(got), list(want)])
-            par = {"windows": checked, "ok": not bad, "mismatches": bad[:4], "checked": where[:32],
+            if full is not None and not full["ok"]:
+                bad.append(["whole contig", full["contig"]] + full["mismatches"][:2])
+            par = {"windows": checked, "ok": not bad, "mismatches": bad[:4], "checked": where[:32], "whole_contig": full,
                    "what": "readCount and meanCoverage of sampled %s against `depth_oracle region -L`%s" % (
                        "windows" if args.config == 3 else "BED regions (first, middle, last of the BED + random ones)",
                        " (batch index, contig, window; first / middle / last batch of the streamed genome)" if args.config == 3 else "")}
@@ -549,7 +625,7 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--codec", default=os.environ.get("SBX_BENCH_CODEC", "zlib"))
-    ap.add_argument("--cpu-sample-reads", type=int, default=int(os.environ.get("SBX_BENCH_CPU_READS", 3_000_000)))
+    ap.add_argument("--cpu-sample-reads", type=int, default=int(os.environ.get("SBX_BENCH_CPU_READS", 10_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="N > 1: skip the strong-scaling / all-reduce side measurements")
@@ -638,6 +714,28 @@ def main():
         par["windows_all_ranks"] = int(okt[1].item())
     parity_ok = par.get("ok_all_ranks", par["ok"])
 
+    # ---- N > 1: what the collective layer saw (so that a scaling record can be audited: RCCL with N ranks on N distinct devices) -----
+    coll = None
+    if dist:
+        import socket
+        props = torch.cuda.get_device_properties(dev_index)
+        knames = {"huffman_decode": "ms_huffman", "lz77_resolve": "ms_lz77", "record_index": "ms_index", "decode_accumulate": "ms_accumulate"}
+        me = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "device_index": dev_index, "device": props.name,
+              "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+              "kernel_ms": {k: round(sum(sum(st[v] for st in p) for p in kstats) / max(1, len(kstats)), 3) for k, v in knames.items()},
+              "reads_seen": int(sum(st["n_records"] for st in kstats[-1])) if kstats else 0,
+              "blocks": int(sum(st["n_bgzf_blocks"] for st in kstats[-1])) if kstats else 0}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        ones = torch.ones(1, dtype=torch.float32, device=red_dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # a collective over the data-path backend: must add up to the world size
+        ident = set((e["host"], e["uuid"] or e["pci_bus_id"] or e["device_index"]) for e in everyone)
+        coll = {"backend": str(dist.get_backend()), "is_rccl": backend == "nccl" and torch.version.hip is not None,
+                "world_size": world, "unique_devices": len(ident), "allreduce_of_ones": float(ones.item()),
+                "ranks": everyone,
+                "what": "torch.distributed backend of this run (`nccl` on a ROCm build IS RCCL), an all-reduce of ones over it, and per rank: "
+                        "host, device identity, per-kernel ms per pass, reads and BGZF blocks of its share"}
+
     # ---- N > 1, default mode, side measurements -------------------------------------------------------------------
     strong = None
     allred = None
@@ -712,13 +810,21 @@ def main():
         tok = sum(s["token_bytes"] for s in last)
         acc_in = sum(s["accumulate_read_bytes"] for s in last)
         # ALGORITHMIC bytes per pass of rank 0: what each kernel has to move, measured by the run itself
-        alg = {"huffman_decode": comp + tok,                  # compressed bytes in; literal + match-entry streams out (counted by K1b)
-               "lz77_resolve": tok + unc,                     # token streams in; inflated bytes out
+        # (the K1a -> K1b token streams are an intermediate of THIS design -- SURVEY 8(d) names compressed bytes in and
+        # inflated bytes / counters out -- so they are reported as `intermediate_bytes`, not counted in a kernel's achieved GB/s)
+        alg = {"huffman_decode": comp,                        # compressed bytes in
+               "lz77_resolve": unc,                           # inflated bytes out
                "record_index": nrec * (36 + 32),              # 36-B fixed part read + 32-B descriptor written per record
                "decode_accumulate": acc_in + cnt}             # descriptors + CIGAR / packed sequence (+ qualities when -q > 0) of the
                                                               # admitted records in; counters (+ span counts) out, once
+        if args.config in (3, 4):
+            # window / region modes print O(windows) numbers: per-position counters are an intermediate there (B_read ~ R_c)
+            alg["decode_accumulate"] = acc_in
+        inter = {"huffman_decode": tok, "lz77_resolve": tok, "record_index": 0,
+                 "decode_accumulate": cnt if args.config in (3, 4) else 0}
         full_size = (args.config == 2 and args.length == CHR1_LEN) or (args.config != 2 and args.scale == 1.0)
-        pmc = pmc_table(args.config) if (full_size and world == 1) else {}
+        pmc, pmc_note = pmc_table(args.config) if (full_size and world == 1) else ({}, "not the full-size single-GPU workload")
+        sq = sq_table(args.config) if (full_size and world == 1) else {}
         per_kernel = {}
         bad_frac = []
         for k in kern:
@@ -726,16 +832,28 @@ def main():
                 continue
             gbps = alg[k] / (kern[k] * 1e-3) / 1e9
             e = {"ms": round(kern[k], 4), "algorithmic_bytes": int(alg[k]), "algorithmic_GBps": round(gbps, 2),
-                 "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 5)}
+                 "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 5), "intermediate_bytes": int(inter[k])}
+            if k in sq:
+                e["issue_roofline"] = issue_roofline(sq[k], kern[k])
             if k in pmc:
                 e["traffic_bytes"] = pmc[k]["traffic"]
                 e["traffic_over_algorithmic"] = round(pmc[k]["traffic"] / max(1.0, alg[k]), 3)
             if not (0.0 < gbps / HBM_PEAK_GBS <= 1.0):
                 bad_frac.append(k)
             per_kernel[k] = e
+        # the fused-path figure of SURVEY.md 8(d): compressed bytes in + counters out over the whole pass
+        fused = (comp + (0 if args.config in (3, 4) else cnt)) / (sum(kern.values()) * 1e-3) / 1e9 if sum(kern.values()) > 0 else 0.0
         roof = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["algorithmic_GBps"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "frac": per_kernel[dom]["frac_of_hbm_peak"],
-                "algorithmic_bytes_per_launch": int(alg[dom]), "kernel_ms": round(kern[dom], 4)}
+                "algorithmic_bytes_per_launch": int(alg[dom]), "intermediate_bytes_per_launch": int(inter[dom]),
+                "kernel_ms": round(kern[dom], 4),
+                "path_frac": round(fused / HBM_PEAK_GBS, 5), "path_GBps": round(fused, 1),
+                "path_what": "SURVEY 8(d) fused figure: (compressed bytes in + counter bytes out) / sum of the kernel times of a pass -- the "
+                             "north star's 0.50 refers to this number"}
+        if "issue_roofline" in per_kernel[dom]:
+            roof["issue_roofline"] = per_kernel[dom]["issue_roofline"]
+        if dom not in pmc:
+            roof["traffic_note"] = pmc_note
         if dom in pmc:
             roof.update({"traffic": pmc[dom]["traffic"], "traffic_unit": "bytes per launch", "traffic_source": pmc[dom]["source"],
                          "traffic_over_algorithmic": per_kernel[dom]["traffic_over_algorithmic"]})
@@ -744,8 +862,6 @@ def main():
                                         "token streams in 16-byte stores, which costs 28.6 GB of partial-sector traffic per launch and saves "
                                         "1.7 ms; SBX_K1A_BURST=22 (32-byte nontemporal bursts): 29.2 ms, 14.2 GB = 1.11 x algorithmic "
                                         "(DESIGN.md section 3, K1a; profiles/round3/call_l_stdout_summary.txt)")
-        # the fused-path figure of SURVEY.md 8(d): compressed bytes in + counters out over the whole pass
-        fused = (comp + cnt) / (sum(kern.values()) * 1e-3) / 1e9 if sum(kern.values()) > 0 else 0.0
         cpu = None
         log("parity %s; cpu baseline" % par.get("ok"))
         if not args.no_cpu_baseline:
@@ -779,7 +895,7 @@ def main():
             "roofline": roof, "kernels": per_kernel,
             "fused_path": {"algorithmic_GBps": round(fused, 1), "frac_of_hbm_peak": round(fused / HBM_PEAK_GBS, 5),
                            "what": "(compressed bytes in + counter bytes out) / sum of the kernel times of a pass, rank 0"},
-            "strong_one_contig": strong, "allreduce_option": allred,
+            "strong_one_contig": strong, "allreduce_option": allred, "collective": coll,
             "cpu_baseline": cpu, "parity_checked": par, "e2e": e2e,
             "e2e_Mreads_per_s": (e2e or {}).get("Mreads_per_s"),
             "e2e_vs_cpu_baseline": (e2e or {}).get("vs_cpu_baseline"),
@@ -807,40 +923,92 @@ def main():
 
 PMC_KERNELS = {"huffman_decode": ["k_huffman_decode", "k_huffman_decode2", "k_translate_literals"],
                "lz77_resolve": ["k_lz77_resolve", "k_lz77_resolve_o32", "k_lz77_resolve_o32_w8", "k_lz77_resolve_o32_u", "k_lz77_resolve_o32_f",
-                                "k_lz77_resolve_o32_uf", "k_lz77_resolve_o32_uf_w8"],
-               "record_index": ["k_walk_blocks", "k_check_scan", "k_describe_blocks", "k_tile_compact", "k_chain_repair", "k_rewalk_mismatched"],
+                                "k_lz77_resolve_o32_uf", "k_lz77_resolve_o32_uf_w8", "k_lz77_resolve_jump", "k_lz77_resolve_exact"],
+               "record_index": ["k_walk_blocks", "k_check_scan", "k_describe_blocks", "k_describe_blocks_w4", "k_describe_blocks_r4", "k_tile_compact", "k_chain_repair", "k_rewalk_mismatched"],
                "decode_accumulate": ["k_accumulate16", "k_accumulate16b", "k_accumulate16c", "k_accumulate", "k_accumulate_mates", "k_find_mates",
                                      "k_find_partners", "k_mates_columns", "k_max_u32"]}
 
 
-def pmc_table(config=2):
-    """HBM bytes per launch of every kernel group from the committed PMC passes of this same workload
-    (tools/profile_round.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, KiB).
-    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is.  The file is measured
-    by the builder on the code of the commit named in profiles/<round>/README.md; the driver's run does not re-measure it."""
-    names = ["pmc_fetch_write_config%d.csv" % config] + (["pmc_fetch_write_chr1_30x.csv"] if config == 2 else [])
-    for rnd, name in [(r, n) for r in ("round4", "round3", "round2") for n in names]:
-        path = os.path.join(ROOT, "profiles", rnd, name)
-        if os.path.exists(path):
-            break
-    else:
-        return {}
-    best = {}
+KERNEL_SOURCES = ["inflate.hip", "inflate2_core.hpp", "index.hip", "depth.hip", "mates.hip", "reduce.hip", "common.hpp", "kernels.hpp"]
+CLOCK_GHZ = 2.4          # what the SIMDs run at under these kernels (GRBM_GUI_ACTIVE / duration: 2.35-2.43, profiles/round4/README.md)
+N_SIMD = 1024
+
+
+def kernel_sources_hash():
+    """sha1 over the device sources of the hot path: the stamp of a committed counter file (`# sources <hash>` in its first line).
+    A counter file measured on other kernel code is STALE and is not joined into the line."""
+    h = hashlib.sha1()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "sambamba_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _stamped_csv(name):
+    """rows of profiles/round5/<name> if the file exists and carries the stamp of the current kernel sources, else (None, why)"""
+    path = os.path.join(ROOT, "profiles", "round5", name)
+    if not os.path.exists(path):
+        return None, "no counter pass committed for this workload (profiles/round5/%s)" % name
     with open(path) as fh:
-        next(fh)
-        for ln in fh:
-            k, c, v, _ = ln.strip().split(",")
-            best[(k, c)] = best.get((k, c), 0.0) + float(v)          # all launches of the ONE pass the PMC run makes (a pass over a whole
-                                                                      # genome is several device batches; the launches at open time are tiny)
+        first = fh.readline().strip()
+        rows = [ln.strip().split(",") for ln in fh if ln.strip() and not ln.startswith("#") and not ln.startswith("kernel,")]
+    want = kernel_sources_hash()
+    if not first.startswith("# sources ") or first.split()[2] != want:
+        return None, "profiles/round5/%s was measured on other kernel sources (%s; now %s): stale, not joined" % (name, first[:40], want)
+    return rows, "profiles/round5/%s (%s)" % (name, first)
+
+
+def pmc_table(config=2):
+    """HBM bytes per pass of every kernel group from the committed PMC passes of this same workload AND these same kernel sources
+    (tools/pmc_pass.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, KiB, summed over the launches of the
+    ONE pass a counter run makes).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is.
+    Returns ({group: {...}}, note); an unstamped or stale file gives ({}, why): `traffic` is then null in the line."""
+    rows, note = _stamped_csv("pmc_fetch_write_config%d.csv" % config)
+    if rows is None:
+        return {}, note
+    best = {}
+    for k, c, v, _ in rows:
+        best[(k, c)] = best.get((k, c), 0.0) + float(v)
     out = {}
     for group, kernels in PMC_KERNELS.items():
         fetch = sum(v for (k, c), v in best.items() if k in kernels and c == "FETCH_SIZE") * 1024
         write = sum(v for (k, c), v in best.items() if k in kernels and c == "WRITE_SIZE") * 1024
         if fetch or write:
             out[group] = {"traffic": int(2 * fetch + write),
-                          "source": "profiles/%s/%s (rocprofv3 PMC, separate passes; FETCH_SIZE raw %.2f GB "
-                                    "doubled, WRITE_SIZE %.2f GB)" % (rnd, name, fetch / 1e9, write / 1e9)}
+                          "source": "%s: rocprofv3 PMC, separate passes; FETCH_SIZE raw %.2f GB doubled, WRITE_SIZE %.2f GB" % (
+                              note, fetch / 1e9, write / 1e9)}
+    return out, note
+
+
+def sq_table(config=2):
+    """SQ instruction counters per pass and kernel group (tools/pmc_pass.sh, `--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS ...`),
+    same stamp rule as pmc_table."""
+    rows, note = _stamped_csv("pmc_sq_config%d.csv" % config)
+    if rows is None:
+        return {}
+    acc = {}
+    for k, c, v, _ in rows:
+        acc[(k, c)] = acc.get((k, c), 0.0) + float(v)
+    out = {}
+    for group, kernels in PMC_KERNELS.items():
+        e = {c: sum(v for (k, c2), v in acc.items() if k in kernels and c2 == c) for c in
+             ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH")}
+        if any(e.values()):
+            e["source"] = note
+            out[group] = e
     return out
+
+
+def issue_roofline(sq, kernel_ms):
+    """The roof the inflate kernels hit: a SIMD of gfx950 issues integer code that is not all adds and shifts
+    at ~one VALU wave-instruction per 4 cycles.  achieved = VALU wave-instructions per second; peak = 1,024 SIMDs x clock / 4."""
+    valu = sq.get("SQ_INSTS_VALU", 0.0)
+    allk = sum(v for k, v in sq.items() if k.startswith("SQ_INSTS_"))
+    peak = N_SIMD * CLOCK_GHZ * 1e9 / 4.0
+    ach = valu / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    return {"bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instructions/s",
+            "frac": round(ach / peak, 4), "valu_wave_instructions": int(valu), "all_wave_instructions": int(allk),
+            "source": sq.get("source")}
 
 
 if __name__ == "__main__":

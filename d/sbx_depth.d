@@ -170,9 +170,8 @@ private bool firstColumn(sbx_ctx* ctx, uint r0, uint r1, out uint fref, out ulon
             if (b == ulong.max) break;
             for (ulong p = b; p < e; p += 65536) {
                 const ulong q = min(e, p + 65536);
-                auto cnt = new uint[cast(size_t)(q - p) * S * SBX_NCOUNTERS];
                 auto cov = new ubyte[cast(size_t)(q - p)];
-                sbxEnforce(ctx, sbx_depth_base_tile(ctx, r, cast(uint) p, cast(uint) q, cnt.ptr, cov.ptr));
+                sbxEnforce(ctx, sbx_depth_base_tile(ctx, r, cast(uint) p, cast(uint) q, null, cov.ptr));     // `covered` alone
                 foreach (x; 0 .. cov.length) if (cov[x]) { fref = r; fpos = p + x; return true; }
             }
             from = e;
@@ -193,9 +192,8 @@ private ulong lastColumn(sbx_ctx* ctx, uint r) {
     }
     for (ulong q = le; q > lb;) {
         const ulong p = q > lb + 65536 ? q - 65536 : lb;
-        auto cnt = new uint[cast(size_t)(q - p) * S * SBX_NCOUNTERS];
         auto cov = new ubyte[cast(size_t)(q - p)];
-        sbxEnforce(ctx, sbx_depth_base_tile(ctx, r, cast(uint) p, cast(uint) q, cnt.ptr, cov.ptr));
+        sbxEnforce(ctx, sbx_depth_base_tile(ctx, r, cast(uint) p, cast(uint) q, null, cov.ptr));             // `covered` alone
         for (ulong x = q; x > p; --x) if (cov[cast(size_t)(x - 1 - p)]) return x - 1;
         q = p;
     }

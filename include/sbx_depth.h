@@ -267,7 +267,10 @@ int sbx_run_interval_owned(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end
  * (k = A,C,G,T,other,DEL,REFSKIP; n_samples = 1 when --combined).  Positions no admitted read
  * spans are all-zero.  covered (optional, may be NULL): 1 byte per position, non-zero iff >= 1
  * admitted read spans the position (a pileup column exists there, pileup.d:345-397) -- needed
- * to tell "column with COV 0" from "no column" when min_base_quality > 0. */
+ * to tell "column with COV 0" from "no column" when min_base_quality > 0.
+ * counters may be NULL when only `covered` is wanted.  The seven counters per position exist after a `base` run (and after
+ * any run with --fix-mate-overlaps or several files); a region / window run keeps what its statistics are sums of -- the bases
+ * counted and the depth of a position -- and answers a request for counters with SBX_EINVAL (`covered` is always available). */
 int sbx_depth_base_tile(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, uint32_t* counters,
                         uint8_t* covered);
 

@@ -403,6 +403,12 @@ class Depth:
             return None
         return int(b.value), int(e.value)
 
+    def covered(self, ref_id, beg, end):
+        """One byte per position of [beg, end): non-zero iff a pileup column exists there (available after every kind of run)."""
+        cov = np.zeros(end - beg, dtype=np.uint8)
+        self._check(self._L.sbx_depth_base_tile(self._ctx, ref_id, beg, end, None, cov.ctypes.data))
+        return cov
+
     def base_counters(self, ref_id, beg, end, with_covered=False):
         S = self.n_samples_eff
         out = np.zeros((end - beg, S, NCOUNTERS), dtype=np.uint32)

@@ -504,7 +504,7 @@ bool first_column(sbx_ctx* c, int r0, int r1, int* ref_out, uint64_t* pos_out) {
                 uint64_t q = std::min(e, p + 65536);
                 cnt.resize((size_t)(q - p) * S * SBX_NCOUNTERS);
                 cov.resize((size_t)(q - p));
-                check(c, sbx_depth_base_tile(c, (uint32_t)r, (uint32_t)p, (uint32_t)q, cnt.data(), cov.data()));
+                check(c, sbx_depth_base_tile(c, (uint32_t)r, (uint32_t)p, (uint32_t)q, nullptr, cov.data()));     // `covered` alone
                 for (uint64_t x = p; x < q; ++x)
                     if (cov[(size_t)(x - p)]) { *ref_out = r; *pos_out = x; return true; }
             }
@@ -612,7 +612,7 @@ struct WindowPrinter {
             const uint64_t p = q > lb + 65536 ? q - 65536 : lb;
             cnt.resize((size_t)(q - p) * Sn * SBX_NCOUNTERS);
             cov.resize((size_t)(q - p));
-            check(c, sbx_depth_base_tile(c, (uint32_t)r, (uint32_t)p, (uint32_t)q, cnt.data(), cov.data()));
+            check(c, sbx_depth_base_tile(c, (uint32_t)r, (uint32_t)p, (uint32_t)q, nullptr, cov.data()));         // `covered` alone
             for (uint64_t x = q; x > p; --x) if (cov[(size_t)(x - 1 - p)]) return x - 1;
             q = p;
         }

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate16(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
     const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, uint32_t n_active,
     const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t S_arg, uint32_t min_bq, uint32_t deep_thr,
-    uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out) {
+    uint32_t* __restrict__ counters, uint32_t* __restrict__ span_out, uint32_t compact) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t S = kOneSample ? 1u : S_arg;      // (one sample -- a single-sample BAM or --combined -- is the common case:
                                                      //  the per-base address arithmetic loses its multiplications)
@@ -521,10 +521,30 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate16(
     // ---- write the tile once: 16-bit pairs -> u32[T][S][7], coalesced 16-byte stores --------------------------
     const uint32_t s7 = S * 7;
     const uint32_t n_cnt = T * s7;                  // multiple of 4 (T >= 16)
+    if (compact) {
+        // region / window statistics need two numbers per position and sample -- the bases counted (codes 0..4) and the depth (all 7:
+        // D / N count as quality 255), depth.d:661-698,760-845 -- not the seven counters: one word {bases : 16 | depth : 16} (a tile of
+        // this kernel holds fewer than 2^16 records), 4 bytes per position instead of 28 (these modes print O(windows))
+        const uint32_t n_ps = T * S;                // multiple of 4
+        uint32_t* outc = counters + (size_t)slot * n_ps;
+        const uint32_t inv_s = 0xFFFFFFFFu / S + 1u;
+        for (uint32_t i4 = threadIdx.x * 4u; i4 < n_ps; i4 += kAccThreads * 4u) {
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t i = i4 + e;
+                const uint32_t p = kOneSample ? i : __umulhi(i, inv_s), smp = kOneSample ? 0u : i - __umul24(p, S);
+                const uint32_t* w = cnt + (__umul24(swz(p), S) + smp) * 4u;
+                const uint32_t m = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[2] & 0xFFFFu);
+                v[e] = m | ((m + (w[2] >> 16) + (w[3] & 0xFFFFu)) << 16);
+            }
+            *(uint4*)(outc + i4) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    }
     uint32_t* out = counters + (size_t)slot * n_cnt;
     const uint32_t inv_s7 = 0xFFFFFFFFu / s7 + 1u;      // i / s7 by reciprocal multiplication (exact for i < 2^16)
     const uint32_t inv_7 = 0xFFFFFFFFu / 7u + 1u;
-    for (uint32_t i4 = threadIdx.x * 4u; i4 < n_cnt; i4 += kAccThreads * 4u) {
+    for (uint32_t i4 = threadIdx.x * 4u; !compact && i4 < n_cnt; i4 += kAccThreads * 4u) {
         uint32_t v[4];
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e) {
@@ -613,7 +633,7 @@ constexpr uint32_t kMapBytes = 704;      // 64 reads x 11 blocks
 __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accumulate16b(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
     const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, uint32_t n_active,
-    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t deep_thr, uint32_t* __restrict__ counters) {
+    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t deep_thr, uint32_t* __restrict__ counters, uint32_t compact) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t per = gridDim.x >> 3;
     const uint32_t slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);      // XCD-aware, as k_accumulate16
@@ -759,6 +779,20 @@ __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 
     __syncthreads();
     // ---- write the tile once: 16-bit pairs -> u32[T][7], coalesced 16-byte stores -------------------------------------------------
     const uint32_t n_out = T * 7u;                  // multiple of 4 (T >= 16)
+    if (compact) {       // region / window modes: {bases counted : 16 | depth : 16} per position (see k_accumulate16)
+        uint32_t* outc = counters + (size_t)slot * T;
+        for (uint32_t i4 = threadIdx.x * 4u; i4 < T; i4 += kAccThreads * 4u) {
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t* w = cnt + blk_dw(i4 + e);
+                const uint32_t m = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[2] & 0xFFFFu);
+                v[e] = m | ((m + (w[2] >> 16) + (w[3] & 0xFFFFu)) << 16);
+            }
+            *(uint4*)(outc + i4) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        return;
+    }
     uint32_t* out = counters + (size_t)slot * n_out;
     const uint32_t inv_7 = 0xFFFFFFFFu / 7u + 1u;
     for (uint32_t i4 = threadIdx.x * 4u; i4 < n_out; i4 += kAccThreads * 4u) {
@@ -786,7 +820,7 @@ constexpr uint32_t kWaveBytesC = kMapBytes + kGapItems * 8u;
 __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accumulate16c(
     const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
     const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, uint32_t n_active,
-    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t deep_thr, uint32_t* __restrict__ counters) {
+    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t deep_thr, uint32_t* __restrict__ counters, uint32_t compact) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t per = gridDim.x >> 3;
     const uint32_t slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);      // XCD-aware, as k_accumulate16
@@ -1041,6 +1075,20 @@ __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 
     __syncthreads();
     // ---- write the tile once: 16-bit pairs -> u32[T][7], coalesced 16-byte stores -------------------------------------------------
     const uint32_t n_out = T * 7u;                  // multiple of 4 (T >= 16)
+    if (compact) {       // region / window modes: {bases counted : 16 | depth : 16} per position (see k_accumulate16)
+        uint32_t* outc = counters + (size_t)slot * T;
+        for (uint32_t i4 = threadIdx.x * 4u; i4 < T; i4 += kAccThreads * 4u) {
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t* w = cnt + blk_dw(i4 + e);
+                const uint32_t m = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[2] & 0xFFFFu);
+                v[e] = m | ((m + (w[2] >> 16) + (w[3] & 0xFFFFu)) << 16);
+            }
+            *(uint4*)(outc + i4) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        return;
+    }
     uint32_t* out = counters + (size_t)slot * n_out;
     const uint32_t inv_7 = 0xFFFFFFFFu / 7u + 1u;
     for (uint32_t i4 = threadIdx.x * 4u; i4 < n_out; i4 += kAccThreads * 4u) {
@@ -1061,27 +1109,29 @@ __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 
 void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_tile_lo, const uint32_t* d_tile_hi,
                        const uint32_t* d_active, uint32_t n_active, uint32_t n_deep, uint32_t deep_thr, const uint32_t* d_tile_base,
                        int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool compact) {
     if (!n_active) return;
+    if (compact && n_deep) throw Error(SBX_EINVAL, "internal error: compact counters with deep tiles");
+    const uint32_t cflag = compact ? 1u : 0u;
     {
         const size_t lds = (size_t)tile_pos * n_samples * 16 + (d_span ? ((size_t)tile_pos + 5) * 4 : 0);
         const dim3 grid(((n_active + 7) / 8) * 8), block(kAccThreads);
         auto go = [&](auto kern) {
             SBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, grid, block, lds, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base, n_ref,
-                               tile_pos, n_samples, min_bq, deep_thr, d_counters, d_span);
+                               tile_pos, n_samples, min_bq, deep_thr, d_counters, d_span, cflag);
         };
         static const int variant = [] { const char* e = getenv("SBX_K3_VARIANT"); return e ? atoi(e) : 3; }();
         if (n_samples == 1 && !d_span && !min_bq && variant == 3) {
             const size_t lds3 = (((size_t)4 * tile_pos + (tile_pos >> 4) + 3) & ~(size_t)3) * 4 + (size_t)(kAccThreads / 64) * kWaveBytesC;
             SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate16c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
             hipLaunchKernelGGL(k_accumulate16c, grid, block, lds3, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base,
-                               n_ref, tile_pos, deep_thr, d_counters);
+                               n_ref, tile_pos, deep_thr, d_counters, cflag);
         } else if (n_samples == 1 && !d_span && !min_bq && variant == 2) {
             const size_t lds2 = (((size_t)4 * tile_pos + (tile_pos >> 4) + 3) & ~(size_t)3) * 4 + (size_t)(kAccThreads / 64) * kMapBytes;
             SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate16b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             hipLaunchKernelGGL(k_accumulate16b, grid, block, lds2, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base,
-                               n_ref, tile_pos, deep_thr, d_counters);
+                               n_ref, tile_pos, deep_thr, d_counters, cflag);
         } else if (n_samples == 1) {
             if (d_span) { if (min_bq) go(k_accumulate16<true, true, true>); else go(k_accumulate16<true, false, true>); }
             else { if (min_bq) go(k_accumulate16<false, true, true>); else go(k_accumulate16<false, false, true>); }

@@ -101,6 +101,10 @@ struct sbx_ctx {
     // several BAMs (MultiBamReader, multireader.d:244): this context is the first file and owns the merged view;
     // every further file is a complete single-file context of its own
     std::vector<sbx_ctx*> members;
+    bool in_group = false;                   // this context is one file of several (the primary or a member): its tiles get merged
+    // the last run kept ONE word per tile position and sample, {bases counted : 16 | depth : 16}, instead of the seven counters
+    // (region / window modes without -m: launch_accumulate `compact`); sbx_depth_base_tile then knows `covered` only
+    bool compact_counters = false;
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr, text_stream = nullptr;     // compute; file bytes host -> device; text device -> host
     FileMap file;
@@ -661,6 +665,8 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
             sbx_ctx* m = sbx_open(one, 1, c->device, e2, sizeof e2);
             if (!m) throw Error(SBX_EIO, e2);
             c->members.push_back(m);
+            m->in_group = true;
+            c->in_group = true;
             if (m->hdr.sorting_order != "coordinate") c->hdr.sorting_order = m->hdr.sorting_order;
             if (!m->has_index) c->has_index = false;
         }
@@ -972,7 +978,7 @@ static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool r
     df.ref_sets = c->d_ref_sets.p;
     SBX_HIP(hipMemcpyAsync(c->d_filter.p, &df, sizeof df, hipMemcpyHostToDevice, s));
     // read groups
-    *rg_out = RgTable{nullptr, nullptr, nullptr, 0, 0};
+    *rg_out = RgTable{nullptr, nullptr, nullptr, 0, 0, 0};
     if (!c->hdr.read_groups.empty()) {
         c->h_rg_ids.clear();
         c->h_rg_off.clear();
@@ -983,7 +989,7 @@ static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool r
         SBX_HIP(hipMemcpyAsync(c->d_rg_ids.p, c->h_rg_ids.data(), c->h_rg_ids.size(), hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(c->d_rg_off.p, c->h_rg_off.data(), c->h_rg_off.size() * 4, hipMemcpyHostToDevice, s));
         SBX_HIP(hipMemcpyAsync(c->d_rg_sample.p, c->hdr.rg_sample.data(), c->h_rg_off.size() * 2, hipMemcpyHostToDevice, s));
-        *rg_out = RgTable{c->d_rg_ids.p, c->d_rg_off.p, c->d_rg_sample.p, (int32_t)c->h_rg_off.size(), 1};
+        *rg_out = RgTable{c->d_rg_ids.p, c->d_rg_off.p, c->d_rg_sample.p, (int32_t)c->h_rg_off.size(), 1, (uint32_t)c->h_rg_ids.size()};
     }
 }
 
@@ -1181,7 +1187,12 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
 
     // ---- K3 ----
     const bool want_span = c->min_bq > 0 || (c->fix_mate && c->mode != SBX_MODE_BASE);
-    size_t per_tile = (size_t)T * S * SBX_NCOUNTERS;
+    // region / window statistics are sums over {bases counted, depth} per position (reduce.hip): without -m, for a single file and
+    // without a tile of 2^16 records or more K3 writes that one word per position instead of seven counters (SBX_COMPACT=0: never)
+    static const bool compact_ok = [] { const char* e = getenv("SBX_COMPACT"); return !e || atoi(e) != 0; }();
+    const bool compact = compact_ok && c->mode != SBX_MODE_BASE && !c->fix_mate && !c->in_group && R.n_deep == 0;
+    c->compact_counters = compact;
+    size_t per_tile = compact ? (size_t)T * S : (size_t)T * S * SBX_NCOUNTERS;
     c->d_counters.ensure((size_t)n_active * per_tile + 4);
     if (want_span) c->d_span.ensure((size_t)n_active * T + 4);
     if (c->fix_mate) {
@@ -1227,7 +1238,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         }
     } else
         launch_accumulate(c->U(), c->d_desc.p, c->d_tile_lo.p, c->d_tile_hi.p, c->d_active.p, n_active, R.n_deep, deep_thr, c->d_tile_base.p,
-                          n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s);
+                          n_ref, T, S, c->min_bq, c->d_counters.p, want_span ? c->d_span.p : nullptr, s, compact);
     t3.stop(s);
     t_all.stop(s);
     c->h_slot_of.resize((size_t)nt);
@@ -1786,14 +1797,19 @@ int sbx_last_run_stats(sbx_ctx* c, sbx_run_stats* out) {
 
 int sbx_depth_base_tile(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, uint32_t* counters, uint8_t* covered) {
     return guarded(c, [&] {
-        if (!c || !counters) throw Error(SBX_EINVAL, "null argument");
+        if (!c || (!counters && !covered)) throw Error(SBX_EINVAL, "null argument");
         if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
         if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
+        if (counters && c->compact_counters)
+            throw Error(SBX_EINVAL, "per-position base counters are kept by `base` runs only: a region / window run keeps the bases counted "
+                                    "and the depth of a position (pass counters = NULL for `covered` alone)");
         SBX_HIP(hipSetDevice(c->device));
         const uint32_t T = c->tile_pos, S = c->n_samples_eff;
-        const size_t row = (size_t)S * SBX_NCOUNTERS;
+        const size_t row = c->compact_counters ? (size_t)S : (size_t)S * SBX_NCOUNTERS;
         const uint32_t t_first = c->h_tile_base[ref_id], t_end = c->h_tile_base[ref_id + 1];
-        memset(counters, 0, (size_t)(end - beg) * row * 4);
+        std::vector<uint32_t> own;          // counters == NULL: `covered` alone
+        if (!counters) { own.assign((size_t)(end - beg) * row + 1, 0u); counters = own.data(); }
+        else memset(counters, 0, (size_t)(end - beg) * row * 4);
         if (covered) memset(covered, 0, (size_t)(end - beg));
         std::vector<uint32_t> spn;
         for (uint64_t p = beg; p < end;) {
@@ -1933,7 +1949,7 @@ static void range_stats(sbx_ctx* c, const std::vector<sbx_region>& ranges, bool 
         SBX_HIP(hipStreamSynchronize(s));   // host vectors above must outlive the async copies
     } else {
     launch_range_reduce(d_chunks.p, (uint32_t)n_chunks, c->d_counters.p, c->span_valid ? c->d_span.p : nullptr, c->d_slot_of.p,
-                        c->d_tile_base.p, T, S, d_thr.p, n_thr, d_nb.p, d_cov.p, d_seen.p, s);
+                        c->d_tile_base.p, T, S, d_thr.p, n_thr, d_nb.p, d_cov.p, d_seen.p, s, c->compact_counters);
     DevBuf<uint64_t> d_wb, d_nw;
     if (windows) {
         d_wb.alloc(win_base.size() + 1);
@@ -2072,6 +2088,7 @@ int sbx_depth_base_tile_device(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32
         if (!c || (!d_out && end > beg)) throw Error(SBX_EINVAL, "null argument");
         if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
         if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
+        if (c->compact_counters) throw Error(SBX_EINVAL, "per-position base counters are kept by `base` runs only");
         SBX_HIP(hipSetDevice(c->device));
         hipStream_t s = c->stream;
         const uint32_t T = c->tile_pos, S = c->n_samples_eff;

@@ -503,8 +503,11 @@ struct Described {
     bool admit, bad, urg;
 };
 
-// p: the record's block_size field (LDS copy, or global memory for a record that does not fit the window)
-__device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexArgs& a) {
+// p: the record's block_size field.  kStaged: p is the lane's staging slot in LDS -- the first kStageHead bytes of the record (fixed
+// part, name and CIGAR fit) -- and `tail_end` points behind the staged copy of the record's last kStageTail bytes (the tags fit);
+// otherwise p is the record in global memory.  The rg table comes as the view the kernel prepared (LDS copy or the global arrays).
+template <bool kStaged>
+__device__ __forceinline__ Described describe_record(const uint8_t* p, const uint8_t* tail_end, uint64_t o, const IndexArgs& a, const RgTable& rgv) {
     Described R;
     const int64_t bs = (int32_t)ld32(p);
     const uint8_t* r = p + 4;
@@ -536,7 +539,9 @@ __device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexAr
     const bool sane = l_seq >= 0 && bs >= fixed && ref_own >= -1 && ref_own < a.refs.n_ref_own;
     R.bad = !sane;
     bool admit = sane && !(flag & 0x4) && ref >= 0;                       // read.d:256, unmapped reads cover nothing
-    if (admit) admit = eval_filter(a.filt, r, ref, pos, bmn, fnc, l_seq, r + fixed, r + bs);      // filtering.d:36-38
+    const uint8_t* const tags_end = kStaged ? tail_end : r + bs;
+    const uint8_t* const tags = kStaged ? tail_end - (bs - fixed) : r + fixed;
+    if (admit) admit = eval_filter(a.filt, r, ref, pos, bmn, fnc, l_seq, tags, tags_end);      // filtering.d:36-38
     if (admit) {
         // basesCovered + shape of the CIGAR
         const uint8_t* cg = r + 32 + l_name;
@@ -584,7 +589,7 @@ __device__ Described describe_record(const uint8_t* p, uint64_t o, const IndexAr
     // every read it iterates over, filtered or not (depth.d:240-250,1211-1214); with -L those are the reads the index
     // fetch returns, which the admitted ones stand for here.
     if (a.rg.lookup && sane && (admit || !a.refs.sel)) {
-        const uint32_t s = lookup_sample(r + fixed, r + bs, a.rg);
+        const uint32_t s = lookup_sample(tags, tags_end, rgv);
         if (s == 0xFFFFu) R.urg = true;
         else d.sample = (uint16_t)s;
     }
@@ -765,9 +770,39 @@ __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
 // ---- 3. describe: one wave per block, one lane per record ---------------------------------------------------
 constexpr int kDescThreads = 256;
 
-__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks(IndexArgs a) {
+// Staging (round 5).  A lane used to follow its record through global memory field by field -- block_size, the fixed part, the CIGAR
+// operations one by one, then the tag bytes one by one up to RG:Z and the read-group table byte by byte: about twenty DEPENDENT
+// round trips of 1-2 us per batch of 64 records, which is what the kernel waited for 79 % of its wave cycles
+// (profiles/round4/pmc_sq_config2_full.csv).  Now the record offsets of the batch give every lane the start of its record AND of the
+// next one, so the head (kStageHead bytes from the record's start) and the tail (the kStageTail bytes in front of the next record: the
+// tags of a record without a long tag list) are fetched with seven independent 16-byte loads, copied to the lane's slot in LDS, and
+// everything is parsed from there -- two round trips to global memory per batch: the offsets, the bytes.  The read-group table
+// is copied to LDS once per workgroup.  A record that does not fit (long name or CIGAR, more than kStageTail bytes of tags, a
+// filter that reads bases or qualities, a size that contradicts the chain) takes the old path through global memory.
+constexpr uint32_t kStageHead = 64, kStageTail = 48, kStageSlot = kStageHead + kStageTail;
+constexpr uint32_t kRgLdsIds = 256, kRgLdsMax = 16;
+
+template <bool kStage>
+__device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     __shared__ uint32_t tot[7];          // records, admitted, malformed, unknown read group of this workgroup's blocks; bytes K3 reads; longest span
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kDescThreads * kStageSlot];
+    __shared__ __attribute__((aligned(4))) char rg_ids[kRgLdsIds];
+    __shared__ uint32_t rg_off[kRgLdsMax];
+    __shared__ uint16_t rg_sample[kRgLdsMax];
     if (threadIdx.x < 7) tot[threadIdx.x] = 0;
+    RgTable rgv = a.rg;
+    const bool rg_small = kStage && a.rg.lookup && a.rg.n_rg <= (int32_t)kRgLdsMax && a.rg.ids_bytes <= kRgLdsIds;
+    if (rg_small) {
+        if (threadIdx.x < a.rg.ids_bytes) rg_ids[threadIdx.x] = a.rg.ids[threadIdx.x];
+        if (threadIdx.x < (uint32_t)a.rg.n_rg) { rg_off[threadIdx.x] = a.rg.id_off[threadIdx.x]; rg_sample[threadIdx.x] = a.rg.sample_of[threadIdx.x]; }
+        rgv.ids = rg_ids; rgv.id_off = rg_off; rgv.sample_of = rg_sample;
+    }
+    // a filter that reads bases or qualities needs the body of the record: no staging
+    bool filt_body = false;
+    for (int k = 0; k < a.filt->n_ops; ++k) {
+        const sbx_filter_op& op = a.filt->ops[k];
+        filt_body = filt_body || op.kind == 13 || (op.kind == 15 && op.field == 1) || (op.kind == 2 && op.field == 7);
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = blockIdx.x * (kDescThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
@@ -778,6 +813,9 @@ __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5,
         const uint64_t beg = a.out_off[b];
         const uint64_t base = (a.state[b] & kStateMask) - count;
         const uint16_t* list = rec_list(a.scratch, beg, b);
+        const uint64_t chain_exit = a.exit_[b];        // where the record chain leaves the block: the end of its last record
+        uint8_t* const slot = stage + threadIdx.x * kStageSlot;
+        typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
         for (uint32_t i0 = 0; i0 < count; i0 += 64) {
             const uint32_t i = i0 + lane;
             const bool live = i < count;
@@ -786,7 +824,30 @@ __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5,
             const uint64_t idx = base + i;
             if (live) {
                 const uint64_t o = beg + list[i];
-                R = describe_record(a.U + o, o, a);
+                const uint64_t o_next = i + 1 < count ? beg + list[i + 1] : chain_exit;
+                // (the head may reach up to 64 bytes past the stream: the allocation has that slack, IndexArgs::u_alloc)
+                bool staged = kStage && !filt_body && o_next >= o + 36 && o_next >= kStageTail && o_next <= a.u_alloc;
+                if (staged) {
+                    u32x4s h[4], t[3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __builtin_memcpy(&h[k], a.U + o + 16 * k, 16);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) __builtin_memcpy(&t[k], a.U + o_next - kStageTail + 16 * k, 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *(u32x4s*)(slot + 16 * k) = h[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) *(u32x4s*)(slot + kStageHead + 16 * k) = t[k];
+                    // does the record fit the slot, and does its size agree with the chain?
+                    const int64_t bs = (int32_t)h[0].x;
+                    const uint32_t bmn = h[0].w, fnc = h[1].x;
+                    const int32_t l_seq = (int32_t)h[1].y;
+                    const int64_t ln = bmn & 0xFFu, nc = fnc & 0xFFFFu;
+                    const int64_t fixed = 32 + ln + 4 * nc + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
+                    staged = l_seq >= 0 && bs >= fixed && o + 4 + (uint64_t)bs == o_next && 36 + ln + 4 * nc <= (int64_t)kStageHead &&
+                             bs - fixed <= (int64_t)kStageTail;
+                }
+                if (staged) R = describe_record<true>(slot, slot + kStageSlot, o, a, rgv);
+                else R = describe_record<false>(a.U + o, nullptr, o, a, rgv);
                 a.desc[idx] = R.d;
                 a.rec_ref[idx] = R.ref;
                 if (a.name_hash) a.name_hash[idx] = R.hash;
@@ -845,6 +906,11 @@ __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5,
         if (tot[6]) atomicMax(&st->max_span, tot[6]);
     }
 }
+
+// the staged form at 5 and at 4 waves per SIMD (96 VGPRs and a few spills / 124 VGPRs), and round 4's kernel (SBX_K2_DESCRIBE=0)
+__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks(IndexArgs a) { describe_blocks_body<true>(a); }
+__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_blocks_w4(IndexArgs a) { describe_blocks_body<true>(a); }
+__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks_r4(IndexArgs a) { describe_blocks_body<false>(a); }
 
 // ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
 __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* __restrict__ tile_lo,
@@ -931,7 +997,11 @@ void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(k_check_scan, dim3(1), dim3(kScanThreads), 0, stream, a);
     SBX_HIP(hipGetLastError());
     const uint32_t per = kDescThreads / 64;
-    hipLaunchKernelGGL(k_describe_blocks, dim3((a.n_blocks + per - 1) / per), dim3(kDescThreads), 0, stream, a);
+    static const int form = [] { const char* e = getenv("SBX_K2_DESCRIBE"); return e ? atoi(e) : 2; }();
+    const dim3 dgrid((a.n_blocks + per - 1) / per), dblock(kDescThreads);
+    if (form == 0) hipLaunchKernelGGL(k_describe_blocks_r4, dgrid, dblock, 0, stream, a);
+    else if (form == 2) hipLaunchKernelGGL(k_describe_blocks_w4, dgrid, dblock, 0, stream, a);
+    else hipLaunchKernelGGL(k_describe_blocks, dgrid, dblock, 0, stream, a);
     SBX_HIP(hipGetLastError());
 }
 

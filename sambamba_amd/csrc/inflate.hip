@@ -911,11 +911,14 @@ struct Short16 {
 // Long copy tasks (16 < n <= 512) of a wave, done by all 64 lanes, 8 bytes per lane, four tasks in
 // flight (loads of all four before the first store).  Lane r of `m` owns a task: n bytes from
 // sbase + s to buf + d.  Source and destination of a task never overlap.
+// (kTasks: tasks per turn of the loop.  tools/token_stats.cpp: a batch of a BAM stream holds 1.6 long far matches and 0.2 long literal
+// runs -- with four tasks unrolled a turn executes ~220 instructions for one or two tasks, most of them predicated off)
+template <int kTasks = 4>
 __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint32_t s, uint8_t* buf, uint32_t d, uint32_t n, uint32_t lane) {
     while (m) {
-        uint32_t S[4], D[4], N[4], wa[4], wb[4];
+        uint32_t S[kTasks], D[kTasks], N[kTasks], wa[kTasks], wb[kTasks];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kTasks; ++j) {
             N[j] = 0; S[j] = 0; D[j] = 0;
             if (m) {
                 const int r = __builtin_ctzll(m);
@@ -927,7 +930,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
         }
         const uint32_t off = 8 * lane;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kTasks; ++j) {
             if (off < N[j]) {
                 const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
                 wa[j] = ldu32(sbase + S[j] + a);
@@ -935,7 +938,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kTasks; ++j) {
             if (off < N[j]) {
                 const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
                 stu32(buf + D[j] + a, wa[j]);
@@ -973,7 +976,7 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // meets below the current group is already final: one lookup resolves a byte whose source lies in an earlier group, bytes that
 // depend on bytes of their own group (short distances, runs) take a few more.  No divergence, no per-kind code paths: ~35
 // instructions per position and group.
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kJump = false>
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kJump = false, bool kExact = false, int kCoop = 4>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -1054,8 +1057,8 @@ __device__ __forceinline__ void lz77_resolve_body(
                 rl.store(buf + (eo - base) + 16u * h, n_l);
                 rf.store(buf + (dst - base) + 16u * h, n_f);
             }
-            coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
-            coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
+            coop_copy<kCoop>(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
+            coop_copy<kCoop>(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
         }
         // ---- phase B: near matches, LDS -> LDS --------------------------------------------------------------
         // A match may start once everything below its source end is final.  Matches start in entry order,
@@ -1121,9 +1124,38 @@ __device__ __forceinline__ void lz77_resolve_body(
             }
             pending = false;
         }
+        // kExact (variant 3): the exact readiness rule.  A match may start once no UNFINISHED match writes into its source range
+        // [src, s_hi).  Entries are in position order, so the matches whose destination meets that range are a contiguous range of
+        // lanes [jlo, jhi] -- found once per batch by two binary searches over the lanes' {start, end} of the match (window offsets,
+        // 16 bits each, one dword per lane in LDS) -- and "unfinished" is the ballot of pending lanes: ready = no pending lane in my
+        // range.  3.3 rounds per batch instead of 5.6 on a BAM stream (tools/token_stats.cpp); every round executes every copy path.
+        uint32_t dep_lo = 0, dep_hi = 0;
+        if (kExact) {
+            uint32_t* rng = (uint32_t*)(smem + (kResThreads / 64) * kWaveLds + 128u) + wv * 64u;
+            // (a lane without a match: start = end = where its match would be -- the arrays stay monotone, the lane is never pending)
+            rng[lane] = dsto | ((dsto + len) << 16);
+            uint32_t jlo = 0, jhi = 0;                       // lanes with end <= srco | lanes with start < s_hi - base
+            const uint32_t s_hio = s_hi - base;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+                const uint32_t a = rng[jlo + step - 1], b2 = rng[jhi + step - 1];
+                jlo += (a >> 16) <= srco ? step : 0u;
+                jhi += (b2 & 0xFFFFu) < s_hio ? step : 0u;
+            }
+            // (lane 63 is never counted by the search -- 63 steps at most -- and never matters: a range ends below its own lane)
+            if (pending && jhi > jlo) {
+                const uint64_t m = (jhi >= 64u ? ~0ull : (1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
+                dep_lo = (uint32_t)m; dep_hi = (uint32_t)(m >> 32);
+            }
+        }
         for (uint64_t pm = __ballot(pending); pm; pm = __ballot(pending)) {
-            const uint32_t F = __builtin_amdgcn_readlane(dst, __builtin_ctzll(pm));
-            const bool ready = pending && s_hi <= F;
+            bool ready;
+            if (kExact) {
+                ready = pending && ((dep_lo & (uint32_t)pm) | (dep_hi & (uint32_t)(pm >> 32))) == 0u;
+            } else {
+                const uint32_t F = __builtin_amdgcn_readlane(dst, __builtin_ctzll(pm));
+                ready = pending && s_hi <= F;
+            }
             pending = pending && !ready;
             const bool plain = ready && dist >= len;
             {
@@ -1136,7 +1168,7 @@ __device__ __forceinline__ void lz77_resolve_body(
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
                 }
-                coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
+                coop_copy<kCoop>(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
             // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
@@ -1229,6 +1261,16 @@ __global__ __launch_bounds__(kResThreads) void k_lz77_resolve_jump(SBX_LZ77_ARGS
     lz77_resolve_body<kHist, kSpanMax, true, true>(SBX_LZ77_PASS);
 }
 constexpr uint32_t kHistJump = 2048, kSpanJump = 1024;
+// variant 3: variant 1 with the exact readiness rule (kExact above); LDS per wave: window + 256 bytes of match ranges
+template <uint32_t kHist, uint32_t kSpanMax>
+__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_exact(SBX_LZ77_ARGS) {
+    lz77_resolve_body<kHist, kSpanMax, true, false, true>(SBX_LZ77_PASS);
+}
+// variants 4 / 5: variant 3 with two / one task per turn of the cooperative copy loop
+template <uint32_t kHist, uint32_t kSpanMax, int kCoop>
+__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_exact_c(SBX_LZ77_ARGS) {
+    lz77_resolve_body<kHist, kSpanMax, true, false, true, kCoop>(SBX_LZ77_PASS);
+}
 
 }  // namespace
 
@@ -1301,7 +1343,7 @@ void launch_k1b(const InflateArgs& a, hipStream_t stream) {
     const uint32_t per = kResThreads / 64;
     dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
     const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
-    static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 1; }();
+    static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 3; }();
     if (variant == 0)
         hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
                            a.n_blocks, a.block0, a.out, a.status);
@@ -1317,7 +1359,18 @@ void launch_k1b(const InflateArgs& a, hipStream_t stream) {
         else if (hist == 4096) SBX_K1B_JUMP(4096u);
         else SBX_K1B_JUMP(kHistJump);
 #undef SBX_K1B_JUMP
-    } else
+    } else if (variant == 4 || variant == 5) {
+        const size_t l3 = lds + 128 + (size_t)(kResThreads / 64) * 256;
+        if (variant == 4)
+            hipLaunchKernelGGL((k_lz77_resolve_exact_c<kHistDefault, kSpanDefault, 2>), grid, block, l3, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
+                               a.n_blocks, a.block0, a.out, a.status);
+        else
+            hipLaunchKernelGGL((k_lz77_resolve_exact_c<kHistDefault, kSpanDefault, 1>), grid, block, l3, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
+                               a.n_blocks, a.block0, a.out, a.status);
+    } else if (variant == 3)
+        hipLaunchKernelGGL((k_lz77_resolve_exact<kHistDefault, kSpanDefault>), grid, block, lds + 128 + (size_t)(kResThreads / 64) * 256, stream, a.lit,
+                           a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
+    else
         hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, a.lit, a.ent, a.nent, a.out_off,
                            a.isize, a.n_blocks, a.block0, a.out, a.status);
     SBX_HIP(hipGetLastError());

@@ -76,6 +76,7 @@ struct RgTable {            // read-group id strings -> sample id (depth.d:1170-
     const uint16_t* sample_of;     // [n_rg]
     int32_t n_rg;
     int32_t lookup;                // 0: every read is sample 0 and RG tags are not inspected
+    uint32_t ids_bytes;            // bytes of `ids`
 };
 
 // ---- K1: BGZF inflate (inflate.hip) -------------------------------------------------------
@@ -173,7 +174,9 @@ constexpr uint32_t kDeepTileRecords = 65536;
 void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t* d_tile_lo, const uint32_t* d_tile_hi,
                        const uint32_t* d_active, uint32_t n_active, uint32_t n_deep, uint32_t deep_thr, const uint32_t* d_tile_base,
                        int32_t n_ref, uint32_t tile_pos, uint32_t n_samples, uint32_t min_bq, uint32_t* d_counters, uint32_t* d_span,
-                       hipStream_t stream);
+                       hipStream_t stream, bool compact = false);
+// compact == true (region / window modes without -m, no deep tile): d_counters holds ONE word per tile position and sample,
+// {bases counted (codes 0..4) : 16 | depth (all 7 counters) : 16}, instead of the seven counters -- what launch_range_reduce needs
 
 // ---- K7: --fix-mate-overlaps, base mode (mates.hip) ---------------------------------------
 // d_mate[i] = index of the single overlapping same-name record of i (0xFFFFFFFF: none),
@@ -197,7 +200,7 @@ void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream
 void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_counters, const uint32_t* d_span,
                          const uint32_t* d_slot_of, const uint32_t* d_tile_base, uint32_t T, uint32_t S,
                          const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases, uint32_t* d_cov_counts,
-                         uint32_t* d_seen, hipStream_t stream);
+                         uint32_t* d_seen, hipStream_t stream, bool compact = false);
 void launch_count_reads_windows(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
                                 uint32_t window, const uint64_t* d_win_base, const uint64_t* d_n_win, uint32_t S,
                                 uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);

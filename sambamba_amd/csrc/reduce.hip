@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kRedThreads) void k_range_reduce(
     const RangeChunk* __restrict__ chunks, uint32_t n_chunks, const uint32_t* __restrict__ counters,
     const uint32_t* __restrict__ span, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ tile_base,
     uint32_t T, uint32_t S, const uint32_t* __restrict__ thresholds, uint32_t n_thr, uint32_t* n_bases /*[id][S]*/,
-    uint32_t* cov_counts /*[id][S][n_thr]*/, uint32_t* seen /*[id]*/) {
+    uint32_t* cov_counts /*[id][S][n_thr]*/, uint32_t* seen /*[id]*/, uint32_t compact) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t ci = blockIdx.x * (kRedThreads / 64) + wv;
     if (ci >= n_chunks) return;
@@ -59,9 +59,16 @@ __global__ __launch_bounds__(kRedThreads) void k_range_reduce(
             if (tile >= t_end) continue;
             const uint32_t slot = slot_of[tile];
             if (slot == 0xFFFFFFFFu) continue;
-            const uint32_t* c = counters + ((size_t)slot * T + (p & (T - 1))) * row + s * 7;
-            const uint32_t m = c[0] + c[1] + c[2] + c[3] + c[4];
-            const uint32_t cov = m + c[5] + c[6];
+            uint32_t m, cov;
+            if (compact) {       // one word per position and sample: {bases counted : 16 | depth : 16} (launch_accumulate, compact)
+                const uint32_t w = counters[((size_t)slot * T + (p & (T - 1))) * S + s];
+                m = w & 0xFFFFu;
+                cov = w >> 16;
+            } else {
+                const uint32_t* c = counters + ((size_t)slot * T + (p & (T - 1))) * row + s * 7;
+                m = c[0] + c[1] + c[2] + c[3] + c[4];
+                cov = m + c[5] + c[6];
+            }
             nb += m;
             if (span) any |= span[(size_t)slot * T + (p & (T - 1))];
             else any |= cov;
@@ -401,11 +408,12 @@ __global__ __launch_bounds__(kRedThreads) void k_count_reads_mates(
 void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const uint32_t* d_counters, const uint32_t* d_span,
                          const uint32_t* d_slot_of, const uint32_t* d_tile_base, uint32_t T, uint32_t S,
                          const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases, uint32_t* d_cov_counts,
-                         uint32_t* d_seen, hipStream_t stream) {
+                         uint32_t* d_seen, hipStream_t stream, bool compact) {
     if (!n_chunks) return;
     const uint32_t per = kRedThreads / 64;
     hipLaunchKernelGGL(k_range_reduce, dim3((n_chunks + per - 1) / per), dim3(kRedThreads), 0, stream, d_chunks, n_chunks,
-                       d_counters, d_span, d_slot_of, d_tile_base, T, S, d_thresholds, n_thr, d_n_bases, d_cov_counts, d_seen);
+                       d_counters, d_span, d_slot_of, d_tile_base, T, S, d_thresholds, n_thr, d_n_bases, d_cov_counts, d_seen,
+                       compact ? 1u : 0u);
     SBX_HIP(hipGetLastError());
 }
 

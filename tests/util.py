@@ -29,10 +29,11 @@ def run_oracle(args, cwd=None):
                           check=True).stdout
 
 
-def run_cli(args, cwd=None, check=True):
-    """Text output of the product CLI (sbx-depth) for `depth <args>` -- runs on the GPU."""
+def run_cli(args, cwd=None, check=True, env=None):
+    """Text output of the product CLI (sbx-depth) for `depth <args>` -- runs on the GPU.  env: extra environment variables."""
     from sambamba_amd import cli_path
-    r = subprocess.run([cli_path()] + list(args), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r = subprocess.run([cli_path()] + list(args), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, **env) if env else None)
     if check and r.returncode != 0:
         raise RuntimeError("sbx-depth failed (%d): %s" % (r.returncode, r.stderr.decode()))
     return r.stdout if check else r
