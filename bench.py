@@ -923,8 +923,8 @@ def main():
 
 PMC_KERNELS = {"huffman_decode": ["k_huffman_decode", "k_huffman_decode2", "k_translate_literals"],
                "lz77_resolve": ["k_lz77_resolve", "k_lz77_resolve_o32", "k_lz77_resolve_o32_w8", "k_lz77_resolve_o32_u", "k_lz77_resolve_o32_f",
-                                "k_lz77_resolve_o32_uf", "k_lz77_resolve_o32_uf_w8", "k_lz77_resolve_jump", "k_lz77_resolve_exact"],
-               "record_index": ["k_walk_blocks", "k_check_scan", "k_describe_blocks", "k_describe_blocks_w4", "k_describe_blocks_r4", "k_tile_compact", "k_chain_repair", "k_rewalk_mismatched"],
+                                "k_lz77_resolve_exact"],
+               "record_index": ["k_walk_blocks", "k_check_scan", "k_check_scan_mw", "k_describe_blocks", "k_describe_blocks_r4", "k_tile_compact", "k_tile_compact_mw", "k_chain_repair", "k_rewalk_mismatched"],
                "decode_accumulate": ["k_accumulate16", "k_accumulate16b", "k_accumulate16c", "k_accumulate", "k_accumulate_mates", "k_find_mates",
                                      "k_find_partners", "k_mates_columns", "k_max_u32"]}
 

@@ -165,6 +165,7 @@ struct sbx_ctx {
     DevBuf<uint32_t> d_mate, d_n_partners, d_mate_ext;
     DevBuf<int32_t> d_ref_len;
     DevBuf<uint32_t> d_tile_base, d_tile_lo, d_tile_hi, d_active, d_slot_of, d_n_active;
+    DevBuf<unsigned long long> d_scan_part;      // scratch of the multi-workgroup scans of K2 (index.hip)
     DevBuf<uint32_t> d_counters, d_span;
     DevBuf<uint32_t> d_covm, d_addm;     // per-column quantities of region/window runs with --fix-mate-overlaps
     DevBuf<DeviceFilter> d_filter;
@@ -1042,6 +1043,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     c->d_active.ensure((size_t)nt + 1);
     c->d_slot_of.ensure((size_t)nt + 1);
     c->d_n_active.ensure(4);
+    c->d_scan_part.ensure(kScanPartWords);
     c->d_stats.ensure(kIndexStatSlots);
     // descriptor capacity: sized for records of >= 160 bytes on average; K2 reports an overflow and the pass is repeated
     // with the exact number (short-read fixtures, amplicon data with tiny records)
@@ -1088,9 +1090,11 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         a.desc = c->d_desc.p; a.rec_ref = c->d_rec_ref.p; a.name_hash = c->fix_mate ? c->d_name_hash.p : nullptr;
         a.desc_cap = c->desc_cap;
         a.tile_lo = c->d_tile_lo.p; a.tile_hi = c->d_tile_hi.p; a.stats = c->d_stats.p; a.flags = c->d_flag.p;
+        a.scan_part = c->d_scan_part.p;
         a.own_ref = c->own_ref; a.own_beg = c->own_beg; a.own_end = c->own_end;
         launch_index_blocks(a, s);
-        launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, deep_thr, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s);
+        launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, deep_thr, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s,
+                            c->d_scan_part.p);
         if (attempt == 0) t2.stop(s);
         R.last_state = 0;
         SBX_HIP(hipMemcpyAsync(R.flags, c->d_flag.p, 16, hipMemcpyDeviceToHost, s));

@@ -767,6 +767,97 @@ __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
     if (t == 0 && run > a.desc_cap) atomicOr(a.flags + 2, 1u);
 }
 
+// The same over SEVERAL workgroups in one launch (round 5: the single workgroup above is a serial link of 0.5 ms between the walk and the
+// describe launches of a chromosome).  Workgroup g takes blocks [4096 g, 4096 g + 4096): chain check, local scan, then it PUBLISHES its total
+// (`part[g]` = total | ready bit) and adds up the totals of the workgroups before it -- those are resident at the same time (the launcher
+// keeps the grid below what the device holds at once) and never wait for a later one, so the look-back cannot deadlock.
+constexpr uint32_t kScanPerWg = 4 * kScanThreads;
+constexpr unsigned long long kScanReady = 1ull << 63;
+constexpr uint32_t kScanMaxWgs = 448;            // 256 CUs x 2 workgroups of 1024 threads, with a margin
+
+// the workgroup's place in the scan: a ticket, not blockIdx -- whoever holds ticket g knows that tickets 0 .. g - 1 have been taken by
+// workgroups that are running (or done), whatever order the hardware started them in; the counter is the last word of `part`
+__device__ __forceinline__ uint32_t scan_ticket(unsigned long long* part) {
+    __shared__ uint32_t ticket;
+    if (threadIdx.x == 0) ticket = (uint32_t)atomicAdd(part + (kScanPartWords - 1), 1ull);
+    __syncthreads();
+    return ticket;
+}
+
+__device__ __forceinline__ uint64_t lookback_sum(unsigned long long* part, uint32_t g, uint64_t* red /*[kScanThreads / 64]*/) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    uint64_t acc = 0;
+    for (uint32_t w = t; w < g; w += kScanThreads) {
+        unsigned long long x;
+        do { x = __hip_atomic_load(part + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (!(x & kScanReady));
+        acc += x & ~kScanReady;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += (uint64_t)__shfl_down((unsigned long long)acc, d, 64);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    uint64_t all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kScanThreads / 64; ++w) all += red[w];
+    __syncthreads();
+    return all;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_check_scan_mw(IndexArgs a, unsigned long long* part) {
+    constexpr int kSub = 4;
+    __shared__ uint64_t wtot[kSub][kScanThreads / 64];
+    __shared__ uint64_t red[kScanThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6, n = a.n_blocks;
+    const uint32_t g = scan_ticket(part);
+    const uint32_t i0 = g * kScanPerWg;
+    uint32_t first_bad = 0xFFFFFFFFu;
+    uint64_t v[kSub], incl[kSub];
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+        v[u] = 0;
+        if (i < n) {
+            v[u] = a.count[i];
+            const ChainRun r = a.runs[a.run_of[i]];
+            if (i != r.blk_first && a.exit_[i - 1] != a.entry[i] && first_bad == 0xFFFFFFFFu) first_bad = i;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        uint64_t x = v[u];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = (uint64_t)__shfl_up((unsigned long long)x, d, 64);
+            if ((int)lane >= d) x += o;
+        }
+        incl[u] = x;
+        if (lane == 63) wtot[u][wv] = x;
+    }
+    __syncthreads();
+    uint64_t before[kSub], total = 0;
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        uint64_t b = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+            const uint64_t x = wtot[u][w];
+            b += w < wv ? x : 0;
+            all += x;
+        }
+        before[u] = total + b;
+        total += all;
+    }
+    if (t == 0) __hip_atomic_store(part + g, (unsigned long long)total | kScanReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t run = lookback_sum(part, g, red);
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+        if (i < n) a.state[i] = (2ull << 62) | (run + before[u] + incl[u]);
+    }
+    if (first_bad != 0xFFFFFFFFu) atomicMin(a.flags + 0, first_bad);
+    if (t == 0 && g == gridDim.x - 1 && run + total > a.desc_cap) atomicOr(a.flags + 2, 1u);       // (the last ticket: run + total = all records)
+}
+
 // ---- 3. describe: one wave per block, one lane per record ---------------------------------------------------
 constexpr int kDescThreads = 256;
 
@@ -907,9 +998,9 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     }
 }
 
-// the staged form at 5 and at 4 waves per SIMD (96 VGPRs and a few spills / 124 VGPRs), and round 4's kernel (SBX_K2_DESCRIBE=0)
-__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks(IndexArgs a) { describe_blocks_body<true>(a); }
-__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_blocks_w4(IndexArgs a) { describe_blocks_body<true>(a); }
+// the staged form at 4 waves per SIMD (124 VGPRs; at 5 waves -- 96 VGPRs and a dozen spills -- it is 0.2 ms slower), and round 4's
+// kernel (SBX_K2_DESCRIBE=0: the A/B partner; config 2: record_index 8.5 -> 7.5 ms with the staged form, profiles/round5)
+__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_blocks(IndexArgs a) { describe_blocks_body<true>(a); }
 __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks_r4(IndexArgs a) { describe_blocks_body<false>(a); }
 
 // ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
@@ -971,6 +1062,67 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* _
     if (t == 0) { n_active[0] = run; n_active[1] = deep_total; }
 }
 
+// several workgroups, one launch (see k_check_scan_mw): workgroup g ranks the active tiles of [4096 g, 4096 g + 4096) behind the
+// active tiles of the workgroups before it; n_active[0] / [1] (zeroed by the launcher) collect the totals
+__global__ __launch_bounds__(kScanThreads) void k_tile_compact_mw(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi,
+                                                                   uint32_t n_tiles, uint32_t deep_thr, uint32_t* __restrict__ active,
+                                                                   uint32_t* __restrict__ slot_of, uint32_t* __restrict__ n_active,
+                                                                   unsigned long long* part) {
+    constexpr int kSub = 4;
+    __shared__ uint32_t wtot[kSub][kScanThreads / 64];
+    __shared__ uint64_t red[kScanThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const uint32_t g = scan_ticket(part);
+    const uint32_t i0 = g * kScanPerWg;
+    uint32_t lo_i[kSub], hi_i[kSub], n_deep = 0;
+    uint64_t m[kSub];
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+        lo_i[u] = i < n_tiles ? tile_lo[i] : 0u;
+        hi_i[u] = i < n_tiles ? tile_hi[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        const bool on = hi_i[u] > lo_i[u];
+        n_deep += on && hi_i[u] - lo_i[u] >= deep_thr ? 1u : 0u;
+        m[u] = __ballot(on);
+        if (lane == 0) wtot[u][wv] = (uint32_t)__popcll(m[u]);
+    }
+    __syncthreads();
+    uint32_t before[kSub], total = 0;
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        uint32_t b = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+            const uint32_t x = wtot[u][w];
+            b += w < wv ? x : 0u;
+            all += x;
+        }
+        before[u] = total + b;
+        total += all;
+    }
+    if (t == 0) __hip_atomic_store(part + g, (unsigned long long)total | kScanReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t run = (uint32_t)lookback_sum(part, g, red);
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * kScanThreads + t;
+        if (i < n_tiles) {
+            if (hi_i[u] > lo_i[u]) {
+                const uint32_t slot = run + before[u] + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
+                active[slot] = i;
+                slot_of[i] = slot;
+            } else {
+                slot_of[i] = 0xFFFFFFFFu;
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) n_deep += __shfl_down(n_deep, d, 64);
+    if (lane == 0 && n_deep) atomicAdd(n_active + 1, n_deep);
+    if (t == 0 && g == gridDim.x - 1) n_active[0] = run + total;
+}
+
 
 }  // namespace
 
@@ -994,13 +1146,19 @@ void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
     if (!a.n_blocks) return;
     hipLaunchKernelGGL(k_walk_blocks, dim3((a.n_blocks + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, stream, a);
     SBX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_check_scan, dim3(1), dim3(kScanThreads), 0, stream, a);
+    // (scan_part: kScanMaxWgs words the launcher owns -- IndexArgs::scan_part; SBX_K2_SCAN=0 keeps the single workgroup)
+    static const bool mw = [] { const char* e = getenv("SBX_K2_SCAN"); return !e || atoi(e) != 0; }();
+    const uint32_t n_wg = (a.n_blocks + kScanPerWg - 1) / kScanPerWg;
+    if (mw && a.scan_part && n_wg > 1 && n_wg <= kScanMaxWgs) {
+        SBX_HIP(hipMemsetAsync(a.scan_part, 0, (size_t)kScanPartWords * 8, stream));
+        hipLaunchKernelGGL(k_check_scan_mw, dim3(n_wg), dim3(kScanThreads), 0, stream, a, a.scan_part);
+    } else
+        hipLaunchKernelGGL(k_check_scan, dim3(1), dim3(kScanThreads), 0, stream, a);
     SBX_HIP(hipGetLastError());
     const uint32_t per = kDescThreads / 64;
-    static const int form = [] { const char* e = getenv("SBX_K2_DESCRIBE"); return e ? atoi(e) : 2; }();
+    static const int form = [] { const char* e = getenv("SBX_K2_DESCRIBE"); return e ? atoi(e) : 1; }();
     const dim3 dgrid((a.n_blocks + per - 1) / per), dblock(kDescThreads);
     if (form == 0) hipLaunchKernelGGL(k_describe_blocks_r4, dgrid, dblock, 0, stream, a);
-    else if (form == 2) hipLaunchKernelGGL(k_describe_blocks_w4, dgrid, dblock, 0, stream, a);
     else hipLaunchKernelGGL(k_describe_blocks, dgrid, dblock, 0, stream, a);
     SBX_HIP(hipGetLastError());
 }
@@ -1027,9 +1185,17 @@ void launch_count_scan(const uint32_t* d_count, uint32_t n_blocks, uint64_t* d_b
 }
 
 void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t deep_thr, uint32_t* d_active,
-                         uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream) {
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(kScanThreads), 0, stream, d_tile_lo, d_tile_hi, n_tiles, deep_thr, d_active,
-                       d_slot_of, d_n_active);
+                         uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream, unsigned long long* d_scan_part) {
+    static const bool mw = [] { const char* e = getenv("SBX_K2_SCAN"); return !e || atoi(e) != 0; }();
+    const uint32_t n_wg = (n_tiles + kScanPerWg - 1) / kScanPerWg;
+    if (mw && d_scan_part && n_wg > 1 && n_wg <= kScanMaxWgs) {
+        SBX_HIP(hipMemsetAsync(d_scan_part, 0, (size_t)kScanPartWords * 8, stream));
+        SBX_HIP(hipMemsetAsync(d_n_active, 0, 8, stream));
+        hipLaunchKernelGGL(k_tile_compact_mw, dim3(n_wg), dim3(kScanThreads), 0, stream, d_tile_lo, d_tile_hi, n_tiles, deep_thr, d_active,
+                           d_slot_of, d_n_active, d_scan_part);
+    } else
+        hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(kScanThreads), 0, stream, d_tile_lo, d_tile_hi, n_tiles, deep_thr, d_active,
+                           d_slot_of, d_n_active);
     SBX_HIP(hipGetLastError());
 }
 

@@ -911,14 +911,13 @@ struct Short16 {
 // Long copy tasks (16 < n <= 512) of a wave, done by all 64 lanes, 8 bytes per lane, four tasks in
 // flight (loads of all four before the first store).  Lane r of `m` owns a task: n bytes from
 // sbase + s to buf + d.  Source and destination of a task never overlap.
-// (kTasks: tasks per turn of the loop.  tools/token_stats.cpp: a batch of a BAM stream holds 1.6 long far matches and 0.2 long literal
-// runs -- with four tasks unrolled a turn executes ~220 instructions for one or two tasks, most of them predicated off)
-template <int kTasks = 4>
+// (four tasks per turn of the loop; two or one per turn -- a batch of a BAM stream holds 1.6 long far matches and 0.2 long literal runs,
+// tools/token_stats.cpp -- execute 8 % fewer vector instructions and are not faster: profiles/round5/README.md)
 __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint32_t s, uint8_t* buf, uint32_t d, uint32_t n, uint32_t lane) {
     while (m) {
-        uint32_t S[kTasks], D[kTasks], N[kTasks], wa[kTasks], wb[kTasks];
+        uint32_t S[4], D[4], N[4], wa[4], wb[4];
 #pragma unroll
-        for (int j = 0; j < kTasks; ++j) {
+        for (int j = 0; j < 4; ++j) {
             N[j] = 0; S[j] = 0; D[j] = 0;
             if (m) {
                 const int r = __builtin_ctzll(m);
@@ -930,7 +929,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
         }
         const uint32_t off = 8 * lane;
 #pragma unroll
-        for (int j = 0; j < kTasks; ++j) {
+        for (int j = 0; j < 4; ++j) {
             if (off < N[j]) {
                 const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
                 wa[j] = ldu32(sbase + S[j] + a);
@@ -938,7 +937,7 @@ __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint
             }
         }
 #pragma unroll
-        for (int j = 0; j < kTasks; ++j) {
+        for (int j = 0; j < 4; ++j) {
             if (off < N[j]) {
                 const uint32_t a = off + 4 <= N[j] ? off : N[j] - 4, c = off + 8 <= N[j] ? off + 4 : N[j] - 4;
                 stu32(buf + D[j] + a, wa[j]);
@@ -966,17 +965,10 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // by their own lane with a second 16-byte step; and a short self-overlapping match (a run, a dinucleotide repeat: 0.8 per
 // batch, 84 % with a period of at most 8) is no longer expanded byte by byte but with four byte permutes of the period
 // (v_perm_b32, selectors per period from a 128-byte table in LDS).
-// kJump (variant 2, written at the end of round 4 when the GPU budget was spent: NOT YET RUN ON A DEVICE, off by default; its
-// algorithm is checked on the CPU, tests/cpp/inflate2_host.cpp `--jump`): the rounds of phase B below cost ~2,000 of the ~3,400
-// instructions a wavefront executes per batch (5.6 rounds, every kind of copy predicated in every round).  The near matches are
-// resolved per OUTPUT BYTE instead: every position of the batch gets the position its byte comes from -- itself for literal and
-// far-match bytes, which phase A has already put into the window; q - dist inside a near match (a self-overlapping match
-// simply points into itself) --, the pointers are followed to a byte that is final (the window below the batch, a literal, a
-// far-match byte), and the byte is copied.  Positions are taken 64 at a time in increasing order, so everything a pointer
-// meets below the current group is already final: one lookup resolves a byte whose source lies in an earlier group, bytes that
-// depend on bytes of their own group (short distances, runs) take a few more.  No divergence, no per-kind code paths: ~35
-// instructions per position and group.
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kJump = false, bool kExact = false, int kCoop = 4>
+// (Round 4's candidate -- near matches resolved per OUTPUT BYTE through origin pointers, `k_lz77_resolve_jump` -- ran on the device in
+// round 5: correct, and 37 % SLOWER than this kernel (30.6 against 22.4 ms on config 2; more instructions of every kind, not fewer:
+// profiles/round5/README.md).  It is gone; what it left is the lesson that the rounds of phase B are cheap -- see kExact below.)
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -1057,8 +1049,8 @@ __device__ __forceinline__ void lz77_resolve_body(
                 rl.store(buf + (eo - base) + 16u * h, n_l);
                 rf.store(buf + (dst - base) + 16u * h, n_f);
             }
-            coop_copy<kCoop>(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
-            coop_copy<kCoop>(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
+            coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
+            coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
         }
         // ---- phase B: near matches, LDS -> LDS --------------------------------------------------------------
         // A match may start once everything below its source end is final.  Matches start in entry order,
@@ -1072,63 +1064,13 @@ __device__ __forceinline__ void lz77_resolve_body(
         const uint32_t s_hi = src + (len < dist ? len : dist);
         const uint32_t dsto = dst - base, srco = src - base;
         bool pending = len != 0 && !far;
-        if (kJump) {
-            // origins, one u16 per position of the batch (window coordinates), behind the windows and the selector table
-            uint16_t* org = (uint16_t*)(smem + (kResThreads / 64) * kWaveLds + 128u) + wv * kSpanMax;
-            const uint32_t lo = opos - base;                       // window offset of the batch's first byte
-            if (__any(pending)) {
-                const uint32_t k = (span + 63u) >> 6;              // groups of 64 positions
-                // 1. marks: the lane of every near match at its first byte, 0xFFFF elsewhere
-                for (uint32_t i = 0; i < k; ++i) org[i * 64u + lane] = 0xFFFFu;
-                if (pending) org[dsto - lo] = (uint16_t)lane;
-                // 2. owner of a position = the last mark at or before it: lane L scans positions [L k, L k + k), the last mark of the lanes
-                //    below it comes from a max-scan over the lanes (marks increase with the position)
-                uint32_t last = 0;                                 // lane + 1 of the last mark in this lane's stretch, 0 = none
-                for (uint32_t i = 0; i < k; ++i) { const uint32_t m = org[lane * k + i]; last = m != 0xFFFFu ? m + 1u : last; }
-                uint32_t incl = last;
-                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true));     // row_shr:1
-                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true));     // row_shr:2
-                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true));     // row_shr:4
-                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true));     // row_shr:8
-                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false));    // row_bcast:15
-                incl = max(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false));    // row_bcast:31
-                uint32_t run = (uint32_t)__shfl_up((int)incl, 1, 64);
-                if (lane == 0) run = 0;
-                for (uint32_t i = 0; i < k; ++i) {
-                    const uint32_t q = lane * k + i, m = org[q];
-                    run = m != 0xFFFFu ? m + 1u : run;
-                    org[q] = (uint16_t)(run ? run - 1u : 0xFFFFu);
-                }
-                // 3. group by group: origin, resolution, the byte
-                const uint32_t cover = pending ? ((dsto - lo + len) << 16) | dist : 0u;      // end of the match (batch-relative) | distance
-                for (uint32_t i = 0; i < k; ++i) {
-                    const uint32_t q = i * 64u + lane, g0 = i * 64u;
-                    const uint32_t e = org[q];
-                    const uint32_t cv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e & 63u) << 2), (int)cover);
-                    const bool cov = q < span && e != 0xFFFFu && q < (cv >> 16);
-                    uint32_t o = cov ? q + lo - (cv & 0xFFFFu) : q + lo;            // (a near match: dist <= window offset of its first byte)
-                    bool open = cov && o >= lo;
-                    org[q] = (uint16_t)o;
-                    // (origins strictly decrease, so a chain inside a group ends within 64 steps; the cap keeps a corrupted table from spinning)
-                    for (uint32_t it = 0; it < 72u && __any(open); ++it) {
-                        if (open) {
-                            const uint32_t sl = o - lo, o2 = org[sl];
-                            if (sl < g0) { o = o2; open = false; }                 // a finished group's slot holds a final origin
-                            else if (o2 == o) open = false;                        // its own origin: a literal or far-match byte of this group
-                            else { o = o2; open = o >= lo; }
-                            org[q] = (uint16_t)o;
-                        }
-                    }
-                    if (cov) buf[q + lo] = buf[o];
-                }
-            }
-            pending = false;
-        }
         // kExact (variant 3): the exact readiness rule.  A match may start once no UNFINISHED match writes into its source range
         // [src, s_hi).  Entries are in position order, so the matches whose destination meets that range are a contiguous range of
         // lanes [jlo, jhi] -- found once per batch by two binary searches over the lanes' {start, end} of the match (window offsets,
         // 16 bits each, one dword per lane in LDS) -- and "unfinished" is the ballot of pending lanes: ready = no pending lane in my
-        // range.  3.3 rounds per batch instead of 5.6 on a BAM stream (tools/token_stats.cpp); every round executes every copy path.
+        // range.  3.3 rounds per batch instead of 5.6 on a BAM stream (tools/token_stats.cpp).  Measured (profiles/round5): scalar
+        // instructions -22 %, vector instructions -4 % (a round is ~25 vector and ~55 scalar instructions; the two searches cost 36 vector
+        // instructions per batch), kernel time -2.5 % (22.2 -> 21.7 ms on config 2): the kernel follows its VECTOR instruction count.
         uint32_t dep_lo = 0, dep_hi = 0;
         if (kExact) {
             uint32_t* rng = (uint32_t*)(smem + (kResThreads / 64) * kWaveLds + 128u) + wv * 64u;
@@ -1168,7 +1110,7 @@ __device__ __forceinline__ void lz77_resolve_body(
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
                 }
-                coop_copy<kCoop>(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
+                coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
             // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
@@ -1247,29 +1189,16 @@ __device__ __forceinline__ void lz77_resolve_body(
                       const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0, uint8_t* out, \
                       const uint32_t* __restrict__ status
 #define SBX_LZ77_PASS lit_stream, ent_stream, n_entries, out_off, isize, n_blocks, block0, out, status
-// k_lz77_resolve: round 2's kernel (own-lane copies up to 16 bytes); k_lz77_resolve_o32: own-lane copies up to 32 bytes + byte-permute
-// expansion of short periodic matches, compiled for 8 waves per SIMD (64 VGPRs either way; the attribute is worth 0.4 ms)
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) void k_lz77_resolve(SBX_LZ77_ARGS) { lz77_resolve_body<kHist, kSpanMax, false>(SBX_LZ77_PASS); }
+// k_lz77_resolve_o32 (round 3; SBX_K1B_VARIANT=1: the A/B partner): own-lane copies up to 32 bytes + byte-permute expansion of short
+// periodic matches, the frontier rule; k_lz77_resolve_exact (round 5, the default): the same with the exact readiness rule (kExact above;
+// LDS per wave: window + 256 bytes of match ranges).  Both compiled for 8 waves per SIMD (64 VGPRs; the attribute is worth 0.4 ms).
 template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_o32(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true>(SBX_LZ77_PASS);
+    lz77_resolve_body<kHist, kSpanMax, true, false>(SBX_LZ77_PASS);
 }
-// variant 2 (see kJump above): phase A of variant 1, near matches by origin pointers; LDS per wave: window + 2 bytes per batch position
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) void k_lz77_resolve_jump(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true, true>(SBX_LZ77_PASS);
-}
-constexpr uint32_t kHistJump = 2048, kSpanJump = 1024;
-// variant 3: variant 1 with the exact readiness rule (kExact above); LDS per wave: window + 256 bytes of match ranges
 template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_exact(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true, false, true>(SBX_LZ77_PASS);
-}
-// variants 4 / 5: variant 3 with two / one task per turn of the cooperative copy loop
-template <uint32_t kHist, uint32_t kSpanMax, int kCoop>
-__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_exact_c(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true, false, true, kCoop>(SBX_LZ77_PASS);
+    lz77_resolve_body<kHist, kSpanMax, true, true>(SBX_LZ77_PASS);
 }
 
 }  // namespace
@@ -1344,35 +1273,12 @@ void launch_k1b(const InflateArgs& a, hipStream_t stream) {
     dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
     const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
     static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 3; }();
-    if (variant == 0)
-        hipLaunchKernelGGL((k_lz77_resolve<kHistDefault, kSpanDefault>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
-                           a.n_blocks, a.block0, a.out, a.status);
-    else if (variant == 2) {
-        // (history kept in LDS, SBX_K1B_HIST = 2048 | 4096 | 8192: the far-match share of the output falls from 29 % to 20 % to 13 %
-        // -- DESIGN.md 3 K1b -- for 6, 4 and 3 waves per SIMD)
-        static const int hist = [] { const char* e = getenv("SBX_K1B_HIST"); return e ? atoi(e) : (int)kHistJump; }();
-#define SBX_K1B_JUMP(H)                                                                                                                    \
-        hipLaunchKernelGGL((k_lz77_resolve_jump<H, kSpanJump>), grid, block,                                                                \
-                           (size_t)(kResThreads / 64) * (H + 1024u + kSpanJump + 16u + 2u * kSpanJump) + 128, stream, a.lit, a.ent, a.nent, \
-                           a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status)
-        if (hist == 8192) SBX_K1B_JUMP(8192u);
-        else if (hist == 4096) SBX_K1B_JUMP(4096u);
-        else SBX_K1B_JUMP(kHistJump);
-#undef SBX_K1B_JUMP
-    } else if (variant == 4 || variant == 5) {
-        const size_t l3 = lds + 128 + (size_t)(kResThreads / 64) * 256;
-        if (variant == 4)
-            hipLaunchKernelGGL((k_lz77_resolve_exact_c<kHistDefault, kSpanDefault, 2>), grid, block, l3, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
-                               a.n_blocks, a.block0, a.out, a.status);
-        else
-            hipLaunchKernelGGL((k_lz77_resolve_exact_c<kHistDefault, kSpanDefault, 1>), grid, block, l3, stream, a.lit, a.ent, a.nent, a.out_off, a.isize,
-                               a.n_blocks, a.block0, a.out, a.status);
-    } else if (variant == 3)
-        hipLaunchKernelGGL((k_lz77_resolve_exact<kHistDefault, kSpanDefault>), grid, block, lds + 128 + (size_t)(kResThreads / 64) * 256, stream, a.lit,
-                           a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
-    else
+    if (variant == 1)
         hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, a.lit, a.ent, a.nent, a.out_off,
                            a.isize, a.n_blocks, a.block0, a.out, a.status);
+    else
+        hipLaunchKernelGGL((k_lz77_resolve_exact<kHistDefault, kSpanDefault>), grid, block, lds + 128 + (size_t)(kResThreads / 64) * 256, stream, a.lit,
+                           a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
     SBX_HIP(hipGetLastError());
 }
 

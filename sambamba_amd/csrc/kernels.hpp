@@ -148,9 +148,11 @@ struct IndexArgs {
     // owners' runs equal the whole
     int32_t own_ref;
     uint32_t own_beg, own_end;
+    unsigned long long* scan_part;  // kScanPartWords words of scratch for the multi-workgroup scans (nullptr: single-workgroup kernels)
     uint32_t* flags;                // [0] lowest block with an inconsistent chain (0xFFFFFFFF: none), [1] lowest block whose
                                     // inflate failed, [2] != 0: desc_cap was too small (nothing useful was written)
 };
+constexpr uint32_t kScanPartWords = 512;
 void launch_index_blocks(const IndexArgs& a, hipStream_t stream);
 // parallel repair round: blocks not entered where their predecessor was left are walked again from there
 // (*d_n_changed += blocks re-walked; reads exit_[b-1] of the previous round: launch until it stays 0)
@@ -166,7 +168,7 @@ size_t count_scan_tmp_bytes(uint32_t n_blocks);
 // compact the tiles that have work: active[] = tile ids, slot_of[t] = index into active or ~0u;
 // d_n_active[0] = number of active tiles, [1] = how many of them have >= 65536 records
 void launch_tile_compact(const uint32_t* d_tile_lo, const uint32_t* d_tile_hi, uint32_t n_tiles, uint32_t deep_thr, uint32_t* d_active,
-                         uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream);
+                         uint32_t* d_slot_of, uint32_t* d_n_active, hipStream_t stream, unsigned long long* d_scan_part = nullptr);
 
 // ---- K3: decode + accumulate (depth.hip) -------------------------------------------------
 // n_deep: active tiles with >= deep_thr (<= 65536) records, counted by tile_compact; they keep 32-bit LDS counters

@@ -102,7 +102,7 @@ def first_column_in(d, ref, beg, end):
         b, e = max(r[0], pos), min(r[1], end)
         step = 1 << 13
         for x in range(b, e, step):
-            _, cov = d.base_counters(ref, x, min(e, x + step), with_covered=True)
+            cov = d.covered(ref, x, min(e, x + step))      # (`covered` is what every kind of run keeps)
             nz = np.flatnonzero(cov)
             if len(nz):
                 return x + int(nz[0])

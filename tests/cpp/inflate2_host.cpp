@@ -27,104 +27,87 @@ static std::vector<uint8_t> read_file(const char* path) {
     return v;
 }
 
-// K1b variant 2 (inflate.hip, kJump) step by step on the CPU -- the algorithm, not the HIP code: batches of <= 64 entries and
-// <= kSpan bytes, a window that keeps >= kHist bytes below the batch, literal and far-match bytes put in place first (phase A), then
-// every near-match byte resolved through origin pointers, positions taken 64 at a time in increasing order, the 64 lanes of a
-// group in lockstep (all reads of a step before its writes).  Returns false on an inconsistency.
-static long g_far_bytes = 0;
-static bool resolve_jump(const uint32_t* ent, uint32_t n_ent, const uint8_t* lit, uint32_t isize, std::vector<uint8_t>& out,
-                         long* n_lookups, long* n_positions, long* n_groups = nullptr, long* n_steps = nullptr) {
-    static const uint32_t kHist = getenv("SBX_EMU_HIST") ? (uint32_t)atoi(getenv("SBX_EMU_HIST")) : 2048u;     // (the kernel: 2048)
-    constexpr uint32_t kSpan = 1024;
-    const uint32_t kCap = kHist + 1024 + kSpan;
+// K1b's near-match resolution with the EXACT readiness rule (inflate.hip, kExact: the default kernel since round 5) step by step on the
+// CPU -- the algorithm, not the HIP code: batches of <= 64 entries and <= kSpan bytes; literal runs and far matches (source below the
+// window base) put in place first (phase A); then rounds: a pending match is READY when no pending match writes into its source range
+// [src, src + min(len, dist)) -- the matches that could are a contiguous range of lanes [jlo, jhi), found by the same two branch-free
+// binary searches over the lanes' {start, end} the kernel runs, tested against the set of pending lanes -- and all ready matches of a
+// round are copied in lockstep (every read of the round before its writes).  Returns false on an inconsistency; counts the rounds.
+static bool resolve_exact(const uint32_t* ent, uint32_t n_ent, const uint8_t* lit, uint32_t isize, std::vector<uint8_t>& out,
+                          long* n_batches, long* n_rounds) {
+    constexpr uint32_t kHist = 2048, kSpan = 1536, kCap = kHist + 1024 + kSpan;
     out.assign(isize, 0);
-    std::vector<uint8_t> buf(kCap + 64, 0xDD);
-    std::vector<uint16_t> org(kSpan, 0);
     uint32_t opos = 0, lpos = 0, base = 0;
     for (uint32_t e0 = 0; e0 < n_ent;) {
-        // the batch: <= 64 entries whose inclusive sums stay <= kSpan (at least one entry: <= 513 bytes)
         uint32_t take = 0, span = 0, lspan = 0;
-        uint32_t lr[64], len[64], dist[64], eo[64], el[64];
+        uint32_t lr[64], len[64], dist[64], dst[64];
         while (take < 64 && e0 + take < n_ent) {
             const uint32_t e = ent[e0 + take], l = e >> 24, n = e & 511u;
             if (span + l + n > kSpan) break;
             lr[take] = l; len[take] = n; dist[take] = ((e >> 9) & 0x7FFFu) + 1u;
-            eo[take] = opos + span; el[take] = lpos + lspan;
+            dst[take] = opos + span + l;
             span += l + n; lspan += l;
             ++take;
         }
-        if (!take) return false;
-        if (opos + span > isize) return false;
-        // slide
-        if (opos - base + kSpan > kCap) {
-            const uint32_t nb = (opos - kHist) & ~15u, delta = nb - base, keep = opos - nb;
-            memmove(buf.data(), buf.data() + delta, keep);
-            base = nb;
-        }
-        const uint32_t lo = opos - base;
-        // phase A: literals and far matches (source below the window: final output)
-        bool near[64];
-        for (uint32_t t = 0; t < take; ++t) {
-            for (uint32_t i = 0; i < lr[t]; ++i) buf[eo[t] - base + i] = lit[el[t] + i];
-            const uint32_t dst = eo[t] + lr[t];
-            near[t] = false;
-            if (len[t]) {
-                if (dist[t] > dst) return false;
-                const uint32_t src = dst - dist[t];
-                if (src < base) { for (uint32_t i = 0; i < len[t]; ++i) buf[dst - base + i] = out[src + i]; g_far_bytes += len[t]; }      // (never self-overlapping: kHist > 258)
-                else near[t] = true;
-            }
-        }
-        // phase B: marks -> owners (last mark at or before a position)
-        const uint32_t k = (span + 63) / 64;
-        for (uint32_t q = 0; q < 64 * k; ++q) org[q] = 0xFFFF;
-        for (uint32_t t = 0; t < take; ++t) if (near[t]) org[eo[t] + lr[t] - opos] = (uint16_t)t;
-        { uint32_t run = 0xFFFF; for (uint32_t q = 0; q < 64 * k; ++q) { if (org[q] != 0xFFFF) run = org[q]; org[q] = (uint16_t)run; } }
-        for (uint32_t g = 0; g < k; ++g) {
-            const uint32_t g0 = 64 * g;
-            uint32_t o[64];
-            bool open[64], cov[64];
-            for (uint32_t l = 0; l < 64; ++l) {
-                const uint32_t q = g0 + l, e = org[q];
-                cov[l] = q < span && e != 0xFFFF && q < eo[e & 63] + lr[e & 63] - opos + len[e & 63];
-                o[l] = cov[l] ? q + lo - dist[e & 63] : q + lo;
-                open[l] = cov[l] && o[l] >= lo;
-            }
-            for (uint32_t l = 0; l < 64; ++l) org[g0 + l] = (uint16_t)o[l];
-            for (int guard = 0;; ++guard) {
-                bool any = false;
-                for (uint32_t l = 0; l < 64; ++l) any |= open[l];
-                if (!any) break;
-                if (guard > 2000) return false;
-                if (n_steps) ++*n_steps;
-                uint32_t o2[64];
-                for (uint32_t l = 0; l < 64; ++l) if (open[l]) { o2[l] = org[o[l] - lo]; ++*n_lookups; }        // reads of the step
-                for (uint32_t l = 0; l < 64; ++l) {                                                              // ... then its writes
-                    if (!open[l]) continue;
-                    const uint32_t sl = o[l] - lo;
-                    if (sl < g0) { o[l] = o2[l]; open[l] = false; }
-                    else if (o2[l] == o[l]) open[l] = false;
-                    else { o[l] = o2[l]; open[l] = o[l] >= lo; }
-                    org[g0 + l] = (uint16_t)o[l];
+        if (!take || opos + span > isize) return false;
+        if (opos - base + kSpan > kCap) base = (opos - kHist) & ~15u;          // the window slides: what lies below `base` is "far"
+        // phase A: literal runs; far matches (their source was final a batch ago)
+        uint32_t lp = lpos;
+        uint64_t pending = 0;
+        uint32_t start[64], end[64];
+        for (uint32_t j = 0; j < 64; ++j) {
+            if (j < take) {
+                for (uint32_t k = 0; k < lr[j]; ++k) out[dst[j] - lr[j] + k] = lit[lp++];
+                if (len[j]) {
+                    if (dist[j] > dst[j]) return false;
+                    const uint32_t src = dst[j] - dist[j];
+                    if (src < base) { for (uint32_t k = 0; k < len[j]; ++k) out[dst[j] + k] = out[src + k]; }
+                    else pending |= 1ull << j;
                 }
+                start[j] = dst[j] - base; end[j] = dst[j] + len[j] - base;
+            } else {
+                start[j] = end[j] = opos + span - base;     // (lanes behind the batch: monotone, never pending)
             }
-            if (n_groups) ++*n_groups;
-            uint8_t v[64];
-            for (uint32_t l = 0; l < 64; ++l) if (cov[l]) { v[l] = buf[o[l]]; ++*n_positions; }
-            for (uint32_t l = 0; l < 64; ++l) if (cov[l]) buf[g0 + l + lo] = v[l];
         }
-        // phase C
-        memcpy(out.data() + opos, buf.data() + lo, span);
+        // dependency masks: two branch-free binary searches per lane, as in the kernel
+        uint64_t dep[64];
+        for (uint32_t i = 0; i < 64; ++i) {
+            dep[i] = 0;
+            if (!(pending >> i & 1)) continue;
+            const uint32_t srco = dst[i] - dist[i] - base, s_hio = srco + (len[i] < dist[i] ? len[i] : dist[i]);
+            uint32_t jlo = 0, jhi = 0;
+            for (uint32_t step = 32; step; step >>= 1) {
+                if (end[jlo + step - 1] <= srco) jlo += step;
+                if (start[jhi + step - 1] < s_hio) jhi += step;
+            }
+            if (jhi > jlo) dep[i] = ((jhi >= 64 ? ~0ull : (1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull));
+        }
+        ++*n_batches;
+        for (int guard = 0; pending; ++guard) {
+            if (guard > 64) return false;                    // (a round finishes at least the first pending match)
+            ++*n_rounds;
+            uint64_t ready = 0;
+            for (uint32_t i = 0; i < 64; ++i) if ((pending >> i & 1) && !(dep[i] & pending)) ready |= 1ull << i;
+            if (!ready) return false;
+            std::vector<std::pair<uint32_t, uint8_t>> writes;
+            for (uint32_t i = 0; i < 64; ++i) {
+                if (!(ready >> i & 1)) continue;
+                const uint32_t src = dst[i] - dist[i];
+                for (uint32_t k = 0; k < len[i]; ++k) writes.push_back({dst[i] + k, out[src + k % dist[i]]});      // reads [src, dst) only
+            }
+            for (auto& w : writes) out[w.first] = w.second;
+            pending &= ~ready;
+        }
         opos += span; lpos += lspan; e0 += take;
     }
     return opos == isize;
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s FILE [lane] [--jump]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s FILE [lane] [--exact]\n", argv[0]); return 2; }
     const uint32_t lane = argc > 2 ? (uint32_t)atoi(argv[2]) : 0u;
-    const bool jump = argc > 3 && !strcmp(argv[3], "--jump");
-    long n_lookups = 0, n_positions = 0, n_groups = 0, n_steps = 0;
+    const bool exact = argc > 3 && !strcmp(argv[3], "--exact");
+    long n_batches = 0, n_rounds = 0;
     std::vector<uint8_t> file = read_file(argv[1]);
     std::vector<uint8_t> lds(kWaveLds + kLenTabBytes + kDistTabBytes, 0xA5);
     uint16_t* len_tab = (uint16_t*)(lds.data() + kWaveLds);
@@ -196,9 +179,9 @@ int main(int argc, char** argv) {
                 if (got.size() > isize) ok = false;
             }
             ok = ok && lp == n_lit && got.size() == isize && memcmp(got.data(), want.data(), isize) == 0;
-            if (ok && jump) {
+            if (ok && exact) {
                 std::vector<uint8_t> got2;
-                ok = resolve_jump(ent.data(), R.n_ent, lit_al, isize, got2, &n_lookups, &n_positions, &n_groups, &n_steps) && memcmp(got2.data(), want.data(), isize) == 0;
+                ok = resolve_exact(ent.data(), R.n_ent, lit_al, isize, got2, &n_batches, &n_rounds) && memcmp(got2.data(), want.data(), isize) == 0;
             }
             if (!ok) {
                 ++n_bad;
@@ -208,9 +191,6 @@ int main(int argc, char** argv) {
         pos += bsize;
     }
     printf("%ld %ld %ld %ld\n", n_blocks, n_fast, n_general, n_bad);
-    if (jump) fprintf(stderr, "jump: %ld far-match bytes (phase A, from global memory)\n", g_far_bytes);
-    if (jump)
-        fprintf(stderr, "jump: %ld near-match bytes, %.2f pointer lookups per byte; %ld groups of 64 positions, %.2f lockstep steps per group\n", n_positions,
-                n_positions ? (double)n_lookups / n_positions : 0.0, n_groups, n_groups ? (double)n_steps / n_groups : 0.0);
+    if (exact) fprintf(stderr, "exact rule: %ld batches, %.2f rounds per batch\n", n_batches, n_batches ? (double)n_rounds / n_batches : 0.0);
     return n_bad == 0 ? 0 : 1;
 }

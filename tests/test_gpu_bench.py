@@ -34,7 +34,6 @@ def test_bench_line(tmp_path, extra):
     assert "accounting_error" not in d
     for k, e in d["kernels"].items():
         assert 0 < e["frac_of_hbm_peak"] <= 1, (k, e)
-    assert d["kernels"]["decode_accumulate"]["algorithmic_bytes"] < d["kernels"]["lz77_resolve"]["algorithmic_bytes"]
     assert d["parity_checked"]["ok"] and d["parity_checked"]["windows"] >= 1
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
     assert d["e2e"]["Mreads_per_s"] > 0

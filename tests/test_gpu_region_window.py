@@ -113,6 +113,10 @@ def test_contig_shards_reproduce_the_whole_run(synth):
         d.set_params(mode=sambamba_amd.SBX_MODE_REGION, thresholds=thr)
         whole_stats = d.run()
         w_reads, w_bases, w_cov, w_seen = d.region_stats(bed, len(thr))
+        w_covered = {r: d.covered(r, 0, lens[r]) for r in range(len(lens))}
+    with sambamba_amd.Depth(synth) as d:         # (the seven counters per position are what a `base` run keeps)
+        d.set_params()
+        d.run()
         w_counts = {r: d.base_counters(r, 0, lens[r]) for r in range(len(lens))}
     for world in (2, 3):
         shards = plan_contig_shards(lens, world)
@@ -129,5 +133,11 @@ def test_contig_shards_reproduce_the_whole_run(synth):
                 reads, bases, cov, seen = d.region_stats([bed[i] for i in mine], len(thr))
                 assert np.array_equal(reads, w_reads[mine]) and np.array_equal(bases, w_bases[mine])
                 assert np.array_equal(cov, w_cov[mine]) and np.array_equal(seen, w_seen[mine])
+                for r in range(sh[0], sh[1]):
+                    assert np.array_equal(d.covered(r, 0, lens[r]), w_covered[r])
+            with sambamba_amd.Depth(synth) as d:
+                d.set_params()
+                d.set_regions(regs)
+                d.run()
                 for r in range(sh[0], sh[1]):
                     assert np.array_equal(d.base_counters(r, 0, lens[r]), w_counts[r])

@@ -23,8 +23,8 @@ def harness(tmp_path_factory):
     return exe
 
 
-def _run(exe, path, lane=0, jump=False):
-    p = subprocess.run([exe, path, str(lane)] + (["--jump"] if jump else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+def _run(exe, path, lane=0, exact=False):
+    p = subprocess.run([exe, path, str(lane)] + (["--exact"] if exact else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
     assert p.returncode == 0, p.stderr
     blocks, fast, general, bad = (int(x) for x in p.stdout.split())
     assert bad == 0
@@ -108,16 +108,17 @@ def test_streams_of_the_device_encoder_are_the_fast_kernels(harness, tmp_path, l
         assert blocks == (len(data) + 0xFF00 - 1) // 0xFF00 and general == 0
 
 
-def test_origin_pointer_resolve_of_k1b_variant_2(harness, tmp_path):
-    """K1b variant 2 (inflate.hip kJump; off by default, written when the round's GPU budget was spent) resolves near matches per
-    output byte through origin pointers.  The harness runs that algorithm step by step -- batches, window, phase A, marks, owners,
-    groups of 64 positions in lockstep -- on the token streams K1a's lane program produces and compares with zlib: the reference's
-    fixtures, a bench-like BAM, streams with runs and short periods (pointers into their own group), other compressors' streams."""
+def test_exact_readiness_rule_of_k1b(harness, tmp_path):
+    """K1b (inflate.hip kExact, the default kernel since round 5) lets a near match start once no unfinished match writes into its source
+    range: the candidates are a contiguous range of lanes found by two branch-free binary searches, tested against the pending lanes.
+    The harness runs that rule step by step -- batches, window base, phase A, dependency masks, rounds in lockstep -- on the token
+    streams K1a's lane program produces and compares with zlib: the reference's fixtures, a bench-like BAM, streams with runs and
+    short periods (self-overlapping matches), other compressors' streams, far and near matches mixed."""
     for name in ("issue225.bam", "issue_193.bam", "issue_204.bam", "mate_overlaps_1_3M_4M.bam"):
-        blocks, fast, general = _run(harness, os.path.join(GOLDEN, name), lane=9, jump=True)
+        blocks, fast, general = _run(harness, os.path.join(GOLDEN, name), lane=9, exact=True)
         assert general == 0
     bam = gen_bam(str(tmp_path / "b.bam"), "chrB:600000", coverage=30, seed=6)
-    blocks, fast, general = _run(harness, bam, lane=2, jump=True)
+    blocks, fast, general = _run(harness, bam, lane=2, exact=True)
     assert blocks > 100 and general == 0
     rng = np.random.default_rng(77)
     path = str(tmp_path / "s.bgzf")
@@ -128,7 +129,7 @@ def test_origin_pointer_resolve_of_k1b_variant_2(harness, tmp_path):
         fh.write(_bgzf_block(bytes(rng.integers(0, 4, 65000, dtype=np.uint8)), level=1))
         fh.write(_bgzf_block(b"ab" * 20 + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) * 20, level=6))     # 3000-byte period: far and near mixed
         fh.write(_bgzf_block(b""))
-    blocks, fast, general = _run(harness, path, lane=0, jump=True)
+    blocks, fast, general = _run(harness, path, lane=0, exact=True)
     assert blocks == 6 and general == 0
 
 
