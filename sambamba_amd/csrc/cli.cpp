@@ -855,11 +855,16 @@ int depth_main(int argc, char** argv) {
         // (sbx_run_interval), device -> text (sbx_stream_base_rows) -- on two contexts that alternate.  PCIe is full duplex:
         // the upload of slice k + 1 and the text of slice k - 1 travel while slice k is computed.
         if (o.mode == "base" && !o.has_regions && o.min_cov > 0 && bp.device_format_applies() && paths.size() == 1 &&
-            !getenv("SBX_NO_PIPELINE") && ((hi.compressed_bytes >= (256u << 20) && g_done_fd >= 0) || getenv("SBX_FORCE_PIPELINE"))) {
-            // (as ONE process -- the default -- the two contexts of the pipeline cost more at exit than their overlap saves: 0.86 s against
-            //  0.75 s for config 2; the one-pass form below is used then.  The pipeline keeps two contexts resident and cuts its slices
-            //  by positions, not by the planner's byte budget: when a slice does not fit (SBX_ENOMEM before any text was written) the
-            //  run falls back to the one-pass form, which goes through sbx_plan_batches)
+            !getenv("SBX_NO_PIPELINE") && (hi.compressed_bytes >= (256u << 20) || getenv("SBX_FORCE_PIPELINE"))) {
+            // Contexts: TWO in the detached child (SBX_DETACH=1: upload, kernels and text of three different slices overlap; the exit of two
+            // contexts is the child's business), ONE in the default one-process form (round 5): two contexts cost more at exit than their
+            // overlap saves (0.86 s against 0.75 s for config 2 in round 3), but slices through ONE context still pay: the upload of slice
+            // k + 1 travels while the text of slice k leaves -- the two PCIe directions -- and the buffers hold a quarter of the job, so
+            // the process has a quarter of the device memory to give back when it ends (config 2: 0.66 -> see profiles/round5).
+            // The slices are cut by positions, not by the planner's byte budget: when one does not fit (SBX_ENOMEM before any text was
+            // written) the run falls back to the one-pass form, which goes through sbx_plan_batches.
+            size_t n_ctx = g_done_fd >= 0 ? 2 : 1;
+            if (const char* e = getenv("SBX_PIPELINE_CONTEXTS")) n_ctx = atoi(e) == 2 ? 2 : 1;
             struct Slice { uint32_t ref; uint64_t beg, end, print_end; };
             std::vector<Slice> sl;
             {
@@ -897,49 +902,16 @@ int depth_main(int argc, char** argv) {
             };
             auto wait_for = [&](auto&& pred) { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return !failure.empty() || pred(); }); return failure.empty(); };
             auto mark = [&](std::vector<int>& v, size_t k) { std::lock_guard<std::mutex> g(mu); v[k] = 1; cv.notify_all(); };
-            std::thread opener([&] {       // the second context opens while the first slice is on its way
-                char e2[512] = {0};
-                const double to = now();
-                sbx_ctx* c2 = sl.size() > 1 ? sbx_open(paths.data(), (int)paths.size(), -1, e2, sizeof e2) : nullptr;
-                t_open2 = now() - to;
-                if (sl.size() > 1 && !c2) { fail(e2); return; }
-                if (c2 && (sbx_set_filter(c2, &filt) != SBX_OK ||
-                           sbx_set_params(c2, mode_id, (uint8_t)o.min_bq, o.fix_mate, o.combined, (uint32_t)o.window, (uint32_t)o.overlap,
-                                          o.thresholds.data(), (int)o.thresholds.size()) != SBX_OK)) { fail(sbx_last_error(c2)); sbx_close(c2); return; }
-                std::lock_guard<std::mutex> g(mu);
-                cx[1] = c2;
-                opened2 = true;
-                cv.notify_all();
-            });
-            std::thread uploader([&] {
-                for (size_t k = 0; k < sl.size(); ++k) {
-                    if (!wait_for([&] { return (k & 1) == 0 || opened2; })) return;
-                    if (k >= 2 && !wait_for([&] { return computed[k - 2] != 0; })) return;       // the context's compressed bytes are free again
-                    sbx_ctx* c = cx[k & 1];
-                    const double tu = now();
-                    const int rc = sbx_prefetch_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end);
-                    if (rc != SBX_OK) { fail(sbx_last_error(c), rc); return; }
-                    busy_up += now() - tu;
-                    mark(uploaded, k);
-                }
-            });
-            std::thread computer([&] {
-                for (size_t k = 0; k < sl.size(); ++k) {
-                    if (!wait_for([&] { return uploaded[k] != 0 && (k < 2 || printed[k - 2] != 0); })) return;
-                    sbx_ctx* c = cx[k & 1];
-                    const double tr = now();
-                    const int rc = sbx_run_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end);
-                    if (rc != SBX_OK) { fail(sbx_last_error(c), rc); return; }
-                    busy_run += now() - tr;
-                    mark(computed, k);
-                }
-            });
+            // (the stage threads start inside the scope of the guard that joins them: an exception while the second or third one is
+            //  being created -- thread exhaustion -- must not destroy a running std::thread)
+            std::thread opener, uploader, computer;
             // whatever leaves this scope -- an exception of any kind included -- first releases the stage threads, then joins them
             struct JoinAll {
                 std::thread &a, &b, &c;
                 decltype(fail)& stop;
+                bool regular = false;
                 ~JoinAll() {
-                    stop("pipeline aborted", SBX_EINVAL);        // (no effect after a regular end: every stage is past its last wait)
+                    if (!regular) stop("pipeline aborted", SBX_EINVAL);
                     if (a.joinable()) a.join();
                     if (b.joinable()) b.join();
                     if (c.joinable()) c.join();
@@ -949,11 +921,50 @@ int depth_main(int argc, char** argv) {
             size_t n_printed = 0;
             bool all_printed = false;
             {
-                JoinAll guard{opener, uploader, computer, fail};
+            JoinAll guard{opener, uploader, computer, fail};
+            opener = std::thread([&] {       // the second context opens while the first slice is on its way
+                char e2[512] = {0};
+                const double to = now();
+                const bool want2 = n_ctx == 2 && sl.size() > 1;
+                sbx_ctx* c2 = want2 ? sbx_open(paths.data(), (int)paths.size(), -1, e2, sizeof e2) : nullptr;
+                t_open2 = now() - to;
+                if (want2 && !c2) { fail(e2); return; }
+                if (c2 && (sbx_set_filter(c2, &filt) != SBX_OK ||
+                           sbx_set_params(c2, mode_id, (uint8_t)o.min_bq, o.fix_mate, o.combined, (uint32_t)o.window, (uint32_t)o.overlap,
+                                          o.thresholds.data(), (int)o.thresholds.size()) != SBX_OK)) { fail(sbx_last_error(c2)); sbx_close(c2); return; }
+                std::lock_guard<std::mutex> g(mu);
+                cx[1] = c2;
+                opened2 = true;
+                cv.notify_all();
+            });
+            uploader = std::thread([&] {
+                for (size_t k = 0; k < sl.size(); ++k) {
+                    if (!wait_for([&] { return k % n_ctx == 0 || opened2; })) return;
+                    if (k >= n_ctx && !wait_for([&] { return computed[k - n_ctx] != 0; })) return;       // the context's compressed bytes are free again
+                    sbx_ctx* c = cx[k % n_ctx];
+                    const double tu = now();
+                    const int rc = sbx_prefetch_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end);
+                    if (rc != SBX_OK) { fail(sbx_last_error(c), rc); return; }
+                    busy_up += now() - tu;
+                    mark(uploaded, k);
+                }
+            });
+            computer = std::thread([&] {
+                for (size_t k = 0; k < sl.size(); ++k) {
+                    // (the run of slice k replaces the counters of slice k - n_ctx in its context: that text must have left)
+                    if (!wait_for([&] { return uploaded[k] != 0 && (k < n_ctx || printed[k - n_ctx] != 0); })) return;
+                    sbx_ctx* c = cx[k % n_ctx];
+                    const double tr = now();
+                    const int rc = sbx_run_interval(c, sl[k].ref, (uint32_t)sl[k].beg, (uint32_t)sl[k].end);
+                    if (rc != SBX_OK) { fail(sbx_last_error(c), rc); return; }
+                    busy_run += now() - tr;
+                    mark(computed, k);
+                }
+            });
                 for (size_t k = 0; k < sl.size(); ++k) {
                     if (!wait_for([&] { return computed[k] != 0; })) break;
                     const double tp = now();
-                    try { bp.run_slice(cx[k & 1], sl[k].ref, sl[k].beg, sl[k].print_end); }
+                    try { bp.run_slice(cx[k % n_ctx], sl[k].ref, sl[k].beg, sl[k].print_end); }
                     catch (const Fail& f) { fail(f.msg); break; }
                     busy_print += now() - tp;
                     done_at[k] = now() - t0;
@@ -962,6 +973,7 @@ int depth_main(int argc, char** argv) {
                 }
                 std::lock_guard<std::mutex> g(mu);
                 all_printed = n_printed == sl.size() && failure.empty();
+                guard.regular = all_printed;       // (every stage is past its last wait: nothing to release)
             }
             if (!all_printed && failure_code == SBX_ENOMEM && n_printed == 0) {
                 // nothing was written yet: the one-pass form below sizes its batches from the device's free memory
@@ -973,9 +985,9 @@ int depth_main(int argc, char** argv) {
             out.flush();
             if (out.fp != stdout) fclose(out.fp);
             if (timing) {
-                fprintf(stderr, "[sbx-depth] open %.3f s, %zu slices through upload / kernels / text in %.3f s (stages busy: upload %.3f, kernels %.3f, text %.3f; "
-                                "second context opened in %.3f s), total %.3f s since main\n",
-                        t_open - t_start, sl.size(), now() - t0, busy_up, busy_run, busy_print, t_open2, now() - t_start);
+                fprintf(stderr, "[sbx-depth] open %.3f s, %zu slices through upload / kernels / text on %zu context(s) in %.3f s (stages busy: upload %.3f, "
+                                "kernels %.3f, text %.3f; second context opened in %.3f s), total %.3f s since main\n",
+                        t_open - t_start, sl.size(), n_ctx, now() - t0, busy_up, busy_run, busy_print, t_open2, now() - t_start);
                 std::string tl;
                 for (double x : done_at) { char b[32]; snprintf(b, sizeof b, " %.3f", x); tl += b; }
                 fprintf(stderr, "[sbx-depth] slices printed at%s s\n", tl.c_str());

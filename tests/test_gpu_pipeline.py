@@ -12,8 +12,11 @@ from tests.util import gen_bam, run_cli, run_oracle
 pytestmark = pytest.mark.gpu
 
 
-def run_pipelined(args, slice_positions, orderly=False):
+def run_pipelined(args, slice_positions, orderly=False, contexts=None):
+    """contexts: None = the form of the process (ONE context as one process, the default since round 5), 1 / 2 = forced"""
     env = dict(os.environ, SBX_FORCE_PIPELINE="1", SBX_SLICE_POSITIONS=str(slice_positions), SBX_STREAM_PIECE="30000")
+    if contexts:
+        env["SBX_PIPELINE_CONTEXTS"] = str(contexts)
     if orderly:
         env["SBX_ORDERLY_EXIT"] = "1"
     r = subprocess.run([cli_path()] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
@@ -35,7 +38,8 @@ def test_pipelined_base_equals_one_pass_and_oracle(bam, args, slice_positions):
     env_off = dict(os.environ, SBX_NO_PIPELINE="1")
     one_pass = subprocess.run([cli_path()] + args + [bam], stdout=subprocess.PIPE, env=env_off, check=True).stdout
     assert one_pass == want
-    assert run_pipelined(args + [bam], slice_positions) == want
+    assert run_pipelined(args + [bam], slice_positions) == want                 # one context: upload of slice k + 1 next to the text of slice k
+    assert run_pipelined(args + [bam], slice_positions, contexts=2) == want     # two contexts: the detached child's form
     assert len(want) > 100000
 
 
