@@ -204,6 +204,22 @@ struct sbx_ctx {
         std::vector<uint32_t> h_nb, h_nr, h_seen;
     } rc;
 
+    // window mode: the statistics of EVERY window of the resident run, computed by the first sbx_depth_window_stats call after the run
+    // (one pass over the records, one reduction over the positions) and handed out contig by contig
+    struct WindowCache {
+        bool valid = false;
+        uint64_t serial = 0;
+        uint32_t window = 0, S = 0;
+        std::vector<uint32_t> thr;
+        std::vector<uint64_t> base, n_win;          // per contig
+        std::vector<sbx_region_stats> st;           // [window id][S]
+        std::vector<uint32_t> cov;                  // [window id][S][n_thr]
+        DevBuf<uint64_t> d_base, d_nwin;
+        DevBuf<uint32_t> d_nb, d_nr, d_cov, d_seen, d_thr;
+        std::vector<uint32_t> h_nb, h_nr;
+    } wc;
+    uint64_t run_serial = 0;                        // counts the runs of this context (have_run = true)
+
     // result of the last sbx_parse_regions
     std::vector<sbx_region> parsed_merged, parsed_raw;
     std::vector<std::string> parsed_lines;
@@ -1291,6 +1307,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     c->stats.launches_accumulate = 1;
     if (getenv("SBX_TIMING")) fprintf(stderr, "[sbx] hipMalloc/hipFree so far: %.3f s\n", alloc_seconds());
     c->have_run = true;
+    ++c->run_serial;
 }
 
 // Several BAMs: every file has been through the pipeline on its own; the per-position results are sums over the
@@ -1359,6 +1376,7 @@ static void merge_members(sbx_ctx* c) {
 static void run_files(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
     for (sbx_ctx* m : files_of(c)) run_impl(m, sel, restricted);
     merge_members(c);
+    ++c->run_serial;
 }
 
 int sbx_run(sbx_ctx* c) {
@@ -2049,6 +2067,65 @@ int sbx_depth_region_stats_from(sbx_ctx* c, const sbx_region* raw, size_t n, con
     });
 }
 
+// Every window of every contig that has data in the resident run, in two launches (round 5; VERDICT r4: window mode spent 86 ms of a
+// whole-genome pass outside the pipeline kernels -- a chunk list of 3.1 M windows built on the host per contig call, and a pass over ALL
+// records of the batch per contig call): count_reads_windows over the records once, range_reduce over the positions once with the
+// windows generated from their id, the results kept until the next run and handed out by sbx_depth_window_stats.
+static void window_stats_all(sbx_ctx* c) {
+    sbx_ctx::WindowCache& wc = c->wc;
+    SBX_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t S = c->n_samples_eff, T = c->tile_pos, w = c->window;
+    const uint32_t n_thr = (uint32_t)c->thresholds.size();
+    if (n_thr > (uint32_t)kMaxThresholds) throw Error(SBX_EUNSUPPORTED, "more than 16 coverage thresholds");
+    const size_t n_ref = c->hdr.refs.size();
+    wc.valid = false;
+    wc.base.assign(n_ref + 1, 0);
+    wc.n_win.assign(n_ref + 1, 0);
+    uint64_t total = 0;
+    for (size_t r = 0; r < n_ref; ++r) {
+        // contigs without an active tile have all-zero windows: they get no ids
+        bool any = false;
+        for (uint32_t t = c->h_tile_base[r]; t < c->h_tile_base[r + 1] && !any; ++t) any = c->h_slot_of[t] != 0xFFFFFFFFu;
+        wc.base[r] = total;
+        wc.n_win[r] = any ? (uint64_t)std::max(0, c->hdr.refs[r].length) / w : 0;
+        total += wc.n_win[r];
+    }
+    wc.base[n_ref] = total;
+    if (total > 0x3FFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "too many windows");
+    const size_t n = (size_t)total, ncov = n * S * std::max<uint32_t>(1, n_thr);
+    wc.d_base.ensure(n_ref + 2); wc.d_nwin.ensure(n_ref + 2);
+    wc.d_nb.ensure(n * S + 1); wc.d_nr.ensure(n * S + 1); wc.d_cov.ensure(ncov + 1); wc.d_seen.ensure(n + 1); wc.d_thr.ensure(n_thr + 1);
+    SBX_HIP(hipMemcpyAsync(wc.d_base.p, wc.base.data(), (n_ref + 1) * 8, hipMemcpyHostToDevice, s));
+    SBX_HIP(hipMemcpyAsync(wc.d_nwin.p, wc.n_win.data(), (n_ref + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_thr) SBX_HIP(hipMemcpyAsync(wc.d_thr.p, c->thresholds.data(), n_thr * 4, hipMemcpyHostToDevice, s));
+    SBX_HIP(hipMemsetAsync(wc.d_nb.p, 0, (n * S + 1) * 4, s));
+    SBX_HIP(hipMemsetAsync(wc.d_nr.p, 0, (n * S + 1) * 4, s));
+    SBX_HIP(hipMemsetAsync(wc.d_cov.p, 0, (ncov + 1) * 4, s));
+    SBX_HIP(hipMemsetAsync(wc.d_seen.p, 0, (n + 1) * 4, s));
+    EventTimer t;
+    t.start(s);
+    launch_range_reduce_windows(wc.d_base.p, wc.d_nwin.p, (uint32_t)n_ref, w, (uint32_t)n, c->d_counters.p, c->span_valid ? c->d_span.p : nullptr,
+                                c->d_slot_of.p, c->d_tile_base.p, T, S, wc.d_thr.p, n_thr, wc.d_nb.p, wc.d_cov.p, wc.d_seen.p, s, c->compact_counters);
+    for (sbx_ctx* f : files_of(c)) {
+        const uint64_t nrec = (f == c && !c->members.empty()) ? c->primary_records : f->stats.n_records;
+        launch_count_reads_windows(f->U(), f->d_desc.p, nrec, f->d_rec_ref.p, w, wc.d_base.p, wc.d_nwin.p, S, c->min_bq, wc.d_nr.p, s);
+    }
+    t.stop(s);
+    wc.h_nb.resize(n * S); wc.h_nr.resize(n * S); wc.cov.assign(ncov, 0);
+    if (n) {
+        SBX_HIP(hipMemcpyAsync(wc.h_nb.data(), wc.d_nb.p, n * S * 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipMemcpyAsync(wc.h_nr.data(), wc.d_nr.p, n * S * 4, hipMemcpyDeviceToHost, s));
+        if (n_thr) SBX_HIP(hipMemcpyAsync(wc.cov.data(), wc.d_cov.p, ncov * 4, hipMemcpyDeviceToHost, s));
+    }
+    SBX_HIP(hipStreamSynchronize(s));
+    c->stats.ms_reduce = t.ms();
+    wc.st.resize(n * S);
+    for (size_t i = 0; i < n * S; ++i) { wc.st[i].n_reads = wc.h_nr[i]; wc.st[i].n_bases = wc.h_nb[i]; }
+    wc.serial = c->run_serial; wc.window = w; wc.S = S; wc.thr = c->thresholds;
+    wc.valid = true;
+}
+
 int sbx_depth_window_stats(sbx_ctx* c, uint32_t ref_id, uint64_t first_win, uint64_t n_win, sbx_region_stats* stats,
                            uint32_t* cov_counts) {
     return guarded(c, [&] {
@@ -2062,6 +2139,22 @@ int sbx_depth_window_stats(sbx_ctx* c, uint32_t ref_id, uint64_t first_win, uint
         const uint64_t len = (uint64_t)std::max(0, c->hdr.refs[ref_id].length);
         const uint64_t total_win = len / w;                       // only full windows are ever printed (depth.d:1057,1071)
         if (first_win + n_win > total_win) throw Error(SBX_EINVAL, "window range exceeds the contig");
+        static const bool all_at_once = [] { const char* e = getenv("SBX_WINDOWS_AT_ONCE"); return !e || atoi(e) != 0; }();
+        if (all_at_once && !c->fix_mate) {
+            if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
+            sbx_ctx::WindowCache& wc = c->wc;
+            const uint32_t S = c->n_samples_eff, n_thr = (uint32_t)c->thresholds.size();
+            if (!(wc.valid && wc.serial == c->run_serial && wc.window == c->window && wc.S == S && wc.thr == c->thresholds)) window_stats_all(c);
+            if (wc.n_win[ref_id] == 0) {            // a contig without data in this run: all-zero windows
+                for (size_t i = 0; i < (size_t)n_win * S; ++i) stats[i] = sbx_region_stats{0, 0};
+                if (cov_counts && n_thr) memset(cov_counts, 0, (size_t)n_win * S * n_thr * 4);
+                return;
+            }
+            const size_t id0 = (size_t)(wc.base[ref_id] + first_win);
+            memcpy(stats, wc.st.data() + id0 * S, (size_t)n_win * S * sizeof(sbx_region_stats));
+            if (cov_counts && n_thr) memcpy(cov_counts, wc.cov.data() + id0 * S * n_thr, (size_t)n_win * S * n_thr * 4);
+            return;
+        }
         std::vector<sbx_region> ranges((size_t)n_win);
         for (uint64_t k = 0; k < n_win; ++k) ranges[(size_t)k] = {ref_id, (uint32_t)((first_win + k) * w), (uint32_t)((first_win + k + 1) * w)};
         // count_reads_windows indexes windows as win_base[ref] + k with k counted from 0 on the contig

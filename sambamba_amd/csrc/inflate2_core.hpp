@@ -215,6 +215,10 @@ struct Lane {
     }
     // Once per step / loop iteration.  A step consumes at most 63 bits; behind a service the ring holds at least the five dwords from
     // the current one on, a window reads two of the four a step can reach.
+    // The prefetch is NOT bounded by the block's payload: the end of the input is tested between deflate blocks (run(): in_bits), so on a
+    // corrupt stream a lane may read on until its output position passes ISIZE -- every symbol it consumes produces at least one of at
+    // most 65536 output bytes: < 128 KiB beyond its own block.  The caller keeps that much readable behind the compressed bytes
+    // (engine.cpp kCompPad); the lane ends with kNeedsGeneral and the general kernel, which tests its input per symbol, names the error.
     SBX_HD void service() {
         if ((bitpos >> 5) + 4u >= wr_dw) {
             put_chunk(pend);

@@ -203,6 +203,12 @@ void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const ui
                          const uint32_t* d_slot_of, const uint32_t* d_tile_base, uint32_t T, uint32_t S,
                          const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases, uint32_t* d_cov_counts,
                          uint32_t* d_seen, hipStream_t stream, bool compact = false);
+// window mode, every window of the run in ONE launch and without a chunk list: window k of contig r has id d_win_base[r] + k
+// (d_win_base = running sum of d_n_win over the contigs), n_windows = their total
+void launch_range_reduce_windows(const uint64_t* d_win_base, const uint64_t* d_n_win, uint32_t n_ref, uint32_t window, uint32_t n_windows,
+                                 const uint32_t* d_counters, const uint32_t* d_span, const uint32_t* d_slot_of, const uint32_t* d_tile_base,
+                                 uint32_t T, uint32_t S, const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases,
+                                 uint32_t* d_cov_counts, uint32_t* d_seen, hipStream_t stream, bool compact);
 void launch_count_reads_windows(const uint8_t* d_U, const RecDesc* d_desc, uint64_t n_records, const int32_t* d_rec_ref,
                                 uint32_t window, const uint64_t* d_win_base, const uint64_t* d_n_win, uint32_t S,
                                 uint32_t min_bq, uint32_t* d_n_reads, hipStream_t stream);

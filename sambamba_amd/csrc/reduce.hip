@@ -38,11 +38,25 @@ __global__ __launch_bounds__(kRedThreads) void k_range_reduce(
     const RangeChunk* __restrict__ chunks, uint32_t n_chunks, const uint32_t* __restrict__ counters,
     const uint32_t* __restrict__ span, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ tile_base,
     uint32_t T, uint32_t S, const uint32_t* __restrict__ thresholds, uint32_t n_thr, uint32_t* n_bases /*[id][S]*/,
-    uint32_t* cov_counts /*[id][S][n_thr]*/, uint32_t* seen /*[id]*/, uint32_t compact) {
+    uint32_t* cov_counts /*[id][S][n_thr]*/, uint32_t* seen /*[id]*/, uint32_t compact,
+    const uint64_t* __restrict__ win_base, const uint64_t* __restrict__ n_win, uint32_t n_ref, uint32_t window) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t ci = blockIdx.x * (kRedThreads / 64) + wv;
     if (ci >= n_chunks) return;
-    RangeChunk ch = chunks[ci];
+    RangeChunk ch;
+    if (chunks) ch = chunks[ci];
+    else {
+        // window mode without a chunk list (round 5): chunk ci IS window ci of the run -- window k of contig r has id win_base[r] + k
+        // (win_base = running sum of the contigs' window counts), so the contig is the last one whose base is <= ci
+        uint32_t lo = 0, hi = n_ref;              // invariant: win_base[lo] <= ci
+        while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (win_base[m] <= ci) lo = m; else hi = m; }
+        const uint64_t k = ci - win_base[lo];
+        if (k >= n_win[lo]) return;
+        ch.ref_id = lo;
+        ch.start = (uint32_t)(k * window);
+        ch.end = ch.start + window;
+        ch.id = ci;
+    }
     const bool no_bases = (ch.id >> 30) & 1u;     // n_bases of this range is gathered per read (count_reads with min_start)
     ch.id &= 0x3FFFFFFFu;
     const uint32_t tb = tile_base[ch.ref_id];
@@ -413,7 +427,19 @@ void launch_range_reduce(const RangeChunk* d_chunks, uint32_t n_chunks, const ui
     const uint32_t per = kRedThreads / 64;
     hipLaunchKernelGGL(k_range_reduce, dim3((n_chunks + per - 1) / per), dim3(kRedThreads), 0, stream, d_chunks, n_chunks,
                        d_counters, d_span, d_slot_of, d_tile_base, T, S, d_thresholds, n_thr, d_n_bases, d_cov_counts, d_seen,
-                       compact ? 1u : 0u);
+                       compact ? 1u : 0u, (const uint64_t*)nullptr, (const uint64_t*)nullptr, 0u, 0u);
+    SBX_HIP(hipGetLastError());
+}
+
+void launch_range_reduce_windows(const uint64_t* d_win_base, const uint64_t* d_n_win, uint32_t n_ref, uint32_t window, uint32_t n_windows,
+                                 const uint32_t* d_counters, const uint32_t* d_span, const uint32_t* d_slot_of, const uint32_t* d_tile_base,
+                                 uint32_t T, uint32_t S, const uint32_t* d_thresholds, uint32_t n_thr, uint32_t* d_n_bases,
+                                 uint32_t* d_cov_counts, uint32_t* d_seen, hipStream_t stream, bool compact) {
+    if (!n_windows || !n_ref) return;
+    const uint32_t per = kRedThreads / 64;
+    hipLaunchKernelGGL(k_range_reduce, dim3((n_windows + per - 1) / per), dim3(kRedThreads), 0, stream, (const RangeChunk*)nullptr, n_windows,
+                       d_counters, d_span, d_slot_of, d_tile_base, T, S, d_thresholds, n_thr, d_n_bases, d_cov_counts, d_seen,
+                       compact ? 1u : 0u, d_win_base, d_n_win, n_ref, window);
     SBX_HIP(hipGetLastError());
 }
 

@@ -1,0 +1,45 @@
+"""bench.py's accounting helpers (CPU): counter files are joined into the line only when they carry the stamp of the kernel sources
+they were measured on; the instruction-issue roofline is plain arithmetic."""
+import os
+import sys
+
+from tests.util import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_sources_hash_is_stable_and_sensitive(tmp_path, monkeypatch):
+    h = bench.kernel_sources_hash()
+    assert len(h) == 16 and h == bench.kernel_sources_hash()
+    # another kernel source list -> another stamp
+    monkeypatch.setattr(bench, "KERNEL_SOURCES", bench.KERNEL_SOURCES[:-1])
+    assert bench.kernel_sources_hash() != h
+
+
+def test_unstamped_or_stale_counter_files_are_not_joined(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    src = tmp_path / "sambamba_amd" / "csrc"
+    src.mkdir(parents=True)
+    for f in bench.KERNEL_SOURCES:
+        (src / f).write_text("// " + f)
+    prof = tmp_path / "profiles" / "round5"
+    prof.mkdir(parents=True)
+    table, note = bench.pmc_table(2)
+    assert table == {} and "no counter pass" in note
+    stamp = bench.kernel_sources_hash()
+    body = "kernel,counter,value,launches_summed\nk_lz77_resolve_exact,FETCH_SIZE,1000,all\nk_lz77_resolve_exact,WRITE_SIZE,500,all\n"
+    (prof / "pmc_fetch_write_config2.csv").write_text("# sources deadbeefdeadbeef\n" + body)
+    table, note = bench.pmc_table(2)
+    assert table == {} and "stale" in note
+    (prof / "pmc_fetch_write_config2.csv").write_text("# sources %s (stamp)\n" % stamp + body)
+    table, note = bench.pmc_table(2)
+    assert table["lz77_resolve"]["traffic"] == (2 * 1000 + 500) * 1024            # FETCH_SIZE doubled (gfx950), KiB units
+    (src / "inflate.hip").write_text("// changed")                                 # the kernel changes: the file is stale again
+    assert bench.pmc_table(2)[0] == {}
+
+
+def test_issue_roofline_arithmetic():
+    r = bench.issue_roofline({"SQ_INSTS_VALU": 6.144e9, "SQ_INSTS_SALU": 1e9, "source": "x"}, 10.0)
+    assert r["peak"] == round(bench.N_SIMD * bench.CLOCK_GHZ / 4.0, 2)             # G wave-instructions per second
+    assert abs(r["frac"] - 1.0) < 1e-3 and r["all_wave_instructions"] == int(7.144e9)
