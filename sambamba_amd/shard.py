@@ -224,7 +224,35 @@ class TextFunnel:
             w.wait()
 
     def begin(self):
-        pass
+        """Rank 0 starts RECEIVING now, on a helper thread, while it formats and writes its own text: the pieces of rank 1, 2, ... are
+        taken off the wire in rank order into a bounded queue (rank 0 used to post its first receive only after its own
+        text was out, so the other ranks' sends sat in their `max_in_flight` window until then); end() drains the queue into the sink."""
+        if self.solo or self.rank != 0:
+            return
+        import queue
+        import threading
+        import torch
+        self._queue = queue.Queue(maxsize=4 * self.max_in_flight)
+        self._recv_error = None
+
+        def receiver():
+            try:
+                for src in range(1, self.dist.get_world_size()):
+                    while True:
+                        n = torch.zeros(1, dtype=torch.int64)
+                        self.dist.recv(n, src=src, group=self.group)
+                        n = int(n.item())
+                        if n < 0:
+                            break
+                        buf = torch.empty(n, dtype=torch.uint8)
+                        self.dist.recv(buf, src=src, group=self.group)
+                        self._queue.put(buf)
+            except Exception as e:          # (reported by end(): a lost rank must not leave rank 0 waiting for the queue)
+                self._recv_error = e
+            self._queue.put(None)
+
+        self._receiver = threading.Thread(target=receiver, name="sbx-text-funnel", daemon=True)
+        self._receiver.start()
 
     def write(self, chunk):
         import torch
@@ -246,16 +274,17 @@ class TextFunnel:
                 w.wait()
             self._posted = []
             return
-        for src in range(1, self.dist.get_world_size()):
-            while True:
-                n = torch.zeros(1, dtype=torch.int64)
-                self.dist.recv(n, src=src, group=self.group)
-                n = int(n.item())
-                if n < 0:
-                    break
-                buf = torch.empty(n, dtype=torch.uint8)
-                self.dist.recv(buf, src=src, group=self.group)
-                self.sink(buf.numpy().tobytes())
+        if getattr(self, "_receiver", None) is None:
+            self.begin()
+        while True:
+            buf = self._queue.get()
+            if buf is None:
+                break
+            self.sink(buf.numpy().tobytes())
+        self._receiver.join()
+        self._receiver = None
+        if self._recv_error is not None:
+            raise self._recv_error
 
 
 def send_text_to_rank0(chunks, dist, write, group=None):
