@@ -769,11 +769,13 @@ __global__ __launch_bounds__(kScanThreads) void k_check_scan(IndexArgs a) {
 
 // The same over SEVERAL workgroups in one launch (round 5: the single workgroup above is a serial link of 0.5 ms between the walk and the
 // describe launches of a chromosome).  Workgroup g takes blocks [4096 g, 4096 g + 4096): chain check, local scan, then it PUBLISHES its total
-// (`part[g]` = total | ready bit) and adds up the totals of the workgroups before it -- those are resident at the same time (the launcher
-// keeps the grid below what the device holds at once) and never wait for a later one, so the look-back cannot deadlock.
+// (`part[g]` = total | ready bit) and adds up the totals of the workgroups before it.  g is a TICKET taken on entry (scan_ticket), so
+// the workgroups g waits for hold earlier tickets: they are running -- a workgroup takes its ticket when it starts -- and never wait for
+// a later one; the look-back cannot deadlock however large the grid is (a whole genome has 3.1 M tiles = 757 workgroups, more than the
+// device holds at once: the later ones simply start as the earlier ones finish).
 constexpr uint32_t kScanPerWg = 4 * kScanThreads;
 constexpr unsigned long long kScanReady = 1ull << 63;
-constexpr uint32_t kScanMaxWgs = 448;            // 256 CUs x 2 workgroups of 1024 threads, with a margin
+constexpr uint32_t kScanMaxWgs = kScanPartWords - 2;      // (the last word of `part` is the ticket counter)
 
 // the workgroup's place in the scan: a ticket, not blockIdx -- whoever holds ticket g knows that tickets 0 .. g - 1 have been taken by
 // workgroups that are running (or done), whatever order the hardware started them in; the counter is the last word of `part`

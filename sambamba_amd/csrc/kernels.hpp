@@ -152,7 +152,7 @@ struct IndexArgs {
     uint32_t* flags;                // [0] lowest block with an inconsistent chain (0xFFFFFFFF: none), [1] lowest block whose
                                     // inflate failed, [2] != 0: desc_cap was too small (nothing useful was written)
 };
-constexpr uint32_t kScanPartWords = 512;
+constexpr uint32_t kScanPartWords = 4096;      // 16 M blocks / tiles per launch of the multi-workgroup scans
 void launch_index_blocks(const IndexArgs& a, hipStream_t stream);
 // parallel repair round: blocks not entered where their predecessor was left are walked again from there
 // (*d_n_changed += blocks re-walked; reads exit_[b-1] of the previous round: launch until it stays 0)
