@@ -934,14 +934,42 @@ CLOCK_GHZ = 2.4          # what the SIMDs run at under these kernels (GRBM_GUI_A
 N_SIMD = 1024
 
 
+def _code_only(text):
+    """C / C++ source without comments and with white space collapsed: what the compiler sees, near enough -- a reworded comment must
+    not make a counter file stale, a changed statement must."""
+    import re
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                      # string / character literal: copied as it is
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return re.sub(r"\s+", " ", "".join(out)).strip()
+
+
 def kernel_sources_hash():
-    """sha1 over the device sources of the hot path: the stamp of a committed counter file (`# sources <hash>` in its first line).
-    A counter file measured on other kernel code is STALE and is not joined into the line."""
+    """sha1 over the CODE (comments stripped, white space collapsed) of the device sources of the hot path: the stamp of a committed
+    counter file (`# sources <hash>` in its first line).  A counter file measured on other kernel code is STALE and is not joined
+    into the line."""
     h = hashlib.sha1()
     for f in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "sambamba_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+        with open(os.path.join(ROOT, "sambamba_amd", "csrc", f), "r", errors="replace") as fh:
+            h.update(_code_only(fh.read()).encode())
+            h.update(b"\0")
+    return "c" + h.hexdigest()[:15]
 
 
 def _stamped_csv(name):

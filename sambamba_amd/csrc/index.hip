@@ -865,8 +865,8 @@ constexpr int kDescThreads = 256;
 
 // Staging (round 5).  A lane used to follow its record through global memory field by field -- block_size, the fixed part, the CIGAR
 // operations one by one, then the tag bytes one by one up to RG:Z and the read-group table byte by byte: about twenty DEPENDENT
-// round trips of 1-2 us per batch of 64 records, which is what the kernel waited for 79 % of its wave cycles
-// (profiles/round4/pmc_sq_config2_full.csv).  Now the record offsets of the batch give every lane the start of its record AND of the
+// round trips per batch of 64 records; the kernel waits 79 % of its wave cycles (profiles/round4/pmc_sq_config2_full.csv), and the
+// hypothesis was that it waits for that chain.  (It does not: see the note at the kernels below.)  Now the record offsets of the batch give every lane the start of its record AND of the
 // next one, so the head (kStageHead bytes from the record's start) and the tail (the kStageTail bytes in front of the next record: the
 // tags of a record without a long tag list) are fetched with seven independent 16-byte loads, copied to the lane's slot in LDS, and
 // everything is parsed from there -- two round trips to global memory per batch: the offsets, the bytes.  The read-group table
@@ -1000,8 +1000,11 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     }
 }
 
-// the staged form at 4 waves per SIMD (124 VGPRs; at 5 waves -- 96 VGPRs and a dozen spills -- it is 0.2 ms slower), and round 4's
-// kernel (SBX_K2_DESCRIBE=0: the A/B partner; config 2: record_index 8.5 -> 7.5 ms with the staged form, profiles/round5)
+// the staged form at 4 waves per SIMD (124 VGPRs; at 5 waves -- 96 VGPRs and a dozen spills -- it is 0.2 ms slower), and the unstaged
+// body (SBX_K2_DESCRIBE=0).  What staging is worth, measured (profiles/round5/README.md section 2): against the unstaged body of THIS
+// build 1.07 ms of config 2's record_index -- but against round 4's kernel under the profiler 4.52 -> 4.38 ms, 3 %: the unstaged body
+// compiled into this template is slower than round 4's kernel was.  `describe` does not wait for its chain of dependent loads; it runs
+// at the rate of scattered 128-byte lines a CU sustains (the walk, with a quarter of the occupancy, runs at the same rate per line).
 __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_blocks(IndexArgs a) { describe_blocks_body<true>(a); }
 __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks_r4(IndexArgs a) { describe_blocks_body<false>(a); }
 

@@ -11,9 +11,24 @@ import bench  # noqa: E402
 
 def test_sources_hash_is_stable_and_sensitive(tmp_path, monkeypatch):
     h = bench.kernel_sources_hash()
-    assert len(h) == 16 and h == bench.kernel_sources_hash()
+    assert len(h) == 16 and h[0] == "c" and h == bench.kernel_sources_hash()
     # another kernel source list -> another stamp
     monkeypatch.setattr(bench, "KERNEL_SOURCES", bench.KERNEL_SOURCES[:-1])
+    assert bench.kernel_sources_hash() != h
+
+
+def test_a_reworded_comment_keeps_the_stamp_a_changed_statement_does_not(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    src = tmp_path / "sambamba_amd" / "csrc"
+    src.mkdir(parents=True)
+    for f in bench.KERNEL_SOURCES:
+        (src / f).write_text("// %s\nint f() { return 1; }  /* one */\nconst char* s = \"// kept\";\n" % f)
+    h = bench.kernel_sources_hash()
+    (src / "index.hip").write_text("// another wording\n\nint f()   {\n  return 1; }\nconst char* s = \"// kept\"; // trailing\n")
+    assert bench.kernel_sources_hash() == h
+    (src / "index.hip").write_text("int f() { return 2; }\nconst char* s = \"// kept\";\n")
+    assert bench.kernel_sources_hash() != h
+    (src / "index.hip").write_text("int f() { return 1; }\nconst char* s = \"// changed\";\n")
     assert bench.kernel_sources_hash() != h
 
 
@@ -22,7 +37,7 @@ def test_unstamped_or_stale_counter_files_are_not_joined(tmp_path, monkeypatch):
     src = tmp_path / "sambamba_amd" / "csrc"
     src.mkdir(parents=True)
     for f in bench.KERNEL_SOURCES:
-        (src / f).write_text("// " + f)
+        (src / f).write_text("// %s\nint marker = 1;\n" % f)
     prof = tmp_path / "profiles" / "round5"
     prof.mkdir(parents=True)
     table, note = bench.pmc_table(2)
@@ -35,7 +50,7 @@ def test_unstamped_or_stale_counter_files_are_not_joined(tmp_path, monkeypatch):
     (prof / "pmc_fetch_write_config2.csv").write_text("# sources %s (stamp)\n" % stamp + body)
     table, note = bench.pmc_table(2)
     assert table["lz77_resolve"]["traffic"] == (2 * 1000 + 500) * 1024            # FETCH_SIZE doubled (gfx950), KiB units
-    (src / "inflate.hip").write_text("// changed")                                 # the kernel changes: the file is stale again
+    (src / "inflate.hip").write_text("int marker = 2;")                            # the kernel changes: the file is stale again
     assert bench.pmc_table(2)[0] == {}
 
 

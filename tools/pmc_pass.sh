@@ -37,7 +37,7 @@ def collect(dirs):
 for name, dirs, floor in (("pmc_fetch_write_config%s.csv" % cfg, ("fetch", "write"), 1024), ("pmc_sq_config%s.csv" % cfg, ("sq1", "sq2"), 1)):
     acc = collect(dirs)
     with open("%s/%s" % (out, name), "w") as fh:
-        fh.write("# sources %s (bench.kernel_sources_hash(): the kernel code these counters were measured on)\n" % stamp)
+        fh.write("# sources %s (bench.kernel_sources_hash(): sha1 of the comment-stripped device sources these counters were measured on)\n" % stamp)
         fh.write("kernel,counter,value,launches_summed\n")
         for (k, c), v in sorted(acc.items()):
             if v >= floor:
