@@ -337,16 +337,25 @@ def parity_full_regions(d, bam, regs, got_rows, share_of_host=1):
         os.rmdir(tmpd)
     except OSError:
         pass
-    bad = []
-    if len(want) != len(regs):
-        bad.append(["row count", len(want), len(regs)])
-    else:
-        for i, ((r, a, b), (wa, wb, wn, wm)) in enumerate(zip(regs, want)):
-            if (a, b) != (wa, wb) or got_rows[i] != (wn, wm):
-                bad.append([r, a, b, list(got_rows[i]), [wn, wm]])
-                if len(bad) >= 4:
-                    break
-    return {"regions": len(regs), "ok": not bad, "mismatches": bad, "oracle_processes": n_sl, "seconds": round(time.time() - t0, 1)}
+    # (the reference prints no row for a region behind the last pileup column of its input -- PerRegionPrinter only learns of a region
+    #  when a column passes it, depth.d:661-698 -- so a slice that ends in read-less regions has fewer rows than regions: a region the
+    #  oracle is silent about must be all-zero on the device)
+    by_pos = {(wa, wb): (wn, wm) for wa, wb, wn, wm in want}
+    bad, silent = [], 0
+    known = set((x[1], x[2]) for x in regs)
+    if len(by_pos) != len(want) or any(k not in known for k in by_pos):
+        bad.append(["rows the list does not hold, or duplicates", len(want), len(regs)])
+    for i, (r, a, b) in enumerate(regs):
+        w = by_pos.get((a, b))
+        if w is None:
+            silent += 1
+            w = (0, "0")
+        if got_rows[i] != w:
+            bad.append([r, a, b, list(got_rows[i]), list(w)])
+            if len(bad) >= 4:
+                break
+    return {"regions": len(regs), "ok": not bad, "mismatches": bad, "oracle_rows": len(want), "regions_without_a_row": silent,
+            "oracle_processes": n_sl, "seconds": round(time.time() - t0, 1)}
 
 
 def cli_e2e(bam, mode_args, reads):
