@@ -968,7 +968,7 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // (Round 4's candidate -- near matches resolved per OUTPUT BYTE through origin pointers, `k_lz77_resolve_jump` -- ran on the device in
 // round 5: correct, and 37 % SLOWER than this kernel (30.6 against 22.4 ms on config 2; more instructions of every kind, not fewer:
 // profiles/round5/README.md).  It is gone; what it left is the lesson that the rounds of phase B are cheap -- see kExact below.)
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact>
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void lz77_resolve_body(
         e0 += take;
         e_next = (e0 + lane < ne) ? ent[e0 + lane] : 0u;            // next batch (wherever this one was cut)
         // ---- slide the window down when this batch might not fit -----------------------------------------
-        if (opos - base + kSpanMax > kCap) {
+        if (!(kAblate & 32u) && opos - base + kSpanMax > kCap) {
             const uint32_t nb = (opos - kHist) & ~15u, delta = nb - base, keep = opos - nb;
             for (uint32_t i = 16 * lane; i < keep; i += 1024) {
                 const u32x4 v = *(const u32x4*)(buf + delta + i);
@@ -1038,8 +1038,8 @@ __device__ __forceinline__ void lz77_resolve_body(
             constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;       // bytes a lane copies itself
             // own-lane copies in steps of 16 bytes: one step, or two when some item of the batch is 17 .. 32 bytes long (the same code
             // and registers for both steps -- what matters is that the kernel keeps its 8 waves per SIMD)
-            const uint32_t own_l = lr <= kOwn ? lr : 0u, own_f = far && len <= kOwn ? len : 0u;
-            const uint32_t steps = kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
+            const uint32_t own_l = (kAblate & 1u) ? 0u : lr <= kOwn ? lr : 0u, own_f = (kAblate & 2u) ? 0u : far && len <= kOwn ? len : 0u;
+            const uint32_t steps = (kAblate & 16u) ? 1u : kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
             for (uint32_t h = 0; h < steps; ++h) {
                 const uint32_t n_l = own_l > 16u * h ? (own_l - 16u * h < 16u ? own_l - 16u * h : 16u) : 0u;
                 const uint32_t n_f = own_f > 16u * h ? (own_f - 16u * h < 16u ? own_f - 16u * h : 16u) : 0u;
@@ -1049,8 +1049,8 @@ __device__ __forceinline__ void lz77_resolve_body(
                 rl.store(buf + (eo - base) + 16u * h, n_l);
                 rf.store(buf + (dst - base) + 16u * h, n_f);
             }
-            coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
-            coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
+            if (!(kAblate & (1u | 64u))) coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
+            if (!(kAblate & (2u | 64u))) coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
         }
         // ---- phase B: near matches, LDS -> LDS --------------------------------------------------------------
         // A match may start once everything below its source end is final.  Matches start in entry order,
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void lz77_resolve_body(
         // waits for, the global loads of phase A are.)
         const uint32_t s_hi = src + (len < dist ? len : dist);
         const uint32_t dsto = dst - base, srco = src - base;
-        bool pending = len != 0 && !far;
+        bool pending = !(kAblate & 4u) && len != 0 && !far;
         // kExact (variant 3): the exact readiness rule.  A match may start once no UNFINISHED match writes into its source range
         // [src, s_hi).  Entries are in position order, so the matches whose destination meets that range are a contiguous range of
         // lanes [jlo, jhi] -- found once per batch by two binary searches over the lanes' {start, end} of the match (window offsets,
@@ -1169,7 +1169,7 @@ __device__ __forceinline__ void lz77_resolve_body(
         {
             const uint8_t* sp = buf + (opos - base);
             uint8_t* dp = o + opos;
-            for (uint32_t i = 16 * lane; i < span; i += 1024) {
+            for (uint32_t i = 16 * lane; !(kAblate & 8u) && i < span; i += 1024) {
                 if (i + 16 <= span) {
                     u32x4 v;
                     v.x = ldu32(sp + i); v.y = ldu32(sp + i + 4); v.z = ldu32(sp + i + 8); v.w = ldu32(sp + i + 12);
