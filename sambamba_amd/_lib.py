@@ -403,6 +403,16 @@ class Depth:
             return None
         return int(b.value), int(e.value)
 
+    def active_end(self, ref_id):
+        """End of the last stretch of tiles of ref_id that hold admitted reads after the last run, or 0: beyond the contig's length
+        when alignments hang over its end (the engine lays out as many spare tiles as they need)."""
+        end, at = 0, 0
+        while True:
+            r = self.next_active_range(ref_id, at)
+            if r is None:
+                return end
+            end = at = r[1]
+
     def covered(self, ref_id, beg, end):
         """One byte per position of [beg, end): non-zero iff a pileup column exists there (available after every kind of run)."""
         cov = np.zeros(end - beg, dtype=np.uint8)

@@ -237,6 +237,9 @@ struct sbx_ctx {
     // results of the last run
     bool have_run = false;
     uint32_t tile_pos = 0, n_samples_eff = 1, n_tiles = 0, n_active = 0;
+    // spare position tiles behind the last position of every contig, for alignments hanging over its end; enlarged (and kept) when a
+    // pass meets an alignment that reaches beyond them (run_impl); spare_of_run: what the last pass was laid out with
+    uint32_t spare_tiles = 1, spare_of_run = 0;
     bool span_valid = false;
     std::vector<uint32_t> h_tile_base, h_slot_of;
     sbx_run_stats stats{};
@@ -928,8 +931,8 @@ static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool r
     for (int32_t r = 0; r < n_ref; ++r) {
         c->h_ref_len[(size_t)r] = c->hdr.refs[(size_t)r].length;
         c->h_tile_base_up[(size_t)r] = (uint32_t)nt;
-        // one spare tile per contig for alignments hanging over the contig end
-        nt += ((uint64_t)std::max(0, c->hdr.refs[(size_t)r].length) + T - 1) / T + 1;
+        // spare tiles per contig for alignments hanging over the contig end
+        nt += ((uint64_t)std::max(0, c->hdr.refs[(size_t)r].length) + T - 1) / T + c->spare_tiles;
         if (nt > 0xFFFFFFF0ull) throw Error(SBX_EUNSUPPORTED, "too many position tiles");
     }
     c->h_tile_base_up[(size_t)n_ref] = (uint32_t)nt;
@@ -1109,7 +1112,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     if (const char* e = getenv("SBX_DEEP_TILE_RECORDS")) { const long v = atol(e); if (v >= 1 && v < (long)kDeepTileRecords) deep_thr = (uint32_t)v; }
     uint32_t n_rewalked = 0;
     uint64_t n_records = 0;
-    bool entries_given = false;
+    bool entries_given = false, spare_retried = false;
     t2.start(s);
     for (int attempt = 0;; ++attempt) {
         if (attempt > 4) throw Error(SBX_EFORMAT, "BAM record chain does not converge");
@@ -1213,8 +1216,26 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
             continue;
         }
         if (R.flags[2]) { want_cap = n_records + 1024; continue; }
+        if (R.st[0].over_tiles && !c->index_mode) {
+            // an admitted alignment reaches beyond the spare tiles of its contig (the reference prints every column a read covers,
+            // pileup.d:345-397): lay the tiles out with room for it and repeat the pass -- the chain is known by now
+            if (spare_retried) throw Error(SBX_EFORMAT, "internal error: alignments beyond the enlarged spare tiles");
+            spare_retried = true;
+            const uint64_t want = (uint64_t)c->spare_tiles + R.st[0].over_tiles;
+            if (want > 0x7FFFFFFFull / T + 2) throw Error(SBX_EFORMAT, "malformed BAM record (an alignment ends beyond position 2^31)");
+            c->spare_tiles = (uint32_t)want;
+            upload_static(c, sel, restricted, T, &nt, &refs, &rg);
+            c->d_tile_lo.ensure((size_t)nt + 1);
+            c->d_tile_hi.ensure((size_t)nt + 1);
+            c->d_active.ensure((size_t)nt + 1);
+            c->d_slot_of.ensure((size_t)nt + 1);
+            entries_given = true;
+            attempt = 0;
+            continue;
+        }
         break;
     }
+    c->spare_of_run = c->spare_tiles;
     IndexStats ist{};
     for (uint32_t k = 0; k < kIndexStatSlots; ++k) {
         const IndexStats& x = R.st[k];
@@ -1410,7 +1431,16 @@ static void merge_members(sbx_ctx* c) {
 }
 
 static void run_files(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
-    for (sbx_ctx* m : files_of(c)) run_impl(m, sel, restricted);
+    const auto files = files_of(c);
+    for (sbx_ctx* m : files) run_impl(m, sel, restricted);
+    // several files share one tile grid: a file that had to enlarge its spare tiles (run_impl) makes the others follow
+    for (bool again = files.size() > 1; again;) {
+        again = false;
+        uint32_t spare = 1;
+        for (sbx_ctx* m : files) spare = std::max(spare, m->spare_tiles);
+        for (sbx_ctx* m : files)
+            if (m->spare_of_run != spare) { m->spare_tiles = spare; run_impl(m, sel, restricted); again = true; }
+    }
     merge_members(c);
     ++c->run_serial;
 }

@@ -597,9 +597,16 @@ __device__ __forceinline__ Described describe_record(const uint8_t* p, const uin
         const uint32_t tb = a.refs.tile_base[ref];
         uint32_t t0 = tb + (uint32_t)pos / a.tile_pos;
         uint32_t t1 = tb + (uint32_t)(d.end - 1) / a.tile_pos;
-        const uint32_t last_tile = a.refs.tile_base[ref + 1] - 1;      // clip alignments hanging over the contig end
-        if (t1 > last_tile) t1 = last_tile;
-        if (t0 > last_tile) { admit = false; d.kind = 0; d.end = d.pos; R.bad = true; }      // starts beyond the contig's spare tile
+        // An alignment may hang over the end of its contig -- the reference's pileup has no notion of a contig's length and makes a
+        // column of every position a read covers (pileup.d:345-397) -- so a contig has spare tiles behind its last position
+        // (RefTable::tile_base).  One that reaches beyond them is reported (IndexStats::over_tiles): the host enlarges the spare
+        // region and repeats the pass; what this pass computes for the clipped record is never used.
+        const uint32_t last_tile = a.refs.tile_base[ref + 1] - 1;
+        if (t1 > last_tile) {
+            atomicMax(&a.stats->over_tiles, t1 - last_tile);
+            t1 = last_tile;
+            if (t0 > last_tile) t0 = last_tile;
+        }
         R.t0 = t0; R.t1 = t1;
     }
     if (a.name_hash) {   // FNV-1a over the read name without its NUL (CustomBamRead, depth.d:252-258)

@@ -114,7 +114,8 @@ struct IndexStats {         // device-side accumulators of the describe pass
     unsigned long long n_records, n_admitted, n_bad, n_unknown_rg;
     // bytes K3 has to read of the admitted records: CIGAR + packed sequence, and their base qualities (read only when -q > 0)
     unsigned long long adm_seq_bytes, adm_qual_bytes;
-    unsigned int max_span, pad_;            // longest alignment (reference positions) among the admitted records
+    unsigned int max_span;                  // longest alignment (reference positions) among the admitted records
+    unsigned int over_tiles;                // position tiles an admitted alignment reaches beyond the spare tiles of its contig (slot 0 only)
 };
 
 struct IndexArgs {

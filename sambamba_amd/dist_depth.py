@@ -346,10 +346,16 @@ def run_sharded(a, dist, device, out, out_path=None):
                 if len(ivs) > 1:
                     raise Unsupported("--reduce allreduce: a rank's slice of a contig must be one interval")
                 piece = 1 << 20
-                # alignments may hang over the contig end: the reduced range includes the spare tile
-                top = L + 1024
+                # alignments may hang over the contig end: the reduced range includes the spare tiles the ranks laid out for them
+                top = L
                 if ivs:
                     d.run_interval_owned(ref, ivs[0][0], ivs[0][1])
+                    top = max(L, d.active_end(ref))
+                if dist is not None:
+                    tt = torch.tensor([top], dtype=torch.int64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    top = int(tt.item())
+                if ivs:
 
                     def emit(a0, buf):
                         if rank == 0:
@@ -379,10 +385,11 @@ def run_sharded(a, dist, device, out, out_path=None):
                 # alignments hanging over the end of the contig have columns beyond it: the owner of the contig's last position prints them
                 if end == d.ref_lengths[ref]:
                     mc = max(min_cov, 1e-9) if min_cov <= 0 else min_cov
-                    if d.measure_base_rows(ref, end, end + 1024, mc, a.max_coverage, a.annotate):
+                    top = max(end, d.active_end(ref))
+                    if top > end and d.measure_base_rows(ref, end, top, mc, a.max_coverage, a.annotate):
                         if min_cov <= 0:
                             raise Unsupported("alignments hang over the end of contig %s: not supported with --min-coverage=0 by the sharded driver" % d.ref_names[ref])
-                        sp.append((ref, end, end + 1024, mc))
+                        sp.append((ref, end, top, mc))
                 return sp
 
             zero_fill = merged is None and min_cov <= 0

@@ -102,6 +102,73 @@ def test_tile_borders_and_contig_overhang(tmp_path):
     _check(p, refs)
 
 
+def _overhang_bam(path, with_far=True):
+    rng = random.Random(3)
+    refs = [("c1", 3000), ("c2", 2000)]
+    recs = [bg.make_record(0, p, "100M", _rand_seq(rng, 100), 30, name="a%d" % p) for p in (100, 2500, 2890)]
+    if with_far:
+        # ends 5,100 positions behind the contig's last one: five tiles beyond the spare tile the engine starts with
+        recs.append(bg.make_record(0, 2950, "100M5000N50M", _rand_seq(rng, 150), [rng.choice([2, 37]) for _ in range(150)], name="long"))
+    recs.append(bg.make_record(0, 2960, "60M", _rand_seq(rng, 60), 30, name="b"))
+    if with_far:
+        recs.append(bg.make_record(0, 4100, "50M", _rand_seq(rng, 50), 30, name="beyond"))     # STARTS beyond the contig's end
+    recs.append(bg.make_record(1, 10, "50M", _rand_seq(rng, 50), 30, name="c"))
+    bg.write_bam(path, refs, recs)
+    return refs
+
+
+def test_alignments_far_beyond_the_contig_end_have_all_their_columns(tmp_path):
+    """The reference's sweep prints every column a read covers, whatever the contig's length says (pileup.d:345-397,
+    depth.d:567-591): an alignment that ends thousands of positions behind the last one makes the engine lay out more spare
+    tiles and repeat the pass -- nothing is clipped."""
+    import sambamba_amd
+    p = str(tmp_path / "over.bam")
+    refs = _overhang_bam(p)
+    for args in (["base"], ["base", "-c", "0"], ["base", "-q", "20", "-a"], ["base", "-m"], ["window", "-w", "500"],
+                 ["window", "-w", "300", "-m"], ["region", "-L", "c1:2901-9000", "-T", "1"], ["base", "-L", "c1:2000-8060"]):
+        got, want = run_cli(args + [p]), run_oracle(args + [p])
+        assert got == want, args
+    assert b"c1\t8099\t" in run_cli(["base", p]) and b"c1\t4149\t2\t" in run_cli(["base", p])
+    with sambamba_amd.Depth(p) as d:
+        d.set_params()
+        d.run()
+        assert d.active_end(0) >= 8100
+        got = d.base_counters(0, 0, 8192)
+        assert np.array_equal(got, oracle_base_counters(p, 0, 0, 8192))
+        d.run()                  # the enlarged layout is kept: same answer from a second run of the context
+        assert np.array_equal(d.base_counters(0, 0, 8192), got)
+
+
+def test_several_files_share_the_enlarged_spare_tiles(tmp_path):
+    a, b, m = str(tmp_path / "plain.bam"), str(tmp_path / "over.bam"), str(tmp_path / "merged.bam")
+    _overhang_bam(a, with_far=False)
+    _overhang_bam(b)
+    # the merged stream of both files, by hand: a's reads come first among equal positions
+    import struct
+    from tests.util import oracle_inflate_all
+
+    def records(path):
+        u = bytes(oracle_inflate_all(path))
+        l_text = struct.unpack_from("<i", u, 4)[0]
+        o = 8 + l_text
+        n_ref = struct.unpack_from("<i", u, o)[0]
+        o += 4
+        for _ in range(n_ref):
+            o += 4 + struct.unpack_from("<i", u, o)[0] + 4
+        out = []
+        while o < len(u):
+            bs = struct.unpack_from("<i", u, o)[0]
+            out.append(u[o:o + 4 + bs])
+            o += 4 + bs
+        return out
+    ra = [(struct.unpack_from("<ii", r, 4), 0, k, r) for k, r in enumerate(records(a))]
+    rb = [(struct.unpack_from("<ii", r, 4), 1, k, r) for k, r in enumerate(records(b))]
+    allr = sorted(ra + rb, key=lambda t: (t[0], t[1], t[2]))
+    bg.write_bam(m, [("c1", 3000), ("c2", 2000)], [t[3] for t in allr])
+    for args in (["base"], ["window", "-w", "500"]):
+        assert run_cli(args + [a, b]) == run_oracle(args + [m]), args
+
+
 def test_records_straddling_small_bgzf_blocks(tmp_path):
     rng = random.Random(8)
     refs = [("c1", 20000)]
