@@ -1441,6 +1441,29 @@ static void run_files(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restr
         for (sbx_ctx* m : files)
             if (m->spare_of_run != spare) { m->spare_tiles = spare; run_impl(m, sel, restricted); again = true; }
     }
+    if (c->fix_mate && files.size() > 1) {
+        // The reference pairs same-name, same-sample records of a column across files (it merges the files before the pileup,
+        // multireader.d:265-268, depth.d:338-377); the files went through the pipeline one by one and were paired within themselves.
+        // That is the same thing unless such a pair exists -- which is checked here, and refused rather than printed differently.
+        hipStream_t s = c->stream;
+        SBX_HIP(hipSetDevice(c->device));
+        for (sbx_ctx* m : files) SBX_HIP(hipStreamSynchronize(m->stream));
+        SBX_HIP(hipMemsetAsync(c->d_flag.p + 7, 0, 4, s));
+        for (size_t x = 0; x < files.size(); ++x)
+            for (size_t y = x + 1; y < files.size(); ++y) {
+                sbx_ctx *a = files[x], *b = files[y];
+                launch_cross_file_mates(a->U(), a->d_desc.p, a->d_name_hash.p, a->d_rec_ref.p, a->stats.n_records, b->U(), b->d_desc.p,
+                                        b->d_name_hash.p, b->d_rec_ref.p, b->stats.n_records, (uint32_t)b->stats.max_alignment_span,
+                                        c->d_flag.p + 7, s);
+            }
+        uint32_t hit = 0;
+        SBX_HIP(hipMemcpyAsync(&hit, c->d_flag.p + 7, 4, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+        if (hit)
+            throw Error(SBX_EUNSUPPORTED, "--fix-mate-overlaps with several BAM files: overlapping records with the same name and sample lie in "
+                                          "different files; the reference pairs them across files (depth.d:338-377 on the merged stream), the "
+                                          "device path pairs within a file -- merge the files first");
+    }
     merge_members(c);
     ++c->run_serial;
 }
@@ -2206,8 +2229,18 @@ int sbx_depth_window_stats(sbx_ctx* c, uint32_t ref_id, uint64_t first_win, uint
         const uint64_t total_win = len / w;                       // only full windows are ever printed (depth.d:1057,1071)
         if (first_win + n_win > total_win) throw Error(SBX_EINVAL, "window range exceeds the contig");
         static const bool all_at_once = [] { const char* e = getenv("SBX_WINDOWS_AT_ONCE"); return !e || atoi(e) != 0; }();
-        if (all_at_once && !c->fix_mate) {
+        // every window of the run at once -- unless there are too many of them to keep (small windows on a large genome: -w 1 on a
+        // human genome is 3 G windows): then this call computes the windows it was asked for, as every call did before round 5
+        bool at_once = all_at_once && !c->fix_mate;
+        if (at_once) {
             if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
+            static const uint64_t budget = [] { const char* e = getenv("SBX_WINDOW_CACHE_BYTES"); return e ? strtoull(e, nullptr, 10) : (1ull << 30); }();
+            uint64_t total = 0;
+            for (auto& r : c->hdr.refs) total += (uint64_t)std::max(0, r.length) / w;
+            const uint64_t per_win = (uint64_t)c->n_samples_eff * (5 + 2 * std::max<uint64_t>(1, c->thresholds.size())) * 4 + 4;
+            if (total > 0x3FFFFFF0ull || total * per_win > budget) at_once = false;
+        }
+        if (at_once) {
             sbx_ctx::WindowCache& wc = c->wc;
             const uint32_t S = c->n_samples_eff, n_thr = (uint32_t)c->thresholds.size();
             if (!(wc.valid && wc.serial == c->run_serial && wc.window == c->window && wc.S == S && wc.thr == c->thresholds)) window_stats_all(c);

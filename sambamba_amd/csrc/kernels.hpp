@@ -188,6 +188,10 @@ void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t
                        uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream);
 // second pass when some record has more than one partner: up to three partners per record in d_ext[3 i ..] (d_n_partners is
 // counted again and must be zero on entry)
+// several files with -m: does an admitted record of file A share name and sample with an overlapping admitted record of file B?  (*d_flag |= 1)
+void launch_cross_file_mates(const uint8_t* d_Ua, const RecDesc* d_desc_a, const uint64_t* d_hash_a, const int32_t* d_ref_a, uint64_t n_a,
+                             const uint8_t* d_Ub, const RecDesc* d_desc_b, const uint64_t* d_hash_b, const int32_t* d_ref_b, uint64_t n_b,
+                             uint32_t max_span_b, uint32_t* d_flag, hipStream_t stream);
 void launch_find_partners(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
                           uint32_t* d_ext, uint32_t* d_n_partners, hipStream_t stream);
 // d_ext == nullptr: every record has at most one partner (d_mate); otherwise records with two or three partners take them

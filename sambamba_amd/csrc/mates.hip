@@ -719,6 +719,57 @@ void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t
     SBX_HIP(hipGetLastError());
 }
 
+namespace {
+// Several BAMs with --fix-mate-overlaps: the reference merges the files into ONE stream before the pileup (multireader.d:265-268) and
+// pairs same-name, same-sample records of a column whatever file they came from (depth.d:338-377); the engine runs every file
+// through the pipeline on its own and pairs within a file.  The two are the same iff no admitted record of file A shares name and
+// sample with an admitted record of file B that overlaps it -- which this kernel decides: one lane per record of A, a binary search
+// for the first record of B that could overlap it (B is coordinate-sorted; its alignments are at most max_span_b long), then the
+// records of B that start inside A's span.  A hit sets *flag; the engine refuses the run (no silent divergence).
+__global__ __launch_bounds__(256) void k_cross_file_mates(const uint8_t* __restrict__ Ua, const RecDesc* __restrict__ da,
+                                                          const uint64_t* __restrict__ ha, const int32_t* __restrict__ ra, uint64_t na,
+                                                          const uint8_t* __restrict__ Ub, const RecDesc* __restrict__ db,
+                                                          const uint64_t* __restrict__ hb, const int32_t* __restrict__ rb, uint64_t nb,
+                                                          uint32_t max_span_b, uint32_t* flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= na) return;
+    const RecDesc a = da[i];
+    if (a.kind == 0) return;
+    const int32_t ref = ra[i];
+    const uint64_t h = ha[i];
+    // (ref, pos) of a coordinate-sorted file ascend, the unmapped reads (ref -1) come last
+    const int64_t want_pos = (int64_t)a.pos - (int64_t)max_span_b;
+    uint64_t lo = 0, hi = nb;
+    while (lo < hi) {
+        const uint64_t m = (lo + hi) >> 1;
+        const int32_t r = rb[m];
+        const bool before = r >= 0 && (r < ref || (r == ref && (int64_t)db[m].pos <= want_pos));
+        if (before) lo = m + 1; else hi = m;
+    }
+    for (uint64_t j = lo; j < nb; ++j) {
+        if (rb[j] != ref) break;
+        const RecDesc b = db[j];
+        if (b.pos >= a.end) break;
+        if (b.kind != 0 && hb[j] == h && b.sample == a.sample && b.end > a.pos && a.l_name == b.l_name) {
+            const uint8_t* x = Ua + a.rec_off + 36;
+            const uint8_t* y = Ub + b.rec_off + 36;
+            bool same = true;
+            for (uint32_t k = 0; k < a.l_name && same; ++k) same = x[k] == y[k];
+            if (same) { atomicOr(flag, 1u); return; }
+        }
+    }
+}
+}  // namespace
+
+void launch_cross_file_mates(const uint8_t* d_Ua, const RecDesc* d_desc_a, const uint64_t* d_hash_a, const int32_t* d_ref_a, uint64_t n_a,
+                             const uint8_t* d_Ub, const RecDesc* d_desc_b, const uint64_t* d_hash_b, const int32_t* d_ref_b, uint64_t n_b,
+                             uint32_t max_span_b, uint32_t* d_flag, hipStream_t stream) {
+    if (!n_a || !n_b) return;
+    hipLaunchKernelGGL(k_cross_file_mates, dim3((uint32_t)((n_a + 255) / 256)), dim3(256), 0, stream, d_Ua, d_desc_a, d_hash_a, d_ref_a, n_a,
+                       d_Ub, d_desc_b, d_hash_b, d_ref_b, n_b, max_span_b, d_flag);
+    SBX_HIP(hipGetLastError());
+}
+
 void launch_find_partners(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
                           uint32_t* d_ext, uint32_t* d_n_partners, hipStream_t stream) {
     if (!n_records) return;

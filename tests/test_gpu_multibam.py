@@ -184,3 +184,84 @@ def test_dictionaries_that_cannot_be_merged_are_rejected(files, tmp_path):
     bg.write_bam(swapped, [("c2", 9000), ("c1", 30000)], [bg.make_record(0, 5, "10M", "ACGTACGTAC", 30)])
     r = run_cli(["base", paths[0], swapped], check=False)
     assert r.returncode != 0 and b"NYI" in r.stderr
+
+
+# ---- -m with several files: the reference pairs across files (multireader.d:265-268 merges the streams before depth.d:338-377 sorts a
+# column's reads by name hash); the engine pairs within a file and must refuse when that is not the same thing --------------------------
+MREFS = [("c1", 6000)]
+
+
+def _pairs(seed, n, rg, prefix):
+    """n overlapping pairs: (pos, record) of both mates, same name"""
+    rng = np.random.RandomState(seed)
+    out = []
+    for k in range(n):
+        p1 = int(rng.randint(0, 5000))
+        p2 = p1 + int(rng.randint(20, 90))
+        for pos, flag in ((p1, 99), (p2, 147)):
+            seq = "".join("ACGT"[i] for i in rng.randint(0, 4, size=100))
+            qual = [int(q) for q in rng.randint(5, 41, size=100)]
+            out.append((pos, bg.make_record(0, pos, "100M", seq, qual, name="%s%d" % (prefix, k), mapq=int(rng.choice([20, 60])), flag=flag,
+                                            tags=bg.tag_z("RG", rg))))
+    return out
+
+
+def _write_sorted(path, recs, rgs):
+    recs = sorted(recs, key=lambda t: t[0])
+    bg.write_bam(path, MREFS, [r[1] for r in recs], read_groups=rgs)
+
+
+def _merged(path, per_file, rgs):
+    allr = []
+    for fi, recs in enumerate(per_file):
+        allr += [(r[0], fi, k, r[1]) for k, r in enumerate(sorted(recs, key=lambda t: t[0]))]
+    allr.sort(key=lambda t: (t[0], t[1], t[2]))
+    bg.write_bam(path, MREFS, [r[3] for r in allr], read_groups=rgs)
+
+
+M_ARGS = [["base", "-m"], ["base", "-m", "-q", "20", "-c", "0"], ["window", "-w", "400", "-m", "-T", "2"],
+          ["region", "-L", "c1:500-5500", "-m", "-T", "1", "-T", "3"]]
+
+
+@pytest.mark.parametrize("args", M_ARGS)
+def test_fix_mate_overlaps_with_pairs_inside_each_file(tmp_path, args):
+    ra, rb = _pairs(11, 150, "ga", "a"), _pairs(12, 120, "ga", "b")         # same sample in both files, names differ
+    a, b, m = str(tmp_path / "a.bam"), str(tmp_path / "b.bam"), str(tmp_path / "m.bam")
+    _write_sorted(a, ra, [("ga", "S1")])
+    _write_sorted(b, rb, [("ga", "S1")])
+    _merged(m, [ra, rb], [("ga", "S1")])
+    assert run_cli(args + [a, b]) == run_oracle(args + [m])
+
+
+@pytest.mark.parametrize("args", M_ARGS)
+def test_a_pair_split_over_two_files_is_refused_not_printed_differently(tmp_path, args):
+    ra, rb = _pairs(21, 40, "ga", "a"), _pairs(22, 40, "ga", "b")
+    split = _pairs(23, 1, "ga", "split")                                      # its first mate goes to file a, its second to file b
+    a, b, m = str(tmp_path / "a.bam"), str(tmp_path / "b.bam"), str(tmp_path / "m.bam")
+    _write_sorted(a, ra + split[:1], [("ga", "S1")])
+    _write_sorted(b, rb + split[1:], [("ga", "S1")])
+    _merged(m, [ra + split[:1], rb + split[1:]], [("ga", "S1")])
+    r = run_cli(args + [a, b], check=False)
+    assert r.returncode != 0 and b"different files" in r.stderr and r.stdout == b""
+    # without -m the same files are fine, and the oracle on the merged stream does pair the two (the outputs differ)
+    plain = [x for x in args if x != "-m"]
+    assert run_cli(plain + [a, b]) == run_oracle(plain + [m])
+    assert run_oracle(args + [m]) != run_oracle(plain + [m])
+
+
+def test_same_names_in_two_files_that_the_reference_would_not_pair(tmp_path):
+    # (1) different samples: depth.d:352 compares sample ids; (2) same sample, but the two records do not overlap
+    ra, rb = _pairs(31, 30, "ga", "a"), _pairs(32, 30, "gb", "b")
+    s1 = _pairs(33, 1, "ga", "split")[:1] + []
+    rng = np.random.RandomState(5)
+    seq = "".join("ACGT"[i] for i in rng.randint(0, 4, size=100))
+    s2 = [(s1[0][0] + 30, bg.make_record(0, s1[0][0] + 30, "100M", seq, 30, name="split0", flag=147, tags=bg.tag_z("RG", "gb")))]
+    far = [(100, bg.make_record(0, 100, "100M", seq, 30, name="far", flag=99, tags=bg.tag_z("RG", "ga")))]
+    far2 = [(900, bg.make_record(0, 900, "100M", seq, 30, name="far", flag=147, tags=bg.tag_z("RG", "ga")))]
+    a, b, m = str(tmp_path / "a.bam"), str(tmp_path / "b.bam"), str(tmp_path / "m.bam")
+    rgs = [("ga", "S1"), ("gb", "S2")]
+    _write_sorted(a, ra + s1 + far, rgs)
+    _write_sorted(b, rb + s2 + far2, rgs)
+    _merged(m, [ra + s1 + far, rb + s2 + far2], rgs)
+    for args in (["base", "-m"], ["window", "-w", "400", "-m"]):
+        assert run_cli(args + [a, b]) == run_oracle(args + [m]), args

@@ -73,3 +73,13 @@ def test_overlapping_windows_in_batches(bams, synth):
 def test_overlap_with_fix_mate_is_rejected(synth):
     r = run_cli(["window", "-w", "300", "--overlap", "100", "-m", synth], check=False)
     assert r.returncode != 0 and b"--overlap" in r.stderr
+
+
+@pytest.mark.parametrize("w", ["1", "7", "250"])
+def test_small_windows_fall_back_to_per_call_statistics_when_the_cache_would_not_fit(bams, w):
+    """the all-windows-at-once cache is bounded; beyond its budget every call computes its own windows -- same text."""
+    for which in ("A", "D"):
+        args = ["window", "-w", w, "-T", "2", bams[which]]
+        want = run_oracle(args)
+        assert run_cli(args) == want
+        assert run_cli(args, env={"SBX_WINDOW_CACHE_BYTES": "64"}) == want
