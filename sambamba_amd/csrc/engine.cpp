@@ -1401,6 +1401,7 @@ static void merge_members(sbx_ctx* c) {
     sbx_run_stats sum{};
     for (sbx_ctx* m : files) {
         SBX_HIP(hipStreamSynchronize(m->stream));
+        if (m->compact_counters) throw Error(SBX_EINVAL, "internal: a member file ran with compact counters");
         launch_merge_tiles(m->d_counters.p, m->d_active.p, m->n_active, d_slot.p, (uint32_t)per_tile, cnt.p, s);
         if (c->span_valid) launch_merge_tiles(m->d_span.p, m->d_active.p, m->n_active, d_slot.p, T, spn.p, s);
         if (region_m) {
@@ -2366,6 +2367,8 @@ static uint64_t format_measure(sbx_ctx* c, const FormatArgs& a, uint32_t* n_chun
 static void check_base_run(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, const char* who) {
     if (!c->have_run) throw Error(SBX_EINVAL, "sbx_run() has not been called");
     if (c->mode != SBX_MODE_BASE) throw Error(SBX_EINVAL, std::string(who) + " needs a `depth base` run");
+    // (the layout of d_counters belongs to the run, not to the current mode setting: a compact run holds one word per position)
+    if (c->compact_counters) throw Error(SBX_EINVAL, std::string(who) + ": the last run kept {bases, depth} per position, not the seven counters");
     if (ref_id >= c->hdr.refs.size() || beg > end) throw Error(SBX_EINVAL, "bad interval");
 }
 

@@ -881,6 +881,7 @@ constexpr int kDescThreads = 256;
 // filter that reads bases or qualities, a size that contradicts the chain) takes the old path through global memory.
 constexpr uint32_t kStageHead = 64, kStageTail = 48, kStageSlot = kStageHead + kStageTail;
 constexpr uint32_t kRgLdsIds = 256, kRgLdsMax = 16;
+static_assert(kRgLdsIds <= (uint32_t)kDescThreads, "the read-group ids are copied to LDS one byte per thread");
 
 template <bool kStage>
 __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {

@@ -242,7 +242,8 @@ def test_a_pair_split_over_two_files_is_refused_not_printed_differently(tmp_path
     _write_sorted(b, rb + split[1:], [("ga", "S1")])
     _merged(m, [ra + split[:1], rb + split[1:]], [("ga", "S1")])
     r = run_cli(args + [a, b], check=False)
-    assert r.returncode != 0 and b"different files" in r.stderr and r.stdout == b""
+    # (the header line is out before the files are opened, as in the reference: depth.d:1152)
+    assert r.returncode != 0 and b"different files" in r.stderr and r.stdout.count(b"\n") <= 1
     # without -m the same files are fine, and the oracle on the merged stream does pair the two (the outputs differ)
     plain = [x for x in args if x != "-m"]
     assert run_cli(plain + [a, b]) == run_oracle(plain + [m])
