@@ -114,6 +114,9 @@ extern (C) nothrow @nogc {
     int sbx_next_active_range(sbx_ctx*, uint ref_id, ulong from, ulong* beg, ulong* end);
     int sbx_tile_info(sbx_ctx*, uint* tile_pos, uint* n_samples);
     int sbx_preload(sbx_ctx*);
+    struct sbx_shard { uint shard; uint ref_id; uint beg; uint end; }
+    int sbx_device_count();
+    int sbx_plan_shards(const(long)* ref_lengths, int n_ref, int n_shards, uint alignment, sbx_shard* shards, size_t cap, size_t* n_out);
 }
 
 /// Thrown exactly where depth.d would throw; depth_main's catch (depth.d:1237-1244) prints it.

@@ -48,7 +48,7 @@ typedef struct sbx_ctx sbx_ctx;
 
 /* sizeof() of the named struct of this header as the library was compiled ("sbx_filter", "sbx_regex",
  * "sbx_filter_op", "sbx_region", "sbx_region_stats", "sbx_header_info", "sbx_batch", "sbx_run_stats",
- * "sbx_regex_state"); 0 for an unknown name.  Lets a foreign-language binding (d/sbx_depth.d, the ctypes
+ * "sbx_regex_state", "sbx_shard"); 0 for an unknown name.  Lets a foreign-language binding (d/sbx_depth.d, the ctypes
  * binding) verify its struct layouts against the library it loaded. */
 size_t sbx_abi_sizeof(const char* type_name);
 
@@ -336,6 +336,27 @@ int sbx_tile_info(sbx_ctx*, uint32_t* tile_pos, uint32_t* n_samples);
  * [*beg,*end) in contig coordinates (tile-aligned end), or *beg == *end == UINT64_MAX when there is
  * none.  Lets a caller walk a contig without copying the all-zero stretches. */
 int sbx_next_active_range(sbx_ctx*, uint32_t ref_id, uint64_t from, uint64_t* beg, uint64_t* end);
+
+/* ---- several devices -----------------------------------------
+ * The path shards by POSITION: the outputs of disjoint position ranges are disjoint, so one process drives N contexts -- one
+ * sbx_open(..., device = k, ...) per device, each from its own thread -- and every context runs the slices it was given
+ * (sbx_run_interval) and hands over its share of the result; there is no data-path collective (the reference's analogue of the
+ * cut is pileupChunks, BioD/bio/std/hts/bam/pileup.d:1011-1015).  `sbx-depth --gpus N` and d/sbx_depth.d (sbxDepthRunSharded)
+ * are built on these two calls. */
+int sbx_device_count(void);          /* HIP devices visible to the process; 0 when there is none (never negative) */
+typedef struct {
+    uint32_t shard;    /* 0 .. n_shards - 1, ascending in the array */
+    uint32_t ref_id;
+    uint32_t beg;      /* [beg, end) of the contig; cuts inside a contig are multiples of `align` */
+    uint32_t end;
+} sbx_shard;
+/* Equal shares of the concatenated reference for n_shards devices: whole contigs and, where a contig is cut, position
+ * intervals inside it -- so ONE long contig shards as well as a genome does.  Every position of every contig belongs to
+ * exactly one shard; a shard's intervals are in genome order; `align` (the tile size 1024, or the window size) keeps tiles /
+ * windows whole.  Host arithmetic only (no device, no context).  *n_out receives the number of intervals (also with
+ * SBX_ENOMEM, when cap is too small: n_ref + n_shards is always enough). */
+int sbx_plan_shards(const int64_t* ref_lengths, int32_t n_ref, int32_t n_shards, uint32_t align, sbx_shard* out, size_t cap,
+                    size_t* n_out);
 
 /* Keep the compressed file resident in HBM across sbx_run() calls (bench: "inputs already
  * resident in HBM when the timed region starts"). */

@@ -82,6 +82,7 @@ EXPORTS = [
     "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_region_stats_from",
     "sbx_depth_window_stats",
     "sbx_format_base_rows", "sbx_stream_base_rows", "sbx_plan_batches", "sbx_run_batch", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
+    "sbx_device_count", "sbx_plan_shards",
 ]
 
 _lib = None
@@ -141,6 +142,8 @@ def lib():
     L.sbx_tile_info.argtypes = [C.c_void_p, u32p, u32p]
     L.sbx_next_active_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, u64p, u64p]
     L.sbx_preload.argtypes = [C.c_void_p]
+    L.sbx_device_count.argtypes = []
+    L.sbx_plan_shards.argtypes = [C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sbx_run_interval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.sbx_bgzf_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
     L.sbx_write_bam.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]

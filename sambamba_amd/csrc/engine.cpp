@@ -271,6 +271,8 @@ std::vector<sbx_ctx*> files_of(sbx_ctx* c) {
 template <class F>
 int guarded(sbx_ctx* c, F&& f) {
     try {
+        // several contexts on several devices, driven from any thread: the device is a property of the context, not of the thread
+        if (c) SBX_HIP(hipSetDevice(c->device));
         f();
         return SBX_OK;
     } catch (const Error& e) {
@@ -600,6 +602,7 @@ size_t sbx_abi_sizeof(const char* name) {
     if (n == "sbx_filter") return sizeof(sbx_filter);
     if (n == "sbx_batch") return sizeof(sbx_batch);
     if (n == "sbx_run_stats") return sizeof(sbx_run_stats);
+    if (n == "sbx_shard") return sizeof(sbx_shard);
     return 0;
 }
 
@@ -641,6 +644,50 @@ int sbx_inflate_blocks(const uint8_t* comp, const uint64_t* comp_off, const uint
         set_err(err, errlen, e.what());
         return SBX_EINVAL;
     }
+}
+
+int sbx_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
+// shares of the concatenated reference (sambamba_amd/shard.py plan_position_shards states the same rule; tests/test_shard_plan_cpu.py
+// holds the two against each other)
+int sbx_plan_shards(const int64_t* ref_lengths, int32_t n_ref, int32_t n_shards, uint32_t align, sbx_shard* out, size_t cap, size_t* n_out) {
+    if (n_out) *n_out = 0;
+    if (n_ref < 0 || n_shards < 1 || align == 0 || (n_ref && !ref_lengths)) return SBX_EINVAL;
+    std::vector<uint64_t> lens((size_t)n_ref), starts((size_t)n_ref);
+    uint64_t total = 0;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        lens[(size_t)r] = ref_lengths[r] > 0 ? (uint64_t)std::min<int64_t>(ref_lengths[r], 0x7FFFFFFF) : 0;
+        starts[(size_t)r] = total;
+        total += lens[(size_t)r];
+    }
+    if (total == 0) return SBX_OK;
+    struct Cut { uint32_t ref; uint64_t pos; };
+    auto less = [](const Cut& a, const Cut& b) { return a.ref != b.ref ? a.ref < b.ref : a.pos < b.pos; };
+    std::vector<Cut> bounds((size_t)n_shards + 1);
+    bounds[0] = {0, 0};
+    for (int32_t k = 1; k < n_shards; ++k) {
+        const uint64_t g = (uint64_t)((unsigned __int128)total * (uint64_t)k / (uint64_t)n_shards);      // 0 <= g < total
+        const size_t r = (size_t)(std::upper_bound(starts.begin(), starts.end(), g) - starts.begin()) - 1;
+        bounds[(size_t)k] = {(uint32_t)r, (g - starts[r]) / align * align};
+        if (less(bounds[(size_t)k], bounds[(size_t)k - 1])) bounds[(size_t)k] = bounds[(size_t)k - 1];   // monotone (tiny contigs, more shards than tiles)
+    }
+    bounds[(size_t)n_shards] = {(uint32_t)n_ref, 0};
+    size_t n = 0;
+    for (int32_t k = 0; k < n_shards; ++k) {
+        const Cut a = bounds[(size_t)k], b = bounds[(size_t)k + 1];
+        for (uint32_t r = a.ref; r <= std::min<uint32_t>(b.ref, (uint32_t)n_ref - 1); ++r) {
+            const uint64_t beg = r == a.ref ? a.pos : 0, end = r == b.ref ? b.pos : lens[r];
+            if (end > beg) {
+                if (out && n < cap) out[n] = {(uint32_t)k, r, (uint32_t)beg, (uint32_t)end};
+                ++n;
+            }
+        }
+    }
+    if (n_out) *n_out = n;
+    return (out && n <= cap) || (!out && cap == 0) ? SBX_OK : SBX_ENOMEM;
 }
 
 sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* err, size_t errlen) {
