@@ -108,6 +108,8 @@ extern (C) nothrow @nogc {
     int sbx_depth_window_stats(sbx_ctx*, uint ref_id, ulong first_win, ulong n_win, sbx_region_stats*, uint* cov_counts);
     int sbx_format_base_rows(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
                              char* out_buf, size_t cap, size_t* out_len);
+    int sbx_format_base_rows_device(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
+                                    void* d_out, size_t cap, size_t* out_len);
     int sbx_stream_base_rows(sbx_ctx*, uint ref_id, uint beg, uint end, double min_cov, double max_cov, int annotate,
                              sbx_write_fn write, void* user);
     int sbx_last_run_stats(sbx_ctx*, sbx_run_stats*);

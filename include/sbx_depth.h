@@ -302,6 +302,11 @@ int sbx_depth_window_stats(sbx_ctx*, uint32_t ref_id, uint64_t first_win, uint64
 int sbx_format_base_rows(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov,
                          int annotate, char* out, size_t cap, size_t* out_len);
 
+/* sbx_format_base_rows with the text left in DEVICE memory: d_out is a device pointer on the context's device with room for cap
+ * bytes (null with cap 0: measure only; *out_len receives the size either way, SBX_ENOMEM when cap is too small).  For a consumer
+ * that keeps working on the device -- and for bench.py's `device_text` figure (the pass including its text, nothing over PCIe). */
+int sbx_format_base_rows_device(sbx_ctx*, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov,
+                                int annotate, void* d_out, size_t cap, size_t* out_len);
 /* The same rows handed to a writer piece by piece, in output order.  The device formats the next piece while the
  * previous one travels to pinned host memory and the writer consumes the one before; `write` returns 0 on success
  * (anything else aborts with SBX_EIO).  `data` is only valid during the call.  Replaces the per-column

@@ -82,7 +82,7 @@ EXPORTS = [
     "sbx_set_regions", "sbx_run", "sbx_depth_base_tile", "sbx_depth_region_stats", "sbx_depth_region_stats_from",
     "sbx_depth_window_stats",
     "sbx_format_base_rows", "sbx_stream_base_rows", "sbx_plan_batches", "sbx_run_batch", "sbx_last_run_stats", "sbx_tile_info", "sbx_next_active_range", "sbx_preload",
-    "sbx_device_count", "sbx_plan_shards",
+    "sbx_device_count", "sbx_plan_shards", "sbx_format_base_rows_device",
 ]
 
 _lib = None
@@ -142,6 +142,8 @@ def lib():
     L.sbx_tile_info.argtypes = [C.c_void_p, u32p, u32p]
     L.sbx_next_active_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, u64p, u64p]
     L.sbx_preload.argtypes = [C.c_void_p]
+    L.sbx_format_base_rows_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_int, C.c_void_p,
+                                              C.c_size_t, C.POINTER(C.c_size_t)]
     L.sbx_device_count.argtypes = []
     L.sbx_plan_shards.argtypes = [C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sbx_run_interval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -370,6 +372,13 @@ class Depth:
         rc = self._L.sbx_format_base_rows(self._ctx, ref_id, beg, end, float(min_cov), float(max_cov), int(annotate), None, 0, C.byref(need))
         if rc != 0 and rc != ENOMEM:
             self._check(rc)
+        return int(need.value)
+
+    def format_base_rows_to_device(self, ref_id, beg, end, device_ptr, cap, min_cov=1.0, max_cov=float("inf"), annotate=False):
+        """sbx_format_base_rows_device: the text of [beg, end) into device memory at device_ptr (cap bytes); returns its size."""
+        need = C.c_size_t(0)
+        self._check(self._L.sbx_format_base_rows_device(self._ctx, ref_id, beg, end, float(min_cov), float(max_cov), int(annotate),
+                                                        C.c_void_p(int(device_ptr)) if device_ptr else None, int(cap), C.byref(need)))
         return int(need.value)
 
     def format_base_rows(self, ref_id, beg, end, min_cov=1.0, max_cov=float("inf"), annotate=False):

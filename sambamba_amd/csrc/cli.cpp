@@ -47,6 +47,7 @@ struct Options {
     bool report_zero = false;
     std::vector<uint32_t> thresholds;
     unsigned long long window = 0, overlap = 0;
+    int gpus = 0;             // --gpus N: shard the job by position over N devices (an extension; SBX_DEVICES lists the ordinals)
 };
 
 void usage() {  // depth.d:50-99
@@ -106,7 +107,7 @@ bool parse_args(int argc, char** argv, Options* o, std::string* err) {
         {"filter", 'F', 1}, {"output-filename", 'o', 1}, {"nthreads", 't', 1}, {"min-coverage", 'c', 1},
         {"max-coverage", 'C', 1}, {"min-base-quality", 'q', 1}, {"annotate", 'a', 0}, {"combined", 0, 0},
         {"fix-mate-overlaps", 'm', 0}, {"regions", 'L', 1}, {"report-zero-coverage", 'z', 0},
-        {"cov-threshold", 'T', 1}, {"window-size", 'w', 1}, {"overlap", 0, 1}};
+        {"cov-threshold", 'T', 1}, {"window-size", 'w', 1}, {"overlap", 0, 1}, {"gpus", 0, 1}};
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
         const Spec* sp = nullptr;
@@ -141,6 +142,7 @@ bool parse_args(int argc, char** argv, Options* o, std::string* err) {
         else if (n == "cov-threshold") o->thresholds.push_back((uint32_t)strtoul(val.c_str(), nullptr, 10));
         else if (n == "window-size") o->window = strtoull(val.c_str(), nullptr, 10);
         else if (n == "overlap") o->overlap = strtoull(val.c_str(), nullptr, 10);
+        else if (n == "gpus") o->gpus = atoi(val.c_str());
     }
     if (o->mode == "window") o->has_regions = false;  // -L is not parsed in window mode (depth.d:1139)
     return true;
@@ -514,6 +516,63 @@ bool first_column(sbx_ctx* c, int r0, int r1, int* ref_out, uint64_t* pos_out) {
     return false;
 }
 
+// first / last pileup column of the resident run inside [beg, end) of contig r (a slice of a sharded job)
+bool first_column_in(sbx_ctx* c, uint32_t r, uint64_t beg, uint64_t end, uint64_t* pos_out) {
+    std::vector<uint8_t> cov;
+    uint64_t from = beg;
+    while (from < end) {
+        uint64_t b, e;
+        check(c, sbx_next_active_range(c, r, from, &b, &e));
+        if (b == ~0ULL || b >= end) return false;
+        b = std::max(b, from);
+        e = std::min(e, end);
+        for (uint64_t p = b; p < e; p += 65536) {
+            const uint64_t q = std::min(e, p + 65536);
+            cov.resize((size_t)(q - p));
+            check(c, sbx_depth_base_tile(c, r, (uint32_t)p, (uint32_t)q, nullptr, cov.data()));
+            for (uint64_t x = p; x < q; ++x)
+                if (cov[(size_t)(x - p)]) { *pos_out = x; return true; }
+        }
+        from = e;
+    }
+    return false;
+}
+bool last_column_from(sbx_ctx* c, uint32_t r, uint64_t beg, uint64_t* pos_out) {
+    std::vector<std::pair<uint64_t, uint64_t>> runs;
+    for (uint64_t from = beg;;) {
+        uint64_t b, e;
+        check(c, sbx_next_active_range(c, r, from, &b, &e));
+        if (b == ~0ULL) break;
+        runs.push_back({std::max(b, from), e});
+        from = e;
+    }
+    std::vector<uint8_t> cov;
+    for (size_t i = runs.size(); i-- > 0;) {
+        for (uint64_t q = runs[i].second; q > runs[i].first;) {
+            const uint64_t p = q > runs[i].first + 65536 ? q - 65536 : runs[i].first;
+            cov.resize((size_t)(q - p));
+            check(c, sbx_depth_base_tile(c, r, (uint32_t)p, (uint32_t)q, nullptr, cov.data()));
+            for (uint64_t x = q; x > p; --x)
+                if (cov[(size_t)(x - 1 - p)]) { *pos_out = x - 1; return true; }
+            q = p;
+        }
+    }
+    return false;
+}
+
+// What a job sharded over several devices collected for the window printer (run_sharded): the statistics of every full window,
+// of the windows behind a contig's end that alignments hanging over it finish or leave unfinished, the first column of the run
+// and the last column of every contig -- everything PerWindowPrinter's rules below are stated in.
+struct WindowData {
+    std::vector<uint64_t> base, n_full;                   // per contig: index of its window 0 in st / cov, number of full windows
+    std::vector<sbx_region_stats> st;                     // [window][S]
+    std::vector<uint32_t> cov;                            // [window][S][max(1, n_thr)]
+    std::vector<std::vector<sbx_region_stats>> extra_st;  // per contig: windows n_full ..
+    std::vector<std::vector<uint32_t>> extra_cov;
+    std::vector<char> has_cols;
+    std::vector<uint64_t> firstcol, lastcol;
+};
+
 // PerWindowPrinter (depth.d:933-1077), fed one batch of contigs at a time.  Windows k = [k*step, k*step + w),
 // step = w - overlap, live in a ring of n = ceil(w / step) slots in the reference; what it prints is, per window:
 //   * n_reads / n_bases of the window as a region -- except in the FIRST ring of the run (windows 1 .. n-1 of contig 0
@@ -539,6 +598,36 @@ struct WindowPrinter {
     std::vector<sbx_region_stats> stale_st;      // and what its n unfinished windows hold
     std::vector<uint32_t> stale_cov;
     std::vector<int> pending_empty;              // read-less contigs seen since
+    const WindowData* data = nullptr;            // a sharded job: the statistics were collected slice by slice; `c` answers for the header only
+
+    bool has_columns(int r) {
+        if (data) return data->has_cols[(size_t)r] != 0;
+        uint64_t b0 = 0, e0 = 0;
+        check(c, sbx_next_active_range(c, (uint32_t)r, 0, &b0, &e0));
+        return b0 != ~0ULL;
+    }
+    bool first_column_of_run(int r0, int r1) {
+        if (!data) return first_column(c, r0, r1, &fref, &fpos);
+        for (int r = r0; r < r1; ++r)
+            if (data->has_cols[(size_t)r]) { fref = r; fpos = data->firstcol[(size_t)r]; return true; }
+        return false;
+    }
+    void collected_stats(int r, uint64_t k0, uint64_t k1, std::vector<sbx_region_stats>& st, std::vector<uint32_t>& cov) {
+        const uint32_t s_n = S();
+        const size_t cstride = std::max<size_t>(1, o.thresholds.size());
+        const uint64_t nf = data->n_full[(size_t)r];
+        const auto& xs = data->extra_st[(size_t)r];
+        const auto& xc = data->extra_cov[(size_t)r];
+        for (uint64_t k = k0; k < k1; ++k) {
+            const sbx_region_stats* ps = nullptr;
+            const uint32_t* pc = nullptr;
+            if (k < nf) { ps = &data->st[(size_t)(data->base[(size_t)r] + k) * s_n]; pc = &data->cov[(size_t)(data->base[(size_t)r] + k) * s_n * cstride]; }
+            else if ((k - nf + 1) * s_n <= xs.size()) { ps = &xs[(size_t)(k - nf) * s_n]; pc = &xc[(size_t)(k - nf) * s_n * cstride]; }
+            if (!ps) continue;
+            std::copy(ps, ps + s_n, st.begin() + (size_t)(k - k0) * s_n);
+            std::copy(pc, pc + s_n * cstride, cov.begin() + (size_t)(k - k0) * s_n * cstride);
+        }
+    }
 
     uint32_t S() const { return o.combined ? 1u : (uint32_t)samples.size(); }
     uint64_t step() const { return (uint64_t)o.window - (uint64_t)o.overlap; }
@@ -552,6 +641,7 @@ struct WindowPrinter {
         st.assign((size_t)(k1 - k0) * s_n, sbx_region_stats{0, 0});
         cov.assign((size_t)(k1 - k0) * s_n * cstride, 0);
         if (k1 <= k0) return;
+        if (data) { collected_stats(r, k0, k1, st, cov); return; }
         const uint64_t len = (uint64_t)std::max<int64_t>(0, sbx_ref_length(c, r));
         if (o.overlap == 0 && k1 * w <= len) {      // full, disjoint windows: the engine's own window statistics
             check(c, sbx_depth_window_stats(c, (uint32_t)r, k0, k1 - k0, st.data(), cov.data()));
@@ -597,6 +687,7 @@ struct WindowPrinter {
     }
     // position of the last pileup column of contig r (it has one)
     uint64_t last_column(int r) {
+        if (data) return data->lastcol[(size_t)r];
         uint64_t from = 0, lb = 0, le = 0;
         for (;;) {
             uint64_t b, e;
@@ -645,13 +736,11 @@ struct WindowPrinter {
     void run_refs(int r0, int r1) {
         if (o.overlap > 0 && o.fix_mate) throw Fail{"--fix-mate-overlaps with --overlap > 0 is not supported on the device path"};
         if (!have_first) {
-            if (!first_column(c, r0, r1, &fref, &fpos)) return;   // no column yet: windows so far print nothing
+            if (!first_column_of_run(r0, r1)) return;   // no column yet: windows so far print nothing
             have_first = true;
         }
         for (int r = std::max(r0, fref); r < r1; ++r) {
-            uint64_t b0 = 0, e0 = 0;
-            check(c, sbx_next_active_range(c, (uint32_t)r, 0, &b0, &e0));
-            if (b0 == ~0ULL) { pending_empty.push_back(r); continue; }
+            if (!has_columns(r)) { pending_empty.push_back(r); continue; }
             for (int e : pending_empty) zero_windows(e);      // read-less contigs between two with columns: push() resets first
             pending_empty.clear();
             contig(r);
@@ -689,19 +778,30 @@ struct RegionPrinter {
     std::vector<uint32_t> cov;
     std::vector<uint8_t> seen;
 
-    void run_refs(int r0, int r1) {
+    void prepare() {
         const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
         const size_t n_thr = std::max<size_t>(1, o.thresholds.size());
         if (st.empty()) { st.assign(raw.size() * S, sbx_region_stats{0, 0}); cov.assign(raw.size() * S * n_thr, 0); seen.assign(raw.size(), 0); }
+    }
+    void run_refs(int r0, int r1) {
+        prepare();
         std::vector<size_t> ids;
-        std::vector<sbx_region> sub;
         for (size_t i = 0; i < raw.size(); ++i)
-            if ((int)raw[i].ref_id >= r0 && (int)raw[i].ref_id < r1) { ids.push_back(i); sub.push_back(raw[i]); }
+            if ((int)raw[i].ref_id >= r0 && (int)raw[i].ref_id < r1) ids.push_back(i);
+        collect(c, ids);
+    }
+    // statistics of the raw regions `ids` from the run resident in context cx (a sharded job: the device that owns them; the rows
+    // of different devices are disjoint, prepare() has been called before the threads started)
+    void collect(sbx_ctx* cx, const std::vector<size_t>& ids) {
+        const uint32_t S = o.combined ? 1u : (uint32_t)samples.size();
+        const size_t n_thr = std::max<size_t>(1, o.thresholds.size());
+        std::vector<sbx_region> sub;
+        for (size_t i : ids) sub.push_back(raw[i]);
         if (sub.empty()) return;
         std::vector<sbx_region_stats> st2(sub.size() * S);
         std::vector<uint32_t> cov2(sub.size() * S * n_thr);
         std::vector<uint8_t> seen2(sub.size());
-        check(c, sbx_depth_region_stats(c, sub.data(), sub.size(), st2.data(), cov2.data(), seen2.data()));
+        check(cx, sbx_depth_region_stats(cx, sub.data(), sub.size(), st2.data(), cov2.data(), seen2.data()));
         const size_t nt = o.thresholds.size();
         for (size_t j = 0; j < ids.size(); ++j) {
             seen[ids[j]] = seen2[j];
@@ -724,6 +824,344 @@ struct RegionPrinter {
             for (uint32_t s2 = 0; s2 < S; ++s2)
                 print_region_row(out, o, l, raw[id].end - raw[id].start, st[id * S + s2], &cov[(id * S + s2) * n_thr], samples[s2]);
         }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Several devices (`--gpus N`, SBX_DEVICES=0,1,...): ONE process, one context per device, each driven by its own thread.
+// The job shards by POSITION (sbx_plan_shards): outputs of disjoint position ranges are disjoint, so nothing travels between
+// the devices -- every context runs its slices (sbx_run_interval: only the BGZF blocks the BAI lists for them are uploaded
+// and inflated) and hands over its share:
+//   base    the text of its positions, formatted on the device and streamed piece by piece (sbx_stream_base_rows) -- with -o into its
+//           own byte range of the file (pwrite at the offset the measured sizes of the slices before it add up to; the devices
+//           write side by side), without -o in genome order through the one output stream, slices dealt round-robin so that
+//           device k + 1 computes while device k prints;
+//   region  the statistics of the BED regions whose first position it owns (a region is never split);
+//   window  the statistics of the windows of its slices (cuts are multiples of the window size), the first / last columns,
+//           and behind a contig's end the windows that alignments hanging over it finish or leave unfinished
+// -- and the printers above print from what was collected, with the reference's rules.  Option sets whose output depends on
+// the order of the whole stream (`window --overlap`, `base -L`, `base -c 0`, host formatting) run on one device, as before.
+// The torch.distributed driver (python -m sambamba_amd.dist_depth) keeps the RCCL all-reduce form of the north star.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kBaiEnd = 1u << 29;       // the coordinate limit of the BAI's binning scheme
+struct Sharded {
+    const Options& o;
+    Out& out;
+    const std::vector<const char*>& paths;
+    const sbx_filter& filt;
+    int mode_id;
+    std::vector<int> devices;
+    sbx_ctx* ctx0;                               // the context opened by depth_main (on devices[0])
+    const std::vector<std::string>& samples;
+    std::vector<sbx_region> merged;              // -L (region mode)
+    std::vector<sbx_ctx*> cx;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::string failure;
+    std::vector<double> busy_run, busy_out;
+
+    static double now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+    void fail(const std::string& m) {
+        std::lock_guard<std::mutex> g(mu);
+        if (failure.empty()) failure = m.empty() ? std::string("a device of the sharded run failed") : m;
+        cv.notify_all();
+    }
+    template <class P> bool wait_for(P&& pred) {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return !failure.empty() || pred(); });
+        return failure.empty();
+    }
+    // context of device k: depth_main's for k == 0, opened here (on the worker's thread, next to the others) otherwise
+    sbx_ctx* context(size_t k) {
+        if (k == 0) return ctx0;
+        char e[512] = {0};
+        sbx_ctx* c = sbx_open(paths.data(), (int)paths.size(), devices[k], e, sizeof e);
+        if (!c) throw Fail{e};
+        { std::lock_guard<std::mutex> g(mu); cx[k] = c; }
+        check(c, sbx_set_filter(c, &filt));
+        check(c, sbx_set_params(c, mode_id, (uint8_t)o.min_bq, o.fix_mate, o.combined, (uint32_t)o.window, (uint32_t)o.overlap,
+                                o.thresholds.data(), (int)o.thresholds.size()));
+        if (!merged.empty()) check(c, sbx_set_regions(c, merged.data(), merged.size()));
+        return c;
+    }
+    // run every worker, join them all, rethrow the first failure
+    template <class W> void run_workers(W&& work) {
+        cx.assign(devices.size(), nullptr);
+        cx[0] = ctx0;
+        busy_run.assign(devices.size(), 0);
+        busy_out.assign(devices.size(), 0);
+        std::vector<std::thread> th;
+        struct Join { std::vector<std::thread>& t; ~Join() { for (auto& x : t) if (x.joinable()) x.join(); } } join{th};
+        for (size_t k = 0; k < devices.size(); ++k)
+            th.emplace_back([&, k] {
+                try { work(k, context(k)); }
+                catch (const Fail& f) { fail(f.msg); }
+                catch (const std::exception& e) { fail(e.what()); }
+            });
+        for (auto& x : th) x.join();
+        if (!failure.empty()) throw Fail{failure};
+    }
+    std::vector<sbx_shard> plan(uint32_t align) {
+        sbx_header_info hi;
+        check(ctx0, sbx_header(ctx0, &hi));
+        std::vector<int64_t> lens((size_t)hi.n_ref);
+        for (int r = 0; r < hi.n_ref; ++r) lens[(size_t)r] = sbx_ref_length(ctx0, r);
+        size_t n = 0;
+        std::vector<sbx_shard> sh((size_t)hi.n_ref + devices.size() + 1);
+        if (sbx_plan_shards(lens.data(), hi.n_ref, (int32_t)devices.size(), align, sh.data(), sh.size(), &n) != SBX_OK) throw Fail{"internal: shard plan"};
+        sh.resize(n);
+        return sh;
+    }
+    // sbx_run_interval over [beg - slack, end (+ slack)) with the slack --fix-mate-overlaps needs in region / window mode: a read that lies
+    // past the overlap with its mate is counted differently from an unpaired one (status `past`, depth.d:717-845), so the mate must be in
+    // the run even when it ends before the slice.  The slack starts at one linear-index window and is raised to the longest alignment
+    // the run reports -- never silently too small.
+    void run_with_mate_slack(sbx_ctx* c, uint32_t ref, uint64_t beg, uint64_t end, bool both_sides) {
+        if (!o.fix_mate) { check(c, sbx_run_interval(c, ref, (uint32_t)beg, (uint32_t)end)); return; }
+        uint64_t slack = 16384;
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            const uint64_t lo = beg > slack ? beg - slack : 0, hi = both_sides ? std::min<uint64_t>(end + slack, 0x7FFFFFFFull) : end;
+            check(c, sbx_run_interval(c, ref, (uint32_t)lo, (uint32_t)hi));
+            sbx_run_stats st;
+            check(c, sbx_last_run_stats(c, &st));
+            if (st.max_alignment_span <= slack) return;
+            slack = (st.max_alignment_span + 16383) / 16384 * 16384;
+        }
+        throw Fail{"--fix-mate-overlaps: the alignments of a slice span more than " + std::to_string(slack) + " positions; run on one device"};
+    }
+
+    // ---- base ----
+    struct Slice { uint32_t ref; uint64_t beg, end, print_end; size_t owner; };
+    // bytes of the text of a slice (the device's measuring pass; nothing is copied)
+    uint64_t measure(sbx_ctx* c, const Slice& sl) {
+        uint64_t total = 0, from = sl.beg;
+        for (;;) {
+            uint64_t b, e;
+            check(c, sbx_next_active_range(c, sl.ref, from, &b, &e));
+            if (b == ~0ULL || b >= sl.print_end) break;
+            b = std::max(b, from);
+            e = std::min(e, sl.print_end);
+            size_t need = 0;
+            const int rc = sbx_format_base_rows(c, sl.ref, (uint32_t)b, (uint32_t)e, o.min_cov, o.max_cov, o.annotate ? 1 : 0, nullptr, 0, &need);
+            if (rc != SBX_OK && rc != SBX_ENOMEM) check(c, rc);
+            total += need;
+            from = e;
+        }
+        return total;
+    }
+    struct Sink { int fd; uint64_t off; FILE* fp; };
+    static int sink_write(void* u, const char* d, size_t n) {
+        Sink* k = (Sink*)u;
+        if (k->fp) return fwrite(d, 1, n, k->fp) == n ? 0 : 1;
+        while (n) {
+            const ssize_t w = pwrite(k->fd, d, n, (off_t)k->off);
+            if (w < 0) { if (errno == EINTR) continue; return 1; }
+            d += w; n -= (size_t)w; k->off += (uint64_t)w;
+        }
+        return 0;
+    }
+    void stream(sbx_ctx* c, const Slice& sl, Sink* sink) {
+        uint64_t from = sl.beg;
+        for (;;) {
+            uint64_t b, e;
+            check(c, sbx_next_active_range(c, sl.ref, from, &b, &e));
+            if (b == ~0ULL || b >= sl.print_end) break;
+            b = std::max(b, from);
+            e = std::min(e, sl.print_end);
+            check(c, sbx_stream_base_rows(c, sl.ref, (uint32_t)b, (uint32_t)e, o.min_cov, o.max_cov, o.annotate ? 1 : 0, sink_write, sink));
+            from = e;
+        }
+    }
+    void base() {
+        const size_t N = devices.size();
+        const bool to_file = out.fp != stdout;
+        sbx_header_info hi;
+        check(ctx0, sbx_header(ctx0, &hi));
+        uint64_t total = 0;
+        for (int r = 0; r < hi.n_ref; ++r) total += (uint64_t)std::max<int64_t>(0, sbx_ref_length(ctx0, r));
+        // slices: a device's share cut so that every slice still fills a device once (the lane-per-block Huffman kernel takes one
+        // residency however few blocks it gets) and the buffers hold a fraction of the share
+        uint64_t want = std::max<uint64_t>(total / (4 * N), 16u << 20);
+        if (const char* e = getenv("SBX_SLICE_POSITIONS")) want = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
+        want = (want + 1023) / 1024 * 1024;
+        std::vector<Slice> sl;
+        for (const sbx_shard& sh : plan(1024)) {
+            const uint64_t len = (uint64_t)sbx_ref_length(ctx0, (int)sh.ref_id);
+            const uint64_t n = ((uint64_t)(sh.end - sh.beg) + want - 1) / want, step = (((uint64_t)(sh.end - sh.beg) + n - 1) / n + 1023) / 1024 * 1024;
+            for (uint64_t b = sh.beg; b < sh.end; b += step) {
+                const uint64_t e = std::min<uint64_t>(sh.end, b + step);
+                sl.push_back({sh.ref_id, b, e, e == len ? 0xFFFFFFFFull : e, (size_t)sh.shard});     // (columns of alignments hanging over the contig end)
+            }
+        }
+        // one output stream: deal the slices round-robin, so that the devices compute next to the one that prints
+        if (!to_file) for (size_t g = 0; g < sl.size(); ++g) sl[g].owner = g % N;
+        std::vector<uint64_t> size(sl.size(), 0);
+        std::vector<char> measured(sl.size(), 0), written(sl.size(), 0);
+        out.flush();
+        fflush(out.fp);
+        const uint64_t head = to_file ? (uint64_t)ftello(out.fp) : 0;
+        const int fd = to_file ? fileno(out.fp) : -1;
+        run_workers([&](size_t k, sbx_ctx* c) {
+            for (size_t g = 0; g < sl.size(); ++g) {
+                if (sl[g].owner != k) continue;
+                double t0 = now();
+                // (the last slice of a contig also takes the reads that START behind the contig's end, up to the index's coordinate limit)
+                check(c, sbx_run_interval(c, sl[g].ref, (uint32_t)sl[g].beg, sl[g].print_end == 0xFFFFFFFFull ? kBaiEnd : (uint32_t)sl[g].end));
+                busy_run[k] += now() - t0;
+                Sink sink{fd, 0, to_file ? nullptr : out.fp};
+                if (to_file) {
+                    const uint64_t sz = measure(c, sl[g]);
+                    { std::lock_guard<std::mutex> lk(mu); size[g] = sz; measured[g] = 1; cv.notify_all(); }
+                    if (!wait_for([&] { for (size_t i = 0; i < g; ++i) if (!measured[i]) return false; return true; })) return;
+                    sink.off = head;
+                    for (size_t i = 0; i < g; ++i) sink.off += size[i];
+                    t0 = now();
+                    const uint64_t at = sink.off;
+                    stream(c, sl[g], &sink);
+                    if (sink.off - at != sz) throw Fail{"internal: measured " + std::to_string(sz) + " bytes of text, wrote " + std::to_string(sink.off - at)};
+                } else {
+                    if (!wait_for([&] { for (size_t i = 0; i < g; ++i) if (!written[i]) return false; return true; })) return;
+                    t0 = now();
+                    stream(c, sl[g], &sink);
+                    fflush(out.fp);
+                }
+                busy_out[k] += now() - t0;
+                std::lock_guard<std::mutex> lk(mu);
+                written[g] = 1;
+                cv.notify_all();
+            }
+        });
+        if (to_file) {
+            uint64_t all = head;
+            for (uint64_t x : size) all += x;
+            if (fseeko(out.fp, (off_t)all, SEEK_SET) != 0) throw Fail{"cannot seek in the output file"};
+        }
+    }
+
+    // ---- region ----
+    void region(RegionPrinter& rp) {
+        const std::vector<sbx_shard> sh = plan(1024);
+        sbx_header_info hi;
+        check(ctx0, sbx_header(ctx0, &hi));
+        // a region belongs to the device that owns its first position (regions starting at or beyond the end of their contig: the owner
+        // of the contig's last position; regions of zero-length contigs: device 0 -- the one-device CLI prints a row for them as well)
+        auto owner = [&](const sbx_region& g) -> size_t {
+            const int64_t len = sbx_ref_length(ctx0, (int)g.ref_id);
+            if (len <= 0) return 0;
+            const uint64_t p = std::min<uint64_t>(g.start, (uint64_t)len - 1);
+            for (const sbx_shard& x : sh)
+                if (x.ref_id == g.ref_id && x.beg <= p && p < x.end) return x.shard;
+            return 0;
+        };
+        std::vector<std::vector<size_t>> ids(devices.size());
+        for (size_t i = 0; i < rp.raw.size(); ++i) ids[owner(rp.raw[i])].push_back(i);
+        rp.prepare();
+        run_workers([&](size_t k, sbx_ctx* c) {
+            // reads are selected against ALL merged regions (a mate that reaches the pileup through a neighbour's region must still pair,
+            // depth.d:717-758), but fetched only for the hull of the owned regions of a contig, widened by the mate slack on each side
+            for (int r = 0; r < hi.n_ref; ++r) {
+                std::vector<size_t> mine;
+                uint64_t lo = ~0ULL, hi_ = 0;
+                for (size_t i : ids[k])
+                    if ((int)rp.raw[i].ref_id == r) { mine.push_back(i); lo = std::min<uint64_t>(lo, rp.raw[i].start); hi_ = std::max<uint64_t>(hi_, rp.raw[i].end); }
+                if (mine.empty()) continue;
+                if (hi_ <= lo) hi_ = lo + 1;
+                double t0 = now();
+                run_with_mate_slack(c, (uint32_t)r, lo, std::min<uint64_t>(hi_, 0x7FFFFFFFull), true);
+                busy_run[k] += now() - t0;
+                t0 = now();
+                rp.collect(c, mine);
+                busy_out[k] += now() - t0;
+            }
+        });
+    }
+
+    // ---- window (--overlap 0) ----
+    void window(WindowPrinter& wp, WindowData& wd) {
+        const uint64_t w = o.window;
+        const std::vector<sbx_shard> sh = plan((uint32_t)w);
+        sbx_header_info hi;
+        check(ctx0, sbx_header(ctx0, &hi));
+        const size_t n_ref = (size_t)hi.n_ref, S = wp.S(), cstride = std::max<size_t>(1, o.thresholds.size());
+        wd.base.assign(n_ref + 1, 0); wd.n_full.assign(n_ref, 0);
+        wd.extra_st.assign(n_ref, {}); wd.extra_cov.assign(n_ref, {});
+        wd.has_cols.assign(n_ref, 0); wd.firstcol.assign(n_ref, ~0ULL); wd.lastcol.assign(n_ref, 0);
+        uint64_t total = 0;
+        for (size_t r = 0; r < n_ref; ++r) {
+            wd.base[r] = total;
+            wd.n_full[r] = (uint64_t)std::max<int64_t>(0, sbx_ref_length(ctx0, (int)r)) / w;
+            total += wd.n_full[r];
+        }
+        wd.base[n_ref] = total;
+        wd.st.assign((size_t)total * S, sbx_region_stats{0, 0});
+        wd.cov.assign((size_t)total * S * cstride, 0);
+        run_workers([&](size_t k, sbx_ctx* c) {
+            WindowPrinter local{c, o, out, samples, false, 0, 0, -1, 0, {}, {}, {}};       // its window_stats() on this device's run
+            for (const sbx_shard& x : sh) {
+                if (x.shard != k) continue;
+                const uint32_t r = x.ref_id;
+                const uint64_t len = (uint64_t)sbx_ref_length(c, (int)r);
+                double t0 = now();
+                const bool last = x.end >= len;
+                run_with_mate_slack(c, r, x.beg, last ? kBaiEnd : x.end, false);
+                busy_run[k] += now() - t0;
+                t0 = now();
+                uint64_t fc = 0, lc = 0;
+                const bool any = first_column_in(c, r, x.beg, last ? 0xFFFFFFFFull : x.end, &fc);
+                if (any && last) last_column_from(c, r, x.beg, &lc);
+                const uint64_t k0 = x.beg / w, k1 = last ? len / w : x.end / w;            // only full windows are printed
+                const uint64_t CH = 1u << 18;
+                std::vector<sbx_region_stats> st;
+                std::vector<uint32_t> cv2;
+                for (uint64_t a = k0; a < k1; a += CH) {
+                    const uint64_t b = std::min(k1, a + CH);
+                    st.assign((size_t)(b - a) * S, sbx_region_stats{0, 0});
+                    cv2.assign((size_t)(b - a) * S * cstride, 0);
+                    check(c, sbx_depth_window_stats(c, r, a, b - a, st.data(), cv2.data()));
+                    std::copy(st.begin(), st.end(), wd.st.begin() + (size_t)(wd.base[r] + a) * S);
+                    // (sbx_depth_window_stats packs the thresholds n_thr wide; the printer's rows are max(1, n_thr) wide)
+                    const size_t nt = o.thresholds.size();
+                    for (size_t i = 0; i < (size_t)(b - a) * S; ++i)
+                        for (size_t t = 0; t < nt; ++t) wd.cov[((size_t)(wd.base[r] + a) * S + i) * cstride + t] = cv2[i * nt + t];
+                }
+                std::vector<sbx_region_stats> xs;
+                std::vector<uint32_t> xc;
+                if (any && last) {
+                    // behind the contig's end: the windows that alignments hanging over it finish (depth.d:1057-1071 sees columns, not
+                    // lengths), and the one the ring still holds when the contig ends
+                    const uint64_t nw = std::max<uint64_t>(len >= w ? (len - w) / w + 1 : 0, lc >= w ? (lc - w) / w + 1 : 0);
+                    const uint64_t nf = len / w;
+                    local.window_stats((int)r, nf, nw + 1, xs, xc);
+                }
+                busy_out[k] += now() - t0;
+                std::lock_guard<std::mutex> lk(mu);
+                if (any) {
+                    wd.has_cols[r] = 1;
+                    wd.firstcol[r] = std::min(wd.firstcol[r], fc);
+                    if (last) { wd.lastcol[r] = lc; wd.extra_st[r] = std::move(xs); wd.extra_cov[r] = std::move(xc); }
+                }
+            }
+        });
+        // a contig whose LAST slice holds no column but an earlier one does: its last column lies in an earlier slice, within the contig --
+        // every window that can be finished is a full one; the printer asks for the last column only to find windows behind the end
+        for (size_t r = 0; r < n_ref; ++r)
+            if (wd.has_cols[r] && wd.extra_st[r].empty()) {
+                wd.lastcol[r] = 0;
+                wd.extra_st[r].assign(S, sbx_region_stats{0, 0});
+                wd.extra_cov[r].assign(S * cstride, 0);
+            }
+    }
+    void close_others() {
+        for (size_t k = 1; k < cx.size(); ++k) if (cx[k]) sbx_close(cx[k]);
+    }
+    void report(double t_start) {
+        std::string a;
+        for (size_t k = 0; k < devices.size(); ++k) {
+            char b[96];
+            snprintf(b, sizeof b, " [device %d: run %.3f s, output %.3f s]", devices[k], busy_run[k], busy_out[k]);
+            a += b;
+        }
+        fprintf(stderr, "[sbx-depth] sharded over %zu contexts:%s, total %.3f s since main\n", devices.size(), a.c_str(), now() - t_start);
     }
 };
 
@@ -790,7 +1228,25 @@ int depth_main(int argc, char** argv) {
         const bool timing = getenv("SBX_TIMING") != nullptr;      // phase wall clock on stderr (profiles/, tools/cli_e2e.sh)
         auto now = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
         const double t_start = now();
-        ctx = sbx_open(paths.data(), (int)paths.size(), -1, ebuf, sizeof ebuf);
+        // --gpus N / SBX_DEVICES=a,b,...: the devices of a sharded job (an ordinal may repeat: several contexts on one device -- how the
+        // sharded path is tested on a one-GPU box)
+        std::vector<int> devices;
+        if (const char* e = getenv("SBX_DEVICES")) {
+            for (const char* q = e; *q;) {
+                char* end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q || v < 0) throw Fail{std::string("SBX_DEVICES: a comma-separated list of device ordinals is expected, got '") + e + "'"};
+                devices.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') throw Fail{std::string("SBX_DEVICES: a comma-separated list of device ordinals is expected, got '") + e + "'"};
+            }
+            if (o.gpus > 0 && (size_t)o.gpus < devices.size()) devices.resize((size_t)o.gpus);
+        } else if (o.gpus > 1) {
+            const int have = sbx_device_count();
+            if (o.gpus > have) throw Fail{"--gpus " + std::to_string(o.gpus) + ": " + std::to_string(have) + " HIP device(s) visible"};
+            for (int k = 0; k < o.gpus; ++k) devices.push_back(k);
+        }
+        ctx = sbx_open(paths.data(), (int)paths.size(), devices.empty() ? -1 : devices[0], ebuf, sizeof ebuf);
         if (!ctx) throw Fail{ebuf};
         const double t_open = now();
         double t_run = 0, t_print = 0;
@@ -850,6 +1306,44 @@ int depth_main(int argc, char** argv) {
         if (n_batches) check(ctx, sbx_plan_batches(ctx, budget, plan.data(), plan.size(), &n_batches));
         BasePrinter bp(ctx, o, out, samples);
         if (o.mode == "base" && o.has_regions) bp.set_bed(merged);
+        // ---- several devices: the job sharded by position, one context per device (struct Sharded) ----
+        if (devices.size() > 1) {
+            bool can = false;
+            const uint32_t S_eff = o.combined ? 1u : (uint32_t)samples.size();
+            if (o.mode == "base") can = !o.has_regions && o.min_cov > 0 && bp.device_format_applies();
+            else if (o.mode == "region") can = true;
+            else {
+                uint64_t total_win = 0;
+                for (int r = 0; r < hi.n_ref; ++r) total_win += (uint64_t)std::max<int64_t>(0, sbx_ref_length(ctx, r)) / o.window;
+                can = o.overlap == 0 && total_win * S_eff * (2 + std::max<size_t>(1, o.thresholds.size())) <= (1ull << 28);
+            }
+            if (!can) {
+                fprintf(stderr, "[sbx-depth] --gpus: the output of this option set depends on the order of the whole stream (base -L, base -c 0, "
+                                "window --overlap) or would not fit the host: running on one device\n");
+            } else {
+                Sharded sh{o, out, paths, filt, mode_id, devices, ctx, samples, o.mode == "region" ? merged : std::vector<sbx_region>{}, {}, {}, {}, {}, {}, {}};
+                if (o.mode == "base") sh.base();
+                else if (o.mode == "region") {
+                    RegionPrinter rp{ctx, o, out, samples, raw, raw_lines, {}, {}, {}};
+                    sh.region(rp);
+                    rp.finish();
+                } else {
+                    WindowData wd;
+                    WindowPrinter wp{ctx, o, out, samples, false, 0, 0, -1, 0, {}, {}, {}};
+                    sh.window(wp, wd);
+                    wp.data = &wd;
+                    wp.run_refs(0, hi.n_ref);
+                    wp.finish();
+                }
+                out.flush();
+                if (out.fp != stdout) fclose(out.fp);
+                if (timing) sh.report(t_start);
+                if (!getenv("SBX_ORDERLY_EXIT")) { fflush(nullptr); report_done(0); _exit(0); }
+                sh.close_others();
+                sbx_close(ctx);
+                return 0;
+            }
+        }
         // ---- `depth base` without -L and with -c > 0: the text is a pure function of the position, so the genome is cut into
         // slices that flow through three overlapping stages -- file -> device (sbx_prefetch_interval), the kernels
         // (sbx_run_interval), device -> text (sbx_stream_base_rows) -- on two contexts that alternate.  PCIe is full duplex:

@@ -1095,6 +1095,9 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
     if (given_runs) make_resident(c, *given_runs);
     else {
         sbx_ctx::RunsCache& rcache = c->runs_cache;
+        // (SBX_RUNS_CACHE=0: every run builds its work list, as a one-shot command does -- bench.py times config 4 both ways)
+        const char* rc_env = getenv("SBX_RUNS_CACHE");
+        if (rc_env && atoi(rc_env) == 0) { rcache.valid = false; c->sel_uploaded_valid = false; }
         const bool hit = rcache.valid && rcache.restricted == restricted && rcache.sel.size() == sel.size() &&
                          (sel.empty() || memcmp(rcache.sel.data(), sel.data(), sel.size() * sizeof(sbx_region)) == 0);
         if (!hit) {
@@ -2439,6 +2442,30 @@ int sbx_format_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end
         c->d_fmt_text.ensure((size_t)total + 64);
         launch_format_write(a, n_chunks, c->d_fmt_off.p, c->d_fmt_text.p, s);
         SBX_HIP(hipMemcpyAsync(out, c->d_fmt_text.p, (size_t)total, hipMemcpyDeviceToHost, s));
+        SBX_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// The same text left in DEVICE memory (a consumer that compresses, checksums or ships it from there; bench.py's `device_text`): d_out
+// is a device pointer of the context's device, or null to measure.
+int sbx_format_base_rows_device(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end, double min_cov, double max_cov, int annotate,
+                                void* d_out, size_t cap, size_t* out_len) {
+    return guarded(c, [&] {
+        if (!c || !out_len) throw Error(SBX_EINVAL, "null argument");
+        check_base_run(c, ref_id, beg, end, "sbx_format_base_rows_device");
+        hipStream_t s = c->stream;
+        *out_len = 0;
+        if (beg == end) return;
+        FormatArgs a = format_args(c, ref_id, min_cov, max_cov, annotate, s);
+        a.beg = beg;
+        a.end = end;
+        uint32_t n_chunks = 0;
+        const uint64_t total = format_measure(c, a, &n_chunks, s);
+        *out_len = (size_t)total;
+        if (!d_out && cap == 0) return;
+        if (total > cap || !d_out) throw Error(SBX_ENOMEM, "output buffer too small for the formatted rows");
+        if (!total) return;
+        launch_format_write(a, n_chunks, c->d_fmt_off.p, (char*)d_out, s);
         SBX_HIP(hipStreamSynchronize(s));
     });
 }

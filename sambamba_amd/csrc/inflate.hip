@@ -38,6 +38,7 @@
 // K1a: one instruction per four cycles with three to four waves per SIMD); neither is HBM-bandwidth bound and their GB/s are
 // reported for completeness (DESIGN.md sections 3 and 4).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "inflate2_core.hpp"
@@ -887,6 +888,36 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 // of several tasks in flight before the first store.  n >= 4: four dwords at offsets min(4k, n - 4) --
 // the ones past the end collapse onto the tail dword, so nothing is predicated per dword.  n < 4: one
 // dword is read (the over-read stays inside the padded buffers) and 1..3 bytes of it are written.
+// (kWide, round 6: gfx950 takes 8-byte LDS and global accesses at any byte address -- hipcc emits ds_read_b64 / ds_write_b64 for them --
+// so 8 .. 16 bytes are two 8-byte words at offsets 0 and n - 8, 4 .. 7 bytes two dwords at 0 and n - 4: no offset arithmetic per dword)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 ldu64(const uint8_t* p) { u32x2 v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void stu64(uint8_t* p, u32x2 v) { __builtin_memcpy(p, &v, 8); }
+struct Short16W {
+    uint32_t w[4];
+    __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
+        if (n >= 8) {
+            const u32x2 a = ldu64(s), b = ldu64(s + n - 8);
+            w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+        } else if (n >= 4) {
+            w[0] = ldu32(s); w[1] = ldu32(s + n - 4);
+        } else if (n) {
+            w[0] = ldu32(s);
+        }
+    }
+    __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
+        if (n >= 8) {
+            u32x2 a, b;
+            a.x = w[0]; a.y = w[1]; b.x = w[2]; b.y = w[3];
+            stu64(d, a); stu64(d + n - 8, b);
+        } else if (n >= 4) {
+            stu32(d, w[0]); stu32(d + n - 4, w[1]);
+        } else if (n) {
+            if (n & 2u) { const uint16_t h = (uint16_t)w[0]; __builtin_memcpy(d, &h, 2); }
+            if (n & 1u) d[n & 2u] = (uint8_t)(w[0] >> (8u * (n & 2u)));
+        }
+    }
+};
 struct Short16 {
     uint32_t w[4];
     __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
@@ -968,7 +999,7 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // (Round 4's candidate -- near matches resolved per OUTPUT BYTE through origin pointers, `k_lz77_resolve_jump` -- ran on the device in
 // round 5: correct, and 37 % SLOWER than this kernel (30.6 against 22.4 ms on config 2; more instructions of every kind, not fewer:
 // profiles/round5/README.md).  It is gone; what it left is the lesson that the rounds of phase B are cheap -- see kExact below.)
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0>
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0, bool kWide = false>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -1043,7 +1074,7 @@ __device__ __forceinline__ void lz77_resolve_body(
             for (uint32_t h = 0; h < steps; ++h) {
                 const uint32_t n_l = own_l > 16u * h ? (own_l - 16u * h < 16u ? own_l - 16u * h : 16u) : 0u;
                 const uint32_t n_f = own_f > 16u * h ? (own_f - 16u * h < 16u ? own_f - 16u * h : 16u) : 0u;
-                Short16 rl, rf;
+                typename std::conditional<kWide, Short16W, Short16>::type rl, rf;
                 rl.load(lit + el + 16u * h, n_l);
                 rf.load(o + src + 16u * h, n_f);
                 rl.store(buf + (eo - base) + 16u * h, n_l);
@@ -1106,7 +1137,7 @@ __device__ __forceinline__ void lz77_resolve_body(
                 const uint32_t steps = kOwn32 && __any(own_s > 16u) ? 2u : 1u;
                 for (uint32_t h = 0; h < steps; ++h) {
                     const uint32_t n_s = own_s > 16u * h ? (own_s - 16u * h < 16u ? own_s - 16u * h : 16u) : 0u;
-                    Short16 rs;
+                    typename std::conditional<kWide, Short16W, Short16>::type rs;
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
                 }
@@ -1198,7 +1229,7 @@ __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 
 }
 template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_exact(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true, true>(SBX_LZ77_PASS);
+    lz77_resolve_body<kHist, kSpanMax, true, true, 0, true>(SBX_LZ77_PASS);
 }
 
 }  // namespace

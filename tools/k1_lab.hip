@@ -10,14 +10,16 @@
 
 #include <zlib.h>
 
+#include <functional>
+
 #include "../sambamba_amd/csrc/host_io.hpp"
 
 namespace sbx {
 void require_device(int) {}
 
-template <uint32_t kAblate>
+template <uint32_t kAblate, bool kWide = false>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lab_k1b(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHistDefault, kSpanDefault, true, true, kAblate>(SBX_LZ77_PASS);
+    lz77_resolve_body<kHistDefault, kSpanDefault, true, true, kAblate, kWide>(SBX_LZ77_PASS);
 }
 
 struct Lab {
@@ -42,15 +44,17 @@ struct Lab {
         return best;
     }
     double last_mean = 0;
-    template <uint32_t kAblate>
-    void k1b(const char* what) {
+    std::function<void()> check;
+    template <uint32_t kAblate, bool kWide = false>
+    void k1b(const char* what, bool verify = false) {
         const uint32_t per = kResThreads / 64;
         dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
         const size_t lds = (size_t)per * (kHistDefault + 1024u + kSpanDefault + 16u) + 128 + (size_t)per * 256;
         const double ms = time([&] {
-            hipLaunchKernelGGL((k_lab_k1b<kAblate>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
+            hipLaunchKernelGGL((k_lab_k1b<kAblate, kWide>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
         });
-        printf("{\"kernel\": \"k1b\", \"ablate\": %u, \"what\": \"%s\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", kAblate, what, ms, last_mean);
+        printf("{\"kernel\": \"k1b\", \"ablate\": %u, \"wide\": %d, \"what\": \"%s\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", kAblate, (int)kWide, what, ms, last_mean);
+        if (verify) check();
         fflush(stdout);
     }
 };
@@ -84,16 +88,14 @@ int main(int argc, char** argv) {
         // the real path first: K1a, K1b, compared with zlib
         const double k1a = lab.time([&] { launch_k1a(lab.a, lab.stream); });
         printf("{\"kernel\": \"k1a\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", k1a, lab.last_mean);
-        const double k1b = lab.time([&] { launch_k1b(lab.a, lab.stream); });
-        printf("{\"kernel\": \"k1b_product\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", k1b, lab.last_mean);
-        {
+        lab.check = [&] {
             std::vector<uint32_t> st(nb);
             SBX_HIP(hipMemcpy(st.data(), d_st.p, nb * 4ull, hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < nb; ++i) if (st[i]) throw Error(SBX_EFORMAT, "block " + std::to_string(i) + ": " + inflate_status_string(st[i]));
-            // a sample of blocks against zlib (every 97th)
+            // a sample of blocks against zlib (every 53rd)
             std::vector<uint8_t> got(65536), want(65536);
             uint32_t checked = 0;
-            for (uint32_t i = 0; i < nb; i += 97) {
+            for (uint32_t i = 0; i < nb; i += 53) {
                 if (!t.isize[i]) continue;
                 SBX_HIP(hipMemcpy(got.data(), d_out.p + t.out_off[i], t.isize[i], hipMemcpyDeviceToHost));
                 z_stream z; memset(&z, 0, sizeof z);
@@ -107,18 +109,29 @@ int main(int argc, char** argv) {
                 ++checked;
             }
             printf("{\"check\": \"zlib\", \"blocks\": %u, \"ok\": true}\n", checked);
+            SBX_HIP(hipMemset(d_out.p, 0xA5, total));            // the next variant's bytes are its own
+        };
+        const double k1b = lab.time([&] { launch_k1b(lab.a, lab.stream); });
+        printf("{\"kernel\": \"k1b_product\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", k1b, lab.last_mean);
+        lab.check();
+        lab.k1b<0, false>("the product body", true);
+        lab.k1b<0, true>("wide own-lane copies (two 8-byte words for 8 .. 16 bytes)", true);
+        lab.k1b<0, false>("the product body, again");
+        lab.k1b<0, true>("wide own-lane copies, again");
+        if (argc > 3 && std::string(argv[3]) == "ablate") {
+            lab.k1b<1>("no literal copies (own + coop)");
+            lab.k1b<2>("no far-match copies (own + coop)");
+            lab.k1b<3>("no phase A");
+            lab.k1b<64>("no cooperative copies in phase A");
+            lab.k1b<16>("phase A: one own-lane step only");
+            lab.k1b<4>("no phase B (near matches)");
+            lab.k1b<8>("no phase C (write-out)");
+            lab.k1b<3 | 4>("no phase A, no phase B");
+            lab.k1b<3 | 4 | 8>("scan and loop only");
+            lab.k1b<3 | 8>("phase B only");
+            lab.k1b<3, true>("wide: no phase A");
+            lab.k1b<4, true>("wide: no phase B");
         }
-        lab.k1b<0>("none (the product body)");
-        lab.k1b<1>("no literal copies (own + coop)");
-        lab.k1b<2>("no far-match copies (own + coop)");
-        lab.k1b<3>("no phase A");
-        lab.k1b<64>("no cooperative copies in phase A");
-        lab.k1b<16>("phase A: one own-lane step only");
-        lab.k1b<4>("no phase B (near matches)");
-        lab.k1b<8>("no phase C (write-out)");
-        lab.k1b<3 | 4>("no phase A, no phase B");
-        lab.k1b<3 | 4 | 8>("scan and loop only");
-        lab.k1b<3 | 8>("phase B only");
         return 0;
     } catch (const std::exception& e) {
         fprintf(stderr, "k1_lab: %s\n", e.what());
