@@ -2465,7 +2465,7 @@ int sbx_format_base_rows_device(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint3
         if (!d_out && cap == 0) return;
         if (total > cap || !d_out) throw Error(SBX_ENOMEM, "output buffer too small for the formatted rows");
         if (!total) return;
-        launch_format_write(a, n_chunks, c->d_fmt_off.p, (char*)d_out, s);
+        launch_format_write(a, n_chunks, c->d_fmt_off.p, (uint8_t*)d_out, s);
         SBX_HIP(hipStreamSynchronize(s));
     });
 }

@@ -918,6 +918,36 @@ struct Short16W {
         }
     }
 };
+// up to 32 bytes in one step: 16 .. 32 bytes are two 16-byte words at offsets 0 and n - 16
+struct Short32W {
+    u32x4 lo, hi;
+    __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
+        if (n >= 16) {
+            __builtin_memcpy(&lo, s, 16); __builtin_memcpy(&hi, s + n - 16, 16);
+        } else if (n >= 8) {
+            const u32x2 a = ldu64(s), b = ldu64(s + n - 8);
+            lo.x = a.x; lo.y = a.y; lo.z = b.x; lo.w = b.y;
+        } else if (n >= 4) {
+            lo.x = ldu32(s); lo.y = ldu32(s + n - 4);
+        } else if (n) {
+            lo.x = ldu32(s);
+        }
+    }
+    __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
+        if (n >= 16) {
+            __builtin_memcpy(d, &lo, 16); __builtin_memcpy(d + n - 16, &hi, 16);
+        } else if (n >= 8) {
+            u32x2 a, b;
+            a.x = lo.x; a.y = lo.y; b.x = lo.z; b.y = lo.w;
+            stu64(d, a); stu64(d + n - 8, b);
+        } else if (n >= 4) {
+            stu32(d, lo.x); stu32(d + n - 4, lo.y);
+        } else if (n) {
+            if (n & 2u) { const uint16_t h = (uint16_t)lo.x; __builtin_memcpy(d, &h, 2); }
+            if (n & 1u) d[n & 2u] = (uint8_t)(lo.x >> (8u * (n & 2u)));
+        }
+    }
+};
 struct Short16 {
     uint32_t w[4];
     __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
@@ -944,7 +974,34 @@ struct Short16 {
 // sbase + s to buf + d.  Source and destination of a task never overlap.
 // (four tasks per turn of the loop; two or one per turn -- a batch of a BAM stream holds 1.6 long far matches and 0.2 long literal runs,
 // tools/token_stats.cpp -- execute 8 % fewer vector instructions and are not faster: profiles/round5/README.md)
+// (k64: one 8-byte word per lane and task instead of two dwords; a task is longer than 8 bytes)
+template <bool k64 = false>
 __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint32_t s, uint8_t* buf, uint32_t d, uint32_t n, uint32_t lane) {
+    if (k64) {
+        while (m) {
+            uint32_t S[4], D[4], N[4];
+            u32x2 wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                N[j] = 0; S[j] = 0; D[j] = 0;
+                if (m) {
+                    const int r = __builtin_ctzll(m);
+                    m &= m - 1;
+                    S[j] = __builtin_amdgcn_readlane(s, r);
+                    D[j] = __builtin_amdgcn_readlane(d, r);
+                    N[j] = __builtin_amdgcn_readlane(n, r);
+                }
+            }
+            const uint32_t off = 8 * lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (off < N[j]) wv[j] = ldu64(sbase + S[j] + (off + 8 <= N[j] ? off : N[j] - 8));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (off < N[j]) stu64(buf + D[j] + (off + 8 <= N[j] ? off : N[j] - 8), wv[j]);
+        }
+        return;
+    }
     while (m) {
         uint32_t S[4], D[4], N[4], wa[4], wb[4];
 #pragma unroll
@@ -999,7 +1056,10 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // (Round 4's candidate -- near matches resolved per OUTPUT BYTE through origin pointers, `k_lz77_resolve_jump` -- ran on the device in
 // round 5: correct, and 37 % SLOWER than this kernel (30.6 against 22.4 ms on config 2; more instructions of every kind, not fewer:
 // profiles/round5/README.md).  It is gone; what it left is the lesson that the rounds of phase B are cheap -- see kExact below.)
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0, bool kWide = false>
+// kOpt (round 6, each bit an A/B in tools/k1_lab): 1 = the write-out reads its 16 bytes with one LDS instruction; 2 = cooperative copies in 8-byte
+// words; 4 = own-lane copies of up to 32 bytes in ONE step (16 .. 32 bytes: two 16-byte words) instead of two steps of 16; 8 = the byte-permute
+// path reads its period with one 8-byte load
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0, bool kWide = false, uint32_t kOpt = 0>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -1070,7 +1130,14 @@ __device__ __forceinline__ void lz77_resolve_body(
             // own-lane copies in steps of 16 bytes: one step, or two when some item of the batch is 17 .. 32 bytes long (the same code
             // and registers for both steps -- what matters is that the kernel keeps its 8 waves per SIMD)
             const uint32_t own_l = (kAblate & 1u) ? 0u : lr <= kOwn ? lr : 0u, own_f = (kAblate & 2u) ? 0u : far && len <= kOwn ? len : 0u;
-            const uint32_t steps = (kAblate & 16u) ? 1u : kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
+            if (kOpt & 4u) {
+                Short32W rl, rf;
+                rl.load(lit + el, own_l);
+                rf.load(o + src, own_f);
+                rl.store(buf + (eo - base), own_l);
+                rf.store(buf + (dst - base), own_f);
+            }
+            const uint32_t steps = (kOpt & 4u) ? 0u : (kAblate & 16u) ? 1u : kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
             for (uint32_t h = 0; h < steps; ++h) {
                 const uint32_t n_l = own_l > 16u * h ? (own_l - 16u * h < 16u ? own_l - 16u * h : 16u) : 0u;
                 const uint32_t n_f = own_f > 16u * h ? (own_f - 16u * h < 16u ? own_f - 16u * h : 16u) : 0u;
@@ -1080,8 +1147,8 @@ __device__ __forceinline__ void lz77_resolve_body(
                 rl.store(buf + (eo - base) + 16u * h, n_l);
                 rf.store(buf + (dst - base) + 16u * h, n_f);
             }
-            if (!(kAblate & (1u | 64u))) coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
-            if (!(kAblate & (2u | 64u))) coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
+            if (!(kAblate & (1u | 64u))) coop_copy<(kOpt & 2u) != 0>(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
+            if (!(kAblate & (2u | 64u))) coop_copy<(kOpt & 2u) != 0>(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
         }
         // ---- phase B: near matches, LDS -> LDS --------------------------------------------------------------
         // A match may start once everything below its source end is final.  Matches start in entry order,
@@ -1134,14 +1201,19 @@ __device__ __forceinline__ void lz77_resolve_body(
             {
                 constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;
                 const uint32_t own_s = plain && len <= kOwn ? len : 0u;       // (source and destination of a plain match do not overlap)
-                const uint32_t steps = kOwn32 && __any(own_s > 16u) ? 2u : 1u;
+                if (kOpt & 4u) {
+                    Short32W rs;
+                    rs.load(buf + srco, own_s);
+                    rs.store(buf + dsto, own_s);
+                }
+                const uint32_t steps = (kOpt & 4u) ? 0u : kOwn32 && __any(own_s > 16u) ? 2u : 1u;
                 for (uint32_t h = 0; h < steps; ++h) {
                     const uint32_t n_s = own_s > 16u * h ? (own_s - 16u * h < 16u ? own_s - 16u * h : 16u) : 0u;
                     typename std::conditional<kWide, Short16W, Short16>::type rs;
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
                 }
-                coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
+                coop_copy<(kOpt & 2u) != 0>(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
             // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
@@ -1154,7 +1226,9 @@ __device__ __forceinline__ void lz77_resolve_body(
                 Short16 ws;
                 uint32_t n_p = 0;
                 if (per_perm) {
-                    const uint32_t x0 = ldu32(buf + srco), x1 = ldu32(buf + srco + 4);
+                    uint32_t x0, x1;
+                    if (kOpt & 8u) { const u32x2 xx = ldu64(buf + srco); x0 = xx.x; x1 = xx.y; }
+                    else { x0 = ldu32(buf + srco); x1 = ldu32(buf + srco + 4); }
                     const u32x4 sel = *(const u32x4*)(per_sel + 4u * (dist - 1u));
                     const uint32_t y0 = __builtin_amdgcn_perm(x1, x0, sel.x), y1 = __builtin_amdgcn_perm(x1, x0, sel.y);
                     const uint32_t y2 = __builtin_amdgcn_perm(x1, x0, sel.z), y3 = __builtin_amdgcn_perm(x1, x0, sel.w);
@@ -1203,7 +1277,8 @@ __device__ __forceinline__ void lz77_resolve_body(
             for (uint32_t i = 16 * lane; !(kAblate & 8u) && i < span; i += 1024) {
                 if (i + 16 <= span) {
                     u32x4 v;
-                    v.x = ldu32(sp + i); v.y = ldu32(sp + i + 4); v.z = ldu32(sp + i + 8); v.w = ldu32(sp + i + 12);
+                    if (kOpt & 1u) __builtin_memcpy(&v, sp + i, 16);
+                    else { v.x = ldu32(sp + i); v.y = ldu32(sp + i + 4); v.z = ldu32(sp + i + 8); v.w = ldu32(sp + i + 12); }
                     __builtin_memcpy(dp + i, &v, 16);
                 } else {
                     for (uint32_t k = i; k < span; ++k) dp[k] = sp[k];
