@@ -437,3 +437,200 @@ sbx_ctx* sbxOpen(string[] bam_filenames) {
     enforce(ctx !is null, fromStringz(err.ptr).idup);
     return ctx;
 }
+
+/**
+ * Several devices (`sambamba depth ... --gpus N`; the compiled counterpart is cli.cpp `struct Sharded`, which the test-suite runs --
+ * tests/test_gpu_cli_sharded.py): ONE process, one device context per GPU (sbx_open(..., device = k, ...)), each driven by its own
+ * thread.  The job shards by POSITION (sbx_plan_shards): the outputs of disjoint position ranges are disjoint, so nothing travels
+ * between the devices -- the reference's analogue of the cut is pileupChunks (BioD/bio/std/hts/bam/pileup.d:1011-1015).
+ *
+ *   base    (no -L, --min-coverage > 0: the text is a pure function of the position) every context runs its slices
+ *           (sbx_run_interval: only the BGZF blocks the BAI lists for them are uploaded and inflated) and streams the text of its
+ *           positions; the slices are dealt round-robin and written in genome order, so device k + 1 computes while device k prints
+ *   region  every context reports on the BED regions whose first position it owns (a region is never split); rows are printed at
+ *           the end, in input order, as PerBedRegionPrinter.close does (depth.d:925-930)
+ * Window mode and the order-dependent option sets (base -L, base -c 0, window --overlap) go through sbxDepthRun on one device
+ * (cli.cpp shards window mode as well: `Sharded::window` collects the statistics the printer's rules are stated in).
+ * Returns false when the option set is not one of the above; the caller then calls sbxDepthRun(ctx0, ...).
+ * `ctx0` is the context depth_main opened (on devices[0]); the others are opened and closed here.
+ */
+bool sbxDepthRunSharded(sbx_ctx* ctx0, string[] bam_filenames, const(int)[] devices, ref const SbxDepthOptions o, File output) {
+    import core.sync.condition : Condition;
+    import core.sync.mutex : Mutex;
+    import core.thread : Thread;
+
+    if (devices.length < 2) return false;
+    const bool base_ok = o.mode == SBX_MODE_BASE && !o.merged_bed.length && o.min_cov > 0;
+    if (!base_ok && o.mode != SBX_MODE_REGION) return false;
+
+    sbx_header_info hi;
+    sbxEnforce(ctx0, sbx_header(ctx0, &hi));
+    enforce(hi.sorted_by_coordinate != 0, "All files must be coordinate-sorted");
+    enforce(hi.has_index != 0, "All files must be indexed");
+    char[512] err;
+    sbx_filter f;
+    enforce(sbx_compile_filter(o.query is null ? null : o.query.toStringz, &f, err.ptr, err.length) == SBX_OK, fromStringz(err.ptr).idup);
+
+    string[] samples;
+    foreach (s; 0 .. hi.n_samples) samples ~= fromStringz(sbx_sample_name(ctx0, s)).idup;
+    const uint S = o.combined ? 1 : cast(uint) samples.length;
+    const size_t n_thr = max(1, o.cov_thresholds.length);
+    const size_t N = devices.length;
+
+    // the plan: equal shares of the concatenated reference, cuts inside a contig at multiples of the tile size
+    auto lens = new long[hi.n_ref];
+    foreach (r; 0 .. hi.n_ref) lens[r] = sbx_ref_length(ctx0, r);
+    size_t n_sh;
+    auto shards = new sbx_shard[hi.n_ref + N + 1];
+    enforce(sbx_plan_shards(lens.ptr, hi.n_ref, cast(int) N, 1024, shards.ptr, shards.length, &n_sh) == SBX_OK, "internal: shard plan");
+    shards = shards[0 .. n_sh];
+
+    void configure(sbx_ctx* c) {
+        sbxEnforce(c, sbx_set_filter(c, &f));
+        sbxEnforce(c, sbx_set_params(c, o.mode, o.min_base_quality, o.fix_mate_overlaps ? 1 : 0, o.combined ? 1 : 0, o.window_size,
+                                     o.overlap, o.cov_thresholds.ptr, cast(int) o.cov_thresholds.length));
+        if (o.merged_bed.length) sbxEnforce(c, sbx_set_regions(c, o.merged_bed.ptr, o.merged_bed.length));
+    }
+    auto cx = new sbx_ctx*[N];
+    cx[0] = ctx0;
+    scope (exit) foreach (k; 1 .. N) if (cx[k] !is null) sbx_close(cx[k]);
+    sbx_ctx* context(size_t k) {          // called on worker k's thread: the contexts open side by side
+        if (k == 0) { configure(ctx0); return ctx0; }
+        char[512] e;
+        auto paths = bam_filenames.map!toStringz.array;
+        auto c = sbx_open(paths.ptr, cast(int) paths.length, devices[k], e.ptr, e.length);
+        enforce(c !is null, fromStringz(e.ptr).idup);
+        cx[k] = c;
+        configure(c);
+        return c;
+    }
+
+    auto mu = new Mutex;
+    auto cv = new Condition(mu);
+    string failure;
+    void fail(string m) { synchronized (mu) { if (failure is null) failure = m.length ? m : "a device of the sharded run failed"; cv.notifyAll(); } }
+    void runWorkers(void delegate(size_t k, sbx_ctx* c) work) {
+        Thread[] th;
+        foreach (k; 0 .. N) {
+            auto t = new Thread({ const size_t me = k; return { try work(me, context(me)); catch (Exception e) fail(e.msg); }; }());
+            t.start();
+            th ~= t;
+        }
+        foreach (t; th) t.join();
+        enforce(failure is null, failure);
+    }
+    // the slack --fix-mate-overlaps needs on both sides of a region hull: a read past the overlap with its mate is counted differently
+    // from an unpaired one (status `past`, depth.d:717-845), so the mate must be in the run; raised to the longest alignment the run reports
+    void runWithMateSlack(sbx_ctx* c, uint r, ulong beg, ulong end) {
+        if (!o.fix_mate_overlaps) { sbxEnforce(c, sbx_run_interval(c, r, cast(uint) beg, cast(uint) end)); return; }
+        ulong slack = 16384;
+        foreach (attempt; 0 .. 4) {
+            sbxEnforce(c, sbx_run_interval(c, r, cast(uint)(beg > slack ? beg - slack : 0), cast(uint) min(end + slack, 0x7FFFFFFFUL)));
+            sbx_run_stats st;
+            sbxEnforce(c, sbx_last_run_stats(c, &st));
+            if (st.max_alignment_span <= slack) return;
+            slack = (st.max_alignment_span + 16383) / 16384 * 16384;
+        }
+        enforce(false, "--fix-mate-overlaps: the alignments of a slice span more than " ~ slack.to!string ~ " positions; run on one device");
+    }
+
+    if (o.mode == SBX_MODE_BASE) {
+        static struct Slice { uint r; ulong beg, end, printEnd; size_t owner; }
+        Slice[] sl;
+        ulong total = 0;
+        foreach (L; lens) total += max(0L, L);
+        ulong want = max(total / (4 * N), 16UL << 20);
+        want = (want + 1023) / 1024 * 1024;
+        foreach (sh; shards) {
+            const ulong len = cast(ulong) lens[sh.ref_id], span = sh.end - sh.beg;
+            const ulong n = (span + want - 1) / want, step = ((span + n - 1) / n + 1023) / 1024 * 1024;
+            for (ulong b = sh.beg; b < sh.end; b += step) {
+                const ulong e = min(cast(ulong) sh.end, b + step);
+                sl ~= Slice(sh.ref_id, b, e, e == len ? 0xFFFF_FFFFUL : e, 0);      // (columns of alignments hanging over the contig end)
+            }
+        }
+        foreach (g, ref x; sl) x.owner = g % N;          // one output stream: round-robin, so that the devices compute next to the one that prints
+        auto written = new bool[sl.length];
+        output.flush();
+        runWorkers((size_t k, sbx_ctx* c) {
+            foreach (g, x; sl) {
+                if (x.owner != k) continue;
+                // (the last slice of a contig also takes the reads that START behind its end, up to the index's coordinate limit)
+                sbxEnforce(c, sbx_run_interval(c, x.r, cast(uint) x.beg, x.printEnd == 0xFFFF_FFFFUL ? 1u << 29 : cast(uint) x.end));
+                synchronized (mu) {
+                    while (failure is null) {
+                        bool ready = true;
+                        foreach (i; 0 .. g) ready &= written[i];
+                        if (ready) break;
+                        cv.wait();
+                    }
+                    if (failure !is null) return;
+                }
+                ulong from = x.beg, b, e;
+                for (;;) {
+                    sbxEnforce(c, sbx_next_active_range(c, x.r, from, &b, &e));
+                    if (b == ulong.max || b >= x.printEnd) break;
+                    b = max(b, from);
+                    e = min(e, x.printEnd);
+                    sbxEnforce(c, sbx_stream_base_rows(c, x.r, cast(uint) b, cast(uint) e, o.min_cov, o.max_cov, o.annotate ? 1 : 0,
+                                                       &sbxFileSink, &output));
+                    from = e;
+                }
+                output.flush();
+                synchronized (mu) { written[g] = true; cv.notifyAll(); }
+            }
+        });
+        return true;
+    }
+
+    // ---- region ----
+    auto r_st = new sbx_region_stats[o.raw_bed.length * S];
+    auto r_cov = new uint[o.raw_bed.length * S * n_thr];
+    auto r_seen = new ubyte[o.raw_bed.length];
+    size_t ownerOf(sbx_region g) {
+        // the device that owns the region's first position (regions starting at or beyond the end of their contig: the owner of the
+        // contig's last position; regions of zero-length contigs: device 0)
+        const long len = lens[g.ref_id];
+        if (len <= 0) return 0;
+        const ulong p = min(cast(ulong) g.start, cast(ulong) len - 1);
+        foreach (x; shards) if (x.ref_id == g.ref_id && x.beg <= p && p < x.end) return x.shard;
+        return 0;
+    }
+    auto ids = new size_t[][N];
+    foreach (i, g; o.raw_bed) ids[ownerOf(g)] ~= i;
+    runWorkers((size_t k, sbx_ctx* c) {
+        // reads are selected against ALL merged regions (a mate that reaches the pileup through a neighbour's region must still pair,
+        // depth.d:717-758), but fetched only for the hull of the owned regions of a contig, widened by the mate slack
+        foreach (r; 0 .. cast(uint) hi.n_ref) {
+            size_t[] mine;
+            sbx_region[] sub;
+            ulong lo = ulong.max, hi_ = 0;
+            foreach (i; ids[k]) if (o.raw_bed[i].ref_id == r) {
+                mine ~= i; sub ~= o.raw_bed[i];
+                lo = min(lo, cast(ulong) o.raw_bed[i].start); hi_ = max(hi_, cast(ulong) o.raw_bed[i].end);
+            }
+            if (!mine.length) continue;
+            if (hi_ <= lo) hi_ = lo + 1;
+            runWithMateSlack(c, r, lo, min(hi_, 0x7FFFFFFFUL));
+            auto st = new sbx_region_stats[sub.length * S];
+            auto cvs = new uint[sub.length * S * n_thr];
+            auto sn = new ubyte[sub.length];
+            sbxEnforce(c, sbx_depth_region_stats(c, sub.ptr, sub.length, st.ptr, cvs.ptr, sn.ptr));
+            foreach (j, id; mine) {          // (rows of different devices are disjoint)
+                r_seen[id] = sn[j];
+                foreach (s; 0 .. S) {
+                    r_st[id * S + s] = st[j * S + s];
+                    foreach (t; 0 .. o.cov_thresholds.length) r_cov[(id * S + s) * n_thr + t] = cvs[(j * S + s) * o.cov_thresholds.length + t];
+                }
+            }
+        }
+    });
+    bool any = false;
+    foreach (v; r_seen) any |= v != 0;
+    if (any) foreach (id, g; o.raw_bed) {
+        const prefix = o.raw_bed_lines[id].stripRight ~ "\t";                            // depth.d:902-906
+        foreach (s; 0 .. S)
+            printRegionRow(output, o, prefix, g.end - g.start, r_st[id * S + s], r_cov[(id * S + s) * n_thr .. $], samples[s]);
+    }
+    return true;
+}
