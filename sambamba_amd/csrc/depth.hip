@@ -630,183 +630,6 @@ __device__ __forceinline__ void load_block(const uint8_t* seq0, uint32_t par, ui
 
 constexpr uint32_t kMapBytes = 704;      // 64 reads x 11 blocks
 
-__global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accumulate16b(
-    const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc, const uint32_t* __restrict__ tile_lo,
-    const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ active, uint32_t n_active,
-    const uint32_t* __restrict__ tile_base, int32_t n_ref, uint32_t T, uint32_t deep_thr, uint32_t* __restrict__ counters, uint32_t compact) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t per = gridDim.x >> 3;
-    const uint32_t slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);      // XCD-aware, as k_accumulate16
-    if (slot >= n_active) return;
-    const uint32_t tile = active[slot];
-    const uint32_t r_lo = tile_lo[tile], r_hi = tile_hi[tile];
-    if (r_hi - r_lo >= deep_thr) return;                // left to the 32-bit kernel
-    const uint32_t n_cnt_dw = 4u * T + (T >> 4);
-    uint32_t* cnt = lds;
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
-    uint8_t* map = (uint8_t*)(lds + ((n_cnt_dw + 3u) & ~3u)) + wave * kMapBytes;
-    for (uint32_t i = threadIdx.x; i < n_cnt_dw; i += kAccThreads) lds[i] = 0;
-
-    int lo_r = 0, hi_r = n_ref;   // invariant: tile_base[lo_r] <= tile < tile_base[hi_r]
-    while (hi_r - lo_r > 1) {
-        int mid = (lo_r + hi_r) >> 1;
-        if (tile_base[mid] <= tile) lo_r = mid; else hi_r = mid;
-    }
-    const int32_t ts = (int32_t)((tile - tile_base[lo_r]) * T);
-    const int32_t te = ts + (int32_t)T;
-    __syncthreads();
-
-    for (uint32_t c = r_lo + wave * 64u; c < r_hi; c += (kAccThreads / 64) * 64u) {
-        const uint32_t ri = c + lane;
-        RecDesc d;
-        d.kind = 0;
-        d.pos = 0; d.end = 0; d.rec_off = 0; d.l_seq = 0; d.n_cigar = 0; d.l_name = 0; d.q_start = 0; d.sample = 0;
-        if (ri < r_hi) d = desc[ri];
-        const bool take = d.kind != 0 && d.pos < te && d.end > ts;
-        // ---- reads with one run of aligned bases: clipped run [t0, t0 + n) of the tile, first base = query offset q0 ----------
-        int32_t i0 = 0, i1 = 0;
-        const bool one_run = take && d.kind == 1;
-        if (one_run) {
-            const int32_t len = d.end - d.pos;
-            i0 = ts > d.pos ? ts - d.pos : 0;
-            i1 = len < te - d.pos ? len : te - d.pos;
-            if ((int64_t)d.q_start + (int64_t)i1 > (int64_t)d.l_seq) i1 = (int32_t)d.l_seq - (int32_t)d.q_start;   // malformed record guard
-        }
-        const uint32_t n_run = one_run && i1 > i0 ? (uint32_t)(i1 - i0) : 0u;
-        const uint32_t t0 = (uint32_t)(d.pos + i0 - ts);
-        const uint32_t nblk_all = n_run ? ((t0 + n_run - 1u) >> 4) - (t0 >> 4) + 1u : 0u;
-        const bool fast = n_run != 0 && nblk_all <= 11u;
-        const uint32_t nblk = fast ? nblk_all : 0u;
-        const uint32_t q0 = (uint32_t)d.q_start + (uint32_t)i0;
-        const uint64_t a64 = d.rec_off + 36u + d.l_name + 4u * (uint32_t)d.n_cigar + (q0 >> 1);     // byte of the run's first base in U
-        // packed per-read parameters, fetched by the worker lanes with cross-lane reads
-        uint32_t incl = nblk;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t o = __shfl_up(incl, dlt, 64);
-            if ((int)lane >= dlt) incl += o;
-        }
-        const uint32_t start = incl - nblk;
-        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        const uint32_t p_lo = (uint32_t)a64;
-        const uint32_t p_hi = (uint32_t)(a64 >> 32) | (start << 16) | ((q0 & 1u) << 31);      // 48-bit offset | start (<= 704) | parity
-        const uint32_t p_tn = t0 | (n_run << 16);
-        for (uint32_t j = 0; j < 11u; ++j)
-            if (j < nblk) map[start + j] = (uint8_t)lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
-            const uint32_t g = g0 + lane;
-            const bool on = g < total;
-            const uint32_t r = on ? (uint32_t)map[g] : 0u;
-            const uint32_t w_lo = __shfl(p_lo, r, 64), w_hi = __shfl(p_hi, r, 64), w_tn = __shfl(p_tn, r, 64);
-            if (on) {
-                const uint32_t rt0 = w_tn & 0xFFFFu, rn = w_tn >> 16;
-                const uint32_t j = g - ((w_hi >> 16) & 0x7FFFu);
-                const uint32_t pb = ((rt0 >> 4) + j) << 4;
-                const uint32_t k0 = pb < rt0 ? rt0 - pb : 0u;
-                const uint32_t k1 = rt0 + rn - pb < 16u ? rt0 + rn - pb : 16u;
-                const uint32_t vm = ((1u << k1) - 1u) & ~((1u << k0) - 1u);
-                const uint8_t* seq0 = U + (((uint64_t)(w_hi & 0xFFFFu) << 32) | w_lo);
-                uint32_t b_lo, b_hi;
-                load_block(seq0, w_hi >> 31, rt0, pb, &b_lo, &b_hi);
-                add_block(cnt, pb, vm, b_lo, b_hi);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();      // the map is rewritten by the next batch
-        // ---- everything else (general CIGARs, runs of more than eleven blocks): one read at a time, 64 lanes ---------------------
-        uint64_t m2 = __ballot(take && !fast && (d.kind == 2 || n_run != 0));
-        while (m2) {
-            const int r = __builtin_ctzll(m2);
-            m2 &= m2 - 1;
-            const uint32_t off_lo = __builtin_amdgcn_readlane((uint32_t)d.rec_off, r);
-            const uint32_t off_hi = __builtin_amdgcn_readlane((uint32_t)(d.rec_off >> 32), r);
-            const int32_t R_pos = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.pos, r);
-            const int32_t R_end = (int32_t)__builtin_amdgcn_readlane((uint32_t)d.end, r);
-            const uint32_t R_lseq = __builtin_amdgcn_readlane(d.l_seq, r);
-            const uint32_t misc = __builtin_amdgcn_readlane((uint32_t)d.n_cigar | ((uint32_t)d.l_name << 16), r);
-            const uint32_t R_ncig = misc & 0xFFFFu;
-            const uint8_t* rec = U + (((uint64_t)off_hi << 32) | off_lo);
-            const uint8_t* cig = rec + 36 + ((misc >> 16) & 0xFFu);
-            const uint8_t* seq = cig + 4 * R_ncig;
-            // CIGAR walk as in k_accumulate: a reference-consuming op occupies max(len, 1) columns (pileup.d:195-205) and the
-            // read leaves the pileup at end = pos + sum(len) (read.d:1380-1383)
-            int32_t rp = R_pos;
-            uint32_t qp = 0;
-            for (uint32_t k = 0; k < R_ncig; ++k) {
-                const uint32_t op = ld32u(cig + 4 * k);
-                const uint32_t ty = (kCigarType >> ((op & 15u) * 2u)) & 3u;
-                uint32_t len = op >> 4;
-                if (ty & 2u) {
-                    if (len == 0) len = 1;
-                    const int32_t room = R_end - rp;
-                    if ((int64_t)len > (int64_t)room) len = (uint32_t)(room > 0 ? room : 0);
-                }
-                if (ty == 3) {
-                    int32_t a0 = ts > rp ? ts - rp : 0;
-                    int32_t a1 = (int32_t)len < te - rp ? (int32_t)len : te - rp;
-                    if ((int64_t)qp + (int64_t)a1 > (int64_t)R_lseq) a1 = (int32_t)R_lseq - (int32_t)qp;   // malformed record guard
-                    if (a1 > a0) {
-                        const uint32_t rt0 = (uint32_t)(rp + a0 - ts), rn = (uint32_t)(a1 - a0), rq0 = qp + (uint32_t)a0;
-                        const uint8_t* seq0 = seq + (rq0 >> 1);
-                        const uint32_t nb = ((rt0 + rn - 1u) >> 4) - (rt0 >> 4) + 1u;
-                        for (uint32_t j = lane; j < nb; j += 64u) {
-                            const uint32_t pb = ((rt0 >> 4) + j) << 4;
-                            const uint32_t k0 = pb < rt0 ? rt0 - pb : 0u;
-                            const uint32_t k1 = rt0 + rn - pb < 16u ? rt0 + rn - pb : 16u;
-                            uint32_t b_lo, b_hi;
-                            load_block(seq0, rq0 & 1u, rt0, pb, &b_lo, &b_hi);
-                            add_block(cnt, pb, ((1u << k1) - 1u) & ~((1u << k0) - 1u), b_lo, b_hi);
-                        }
-                    }
-                    rp += (int32_t)len;
-                    qp += len;
-                } else if (ty == 2) {
-                    const uint32_t code = (op & 15u) == 2u ? 5u : 6u;      // D -> DEL, otherwise (N) -> REFSKIP
-                    const int32_t g0 = ts > rp ? ts - rp : 0;
-                    const int64_t room = (int64_t)te - rp;
-                    const int32_t g1 = (int64_t)len < room ? (int32_t)len : (int32_t)(room < 0 ? 0 : room);
-                    for (int32_t i = g0 + (int32_t)lane; i < g1; i += 64)
-                        atomicAdd(cnt + blk_dw((uint32_t)(rp + i - ts)) + (code >> 1), 1u << ((code & 1u) << 4));
-                    rp += (int32_t)len;
-                } else if (ty == 1) {
-                    qp += len;
-                }
-                if (rp >= te || rp >= R_end) break;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- write the tile once: 16-bit pairs -> u32[T][7], coalesced 16-byte stores -------------------------------------------------
-    const uint32_t n_out = T * 7u;                  // multiple of 4 (T >= 16)
-    if (compact) {       // region / window modes: {bases counted : 16 | depth : 16} per position (see k_accumulate16)
-        uint32_t* outc = counters + (size_t)slot * T;
-        for (uint32_t i4 = threadIdx.x * 4u; i4 < T; i4 += kAccThreads * 4u) {
-            uint32_t v[4];
-#pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                const uint32_t* w = cnt + blk_dw(i4 + e);
-                const uint32_t m = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[2] & 0xFFFFu);
-                v[e] = m | ((m + (w[2] >> 16) + (w[3] & 0xFFFFu)) << 16);
-            }
-            *(uint4*)(outc + i4) = make_uint4(v[0], v[1], v[2], v[3]);
-        }
-        return;
-    }
-    uint32_t* out = counters + (size_t)slot * n_out;
-    const uint32_t inv_7 = 0xFFFFFFFFu / 7u + 1u;
-    for (uint32_t i4 = threadIdx.x * 4u; i4 < n_out; i4 += kAccThreads * 4u) {
-        uint32_t v[4];
-#pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t i = i4 + e;
-            const uint32_t p = __umulhi(i, inv_7), k = i - p * 7u;
-            const uint32_t w = cnt[blk_dw(p) + (k >> 1)];
-            v[e] = (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
-        }
-        *(uint4*)(out + i4) = make_uint4(v[0], v[1], v[2], v[3]);
-    }
-}
 
 // variant 3 of K3: variant 2 plus a second stage that sends the runs of general CIGARs through the packed block routine too
 typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
@@ -1121,16 +944,10 @@ void launch_accumulate(const uint8_t* d_U, const RecDesc* d_desc, const uint32_t
             hipLaunchKernelGGL(kern, grid, block, lds, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base, n_ref,
                                tile_pos, n_samples, min_bq, deep_thr, d_counters, d_span, cflag);
         };
-        static const int variant = [] { const char* e = getenv("SBX_K3_VARIANT"); return e ? atoi(e) : 3; }();
-        if (n_samples == 1 && !d_span && !min_bq && variant == 3) {
+        if (n_samples == 1 && !d_span && !min_bq) {
             const size_t lds3 = (((size_t)4 * tile_pos + (tile_pos >> 4) + 3) & ~(size_t)3) * 4 + (size_t)(kAccThreads / 64) * kWaveBytesC;
             SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate16c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
             hipLaunchKernelGGL(k_accumulate16c, grid, block, lds3, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base,
-                               n_ref, tile_pos, deep_thr, d_counters, cflag);
-        } else if (n_samples == 1 && !d_span && !min_bq && variant == 2) {
-            const size_t lds2 = (((size_t)4 * tile_pos + (tile_pos >> 4) + 3) & ~(size_t)3) * 4 + (size_t)(kAccThreads / 64) * kMapBytes;
-            SBX_HIP(hipFuncSetAttribute((const void*)k_accumulate16b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL(k_accumulate16b, grid, block, lds2, stream, d_U, d_desc, d_tile_lo, d_tile_hi, d_active, n_active, d_tile_base,
                                n_ref, tile_pos, deep_thr, d_counters, cflag);
         } else if (n_samples == 1) {
             if (d_span) { if (min_bq) go(k_accumulate16<true, true, true>); else go(k_accumulate16<true, false, true>); }

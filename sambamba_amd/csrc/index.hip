@@ -1014,7 +1014,6 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
 // compiled into this template is slower than round 4's kernel was.  `describe` does not wait for its chain of dependent loads; it runs
 // at the rate of scattered 128-byte lines a CU sustains (the walk, with a quarter of the occupancy, runs at the same rate per line).
 __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_blocks(IndexArgs a) { describe_blocks_body<true>(a); }
-__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_blocks_r4(IndexArgs a) { describe_blocks_body<false>(a); }
 
 // ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
 __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* __restrict__ tile_lo,
@@ -1169,10 +1168,8 @@ void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(k_check_scan, dim3(1), dim3(kScanThreads), 0, stream, a);
     SBX_HIP(hipGetLastError());
     const uint32_t per = kDescThreads / 64;
-    static const int form = [] { const char* e = getenv("SBX_K2_DESCRIBE"); return e ? atoi(e) : 1; }();
     const dim3 dgrid((a.n_blocks + per - 1) / per), dblock(kDescThreads);
-    if (form == 0) hipLaunchKernelGGL(k_describe_blocks_r4, dgrid, dblock, 0, stream, a);
-    else hipLaunchKernelGGL(k_describe_blocks, dgrid, dblock, 0, stream, a);
+    hipLaunchKernelGGL(k_describe_blocks, dgrid, dblock, 0, stream, a);
     SBX_HIP(hipGetLastError());
 }
 

@@ -38,7 +38,6 @@
 // K1a: one instruction per four cycles with three to four waves per SIMD); neither is HBM-bandwidth bound and their GB/s are
 // reported for completeness (DESIGN.md sections 3 and 4).
 #include <cstdlib>
-#include <type_traits>
 
 #include "common.hpp"
 #include "inflate2_core.hpp"
@@ -884,16 +883,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-// One short copy task (n <= 16) of a lane, loads and stores separated so that a caller can put the loads
-// of several tasks in flight before the first store.  n >= 4: four dwords at offsets min(4k, n - 4) --
-// the ones past the end collapse onto the tail dword, so nothing is predicated per dword.  n < 4: one
-// dword is read (the over-read stays inside the padded buffers) and 1..3 bytes of it are written.
-// (kWide, round 6: gfx950 takes 8-byte LDS and global accesses at any byte address -- hipcc emits ds_read_b64 / ds_write_b64 for them --
-// so 8 .. 16 bytes are two 8-byte words at offsets 0 and n - 8, 4 .. 7 bytes two dwords at 0 and n - 4: no offset arithmetic per dword)
+// One short copy task (n <= 16) of a lane, loads and stores separated so that a caller can put the loads of several tasks in flight
+// before the first store.  gfx950 takes 8-byte LDS and global accesses at any byte address (hipcc emits ds_read_b64 / ds_write_b64 for
+// them), so 8 .. 16 bytes are two 8-byte words at offsets 0 and n - 8, 4 .. 7 bytes two dwords at 0 and n - 4 -- the words overlap in
+// the middle, nothing is computed per dword; below 4 bytes one dword is read (the over-read stays inside the padded buffers) and 1 .. 3
+// bytes of it are written.  (Rounds 1-5 copied four dwords at offsets min(4 k, n - 4): 21.5 ms against 18.5 ms for config 2's K1b,
+// profiles/round6/call_d_k1b_wide_config2.jsonl.)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x2 ldu64(const uint8_t* p) { u32x2 v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ void stu64(uint8_t* p, u32x2 v) { __builtin_memcpy(p, &v, 8); }
-struct Short16W {
+struct Short16 {
     uint32_t w[4];
     __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
         if (n >= 8) {
@@ -918,90 +917,13 @@ struct Short16W {
         }
     }
 };
-// up to 32 bytes in one step: 16 .. 32 bytes are two 16-byte words at offsets 0 and n - 16
-struct Short32W {
-    u32x4 lo, hi;
-    __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
-        if (n >= 16) {
-            __builtin_memcpy(&lo, s, 16); __builtin_memcpy(&hi, s + n - 16, 16);
-        } else if (n >= 8) {
-            const u32x2 a = ldu64(s), b = ldu64(s + n - 8);
-            lo.x = a.x; lo.y = a.y; lo.z = b.x; lo.w = b.y;
-        } else if (n >= 4) {
-            lo.x = ldu32(s); lo.y = ldu32(s + n - 4);
-        } else if (n) {
-            lo.x = ldu32(s);
-        }
-    }
-    __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
-        if (n >= 16) {
-            __builtin_memcpy(d, &lo, 16); __builtin_memcpy(d + n - 16, &hi, 16);
-        } else if (n >= 8) {
-            u32x2 a, b;
-            a.x = lo.x; a.y = lo.y; b.x = lo.z; b.y = lo.w;
-            stu64(d, a); stu64(d + n - 8, b);
-        } else if (n >= 4) {
-            stu32(d, lo.x); stu32(d + n - 4, lo.y);
-        } else if (n) {
-            if (n & 2u) { const uint16_t h = (uint16_t)lo.x; __builtin_memcpy(d, &h, 2); }
-            if (n & 1u) d[n & 2u] = (uint8_t)(lo.x >> (8u * (n & 2u)));
-        }
-    }
-};
-struct Short16 {
-    uint32_t w[4];
-    __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
-        if (n >= 4) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; w[k] = ldu32(s + o); }
-        } else if (n) {
-            w[0] = ldu32(s);
-        }
-    }
-    __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
-        if (n >= 4) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) { const uint32_t o = 4 * k + 4 <= n ? 4 * k : n - 4; stu32(d + o, w[k]); }
-        } else if (n) {
-            if (n & 2u) { const uint16_t h = (uint16_t)w[0]; __builtin_memcpy(d, &h, 2); }
-            if (n & 1u) d[n & 2u] = (uint8_t)(w[0] >> (8u * (n & 2u)));
-        }
-    }
-};
 
 // Long copy tasks (16 < n <= 512) of a wave, done by all 64 lanes, 8 bytes per lane, four tasks in
 // flight (loads of all four before the first store).  Lane r of `m` owns a task: n bytes from
 // sbase + s to buf + d.  Source and destination of a task never overlap.
 // (four tasks per turn of the loop; two or one per turn -- a batch of a BAM stream holds 1.6 long far matches and 0.2 long literal runs,
 // tools/token_stats.cpp -- execute 8 % fewer vector instructions and are not faster: profiles/round5/README.md)
-// (k64: one 8-byte word per lane and task instead of two dwords; a task is longer than 8 bytes)
-template <bool k64 = false>
 __device__ __forceinline__ void coop_copy(uint64_t m, const uint8_t* sbase, uint32_t s, uint8_t* buf, uint32_t d, uint32_t n, uint32_t lane) {
-    if (k64) {
-        while (m) {
-            uint32_t S[4], D[4], N[4];
-            u32x2 wv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                N[j] = 0; S[j] = 0; D[j] = 0;
-                if (m) {
-                    const int r = __builtin_ctzll(m);
-                    m &= m - 1;
-                    S[j] = __builtin_amdgcn_readlane(s, r);
-                    D[j] = __builtin_amdgcn_readlane(d, r);
-                    N[j] = __builtin_amdgcn_readlane(n, r);
-                }
-            }
-            const uint32_t off = 8 * lane;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (off < N[j]) wv[j] = ldu64(sbase + S[j] + (off + 8 <= N[j] ? off : N[j] - 8));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (off < N[j]) stu64(buf + D[j] + (off + 8 <= N[j] ? off : N[j] - 8), wv[j]);
-        }
-        return;
-    }
     while (m) {
         uint32_t S[4], D[4], N[4], wa[4], wb[4];
 #pragma unroll
@@ -1056,10 +978,8 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // (Round 4's candidate -- near matches resolved per OUTPUT BYTE through origin pointers, `k_lz77_resolve_jump` -- ran on the device in
 // round 5: correct, and 37 % SLOWER than this kernel (30.6 against 22.4 ms on config 2; more instructions of every kind, not fewer:
 // profiles/round5/README.md).  It is gone; what it left is the lesson that the rounds of phase B are cheap -- see kExact below.)
-// kOpt (round 6, each bit an A/B in tools/k1_lab): 1 = the write-out reads its 16 bytes with one LDS instruction; 2 = cooperative copies in 8-byte
-// words; 4 = own-lane copies of up to 32 bytes in ONE step (16 .. 32 bytes: two 16-byte words) instead of two steps of 16; 8 = the byte-permute
-// path reads its period with one 8-byte load
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0, bool kWide = false, uint32_t kOpt = 0>
+// (kAblate: tools/k1_lab compiles parts of the batch loop out to time them; 0 in the product)
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -1130,25 +1050,18 @@ __device__ __forceinline__ void lz77_resolve_body(
             // own-lane copies in steps of 16 bytes: one step, or two when some item of the batch is 17 .. 32 bytes long (the same code
             // and registers for both steps -- what matters is that the kernel keeps its 8 waves per SIMD)
             const uint32_t own_l = (kAblate & 1u) ? 0u : lr <= kOwn ? lr : 0u, own_f = (kAblate & 2u) ? 0u : far && len <= kOwn ? len : 0u;
-            if (kOpt & 4u) {
-                Short32W rl, rf;
-                rl.load(lit + el, own_l);
-                rf.load(o + src, own_f);
-                rl.store(buf + (eo - base), own_l);
-                rf.store(buf + (dst - base), own_f);
-            }
-            const uint32_t steps = (kOpt & 4u) ? 0u : (kAblate & 16u) ? 1u : kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
+            const uint32_t steps = (kAblate & 16u) ? 1u : kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
             for (uint32_t h = 0; h < steps; ++h) {
                 const uint32_t n_l = own_l > 16u * h ? (own_l - 16u * h < 16u ? own_l - 16u * h : 16u) : 0u;
                 const uint32_t n_f = own_f > 16u * h ? (own_f - 16u * h < 16u ? own_f - 16u * h : 16u) : 0u;
-                typename std::conditional<kWide, Short16W, Short16>::type rl, rf;
+                Short16 rl, rf;
                 rl.load(lit + el + 16u * h, n_l);
                 rf.load(o + src + 16u * h, n_f);
                 rl.store(buf + (eo - base) + 16u * h, n_l);
                 rf.store(buf + (dst - base) + 16u * h, n_f);
             }
-            if (!(kAblate & (1u | 64u))) coop_copy<(kOpt & 2u) != 0>(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
-            if (!(kAblate & (2u | 64u))) coop_copy<(kOpt & 2u) != 0>(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
+            if (!(kAblate & (1u | 64u))) coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
+            if (!(kAblate & (2u | 64u))) coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
         }
         // ---- phase B: near matches, LDS -> LDS --------------------------------------------------------------
         // A match may start once everything below its source end is final.  Matches start in entry order,
@@ -1201,19 +1114,14 @@ __device__ __forceinline__ void lz77_resolve_body(
             {
                 constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;
                 const uint32_t own_s = plain && len <= kOwn ? len : 0u;       // (source and destination of a plain match do not overlap)
-                if (kOpt & 4u) {
-                    Short32W rs;
-                    rs.load(buf + srco, own_s);
-                    rs.store(buf + dsto, own_s);
-                }
-                const uint32_t steps = (kOpt & 4u) ? 0u : kOwn32 && __any(own_s > 16u) ? 2u : 1u;
+                const uint32_t steps = kOwn32 && __any(own_s > 16u) ? 2u : 1u;
                 for (uint32_t h = 0; h < steps; ++h) {
                     const uint32_t n_s = own_s > 16u * h ? (own_s - 16u * h < 16u ? own_s - 16u * h : 16u) : 0u;
-                    typename std::conditional<kWide, Short16W, Short16>::type rs;
+                    Short16 rs;
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
                 }
-                coop_copy<(kOpt & 2u) != 0>(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
+                coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
             // self-overlapping matches: byte k is src[k mod dist].  Short ones in their own lane (all
             // loads first: the bytes read lie in [src, dst)), long ones by doubling: the period, then
@@ -1222,25 +1130,29 @@ __device__ __forceinline__ void lz77_resolve_body(
             const bool per_perm = kOwn32 && per && len <= 16 && dist <= 8;
             if (kOwn32 && __any(per_perm)) {
                 // output byte k = period[k mod dist]: the period sits in the first (<= 8) bytes at src, output dword j is one byte
-                // permute of them; the tail dword (offset len - 4) is cut out of two neighbours
+                // permute of them; the tail words are cut out of neighbouring dwords
                 Short16 ws;
                 uint32_t n_p = 0;
                 if (per_perm) {
-                    uint32_t x0, x1;
-                    if (kOpt & 8u) { const u32x2 xx = ldu64(buf + srco); x0 = xx.x; x1 = xx.y; }
-                    else { x0 = ldu32(buf + srco); x1 = ldu32(buf + srco + 4); }
+                    const u32x2 xx = ldu64(buf + srco);
+                    const uint32_t x0 = xx.x, x1 = xx.y;
                     const u32x4 sel = *(const u32x4*)(per_sel + 4u * (dist - 1u));
                     const uint32_t y0 = __builtin_amdgcn_perm(x1, x0, sel.x), y1 = __builtin_amdgcn_perm(x1, x0, sel.y);
                     const uint32_t y2 = __builtin_amdgcn_perm(x1, x0, sel.z), y3 = __builtin_amdgcn_perm(x1, x0, sel.w);
                     n_p = len;
-                    const uint32_t to = len >= 4u ? len - 4u : 0u, tj = to >> 2, tsh = to & 3u;
-                    const uint32_t ta = tj == 0u ? y0 : tj == 1u ? y1 : tj == 2u ? y2 : y3;
-                    const uint32_t tb = tj == 0u ? y1 : tj == 1u ? y2 : y3;          // (tj == 3 only with tsh == 0)
-                    const uint32_t tail = __builtin_amdgcn_alignbyte(tb, ta, tsh);
-                    ws.w[0] = y0;                              // (Short16::store: dword k goes to offset 4 k when it fits, else to len - 4)
-                    ws.w[1] = 8u <= len ? y1 : tail;
-                    ws.w[2] = 12u <= len ? y2 : tail;
-                    ws.w[3] = 16u <= len ? y3 : tail;
+                    // (Short16::store: 8 .. 16 bytes are the words at offsets 0 and len - 8, 4 .. 7 bytes the dwords at 0 and len - 4)
+                    ws.w[0] = y0;
+                    if (len >= 8u) {
+                        const uint32_t to = len - 8u, tj = to >> 2, tsh = to & 3u;          // (tj == 2 only with tsh == 0)
+                        const uint32_t ta = tj == 0u ? y0 : tj == 1u ? y1 : y2;
+                        const uint32_t tb = tj == 0u ? y1 : tj == 1u ? y2 : y3;
+                        const uint32_t tc = tj == 0u ? y2 : y3;
+                        ws.w[1] = y1;
+                        ws.w[2] = __builtin_amdgcn_alignbyte(tb, ta, tsh);
+                        ws.w[3] = __builtin_amdgcn_alignbyte(tc, tb, tsh);
+                    } else {
+                        ws.w[1] = __builtin_amdgcn_alignbyte(y1, y0, len >= 4u ? len - 4u : 0u);
+                    }
                 }
                 ws.store(buf + dsto, n_p);
             }
@@ -1277,8 +1189,7 @@ __device__ __forceinline__ void lz77_resolve_body(
             for (uint32_t i = 16 * lane; !(kAblate & 8u) && i < span; i += 1024) {
                 if (i + 16 <= span) {
                     u32x4 v;
-                    if (kOpt & 1u) __builtin_memcpy(&v, sp + i, 16);
-                    else { v.x = ldu32(sp + i); v.y = ldu32(sp + i + 4); v.z = ldu32(sp + i + 8); v.w = ldu32(sp + i + 12); }
+                    __builtin_memcpy(&v, sp + i, 16);
                     __builtin_memcpy(dp + i, &v, 16);
                 } else {
                     for (uint32_t k = i; k < span; ++k) dp[k] = sp[k];
@@ -1295,16 +1206,12 @@ __device__ __forceinline__ void lz77_resolve_body(
                       const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0, uint8_t* out, \
                       const uint32_t* __restrict__ status
 #define SBX_LZ77_PASS lit_stream, ent_stream, n_entries, out_off, isize, n_blocks, block0, out, status
-// k_lz77_resolve_o32 (round 3; SBX_K1B_VARIANT=1: the A/B partner): own-lane copies up to 32 bytes + byte-permute expansion of short
-// periodic matches, the frontier rule; k_lz77_resolve_exact (round 5, the default): the same with the exact readiness rule (kExact above;
-// LDS per wave: window + 256 bytes of match ranges).  Both compiled for 8 waves per SIMD (64 VGPRs; the attribute is worth 0.4 ms).
-template <uint32_t kHist, uint32_t kSpanMax>
-__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_o32(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true, false>(SBX_LZ77_PASS);
-}
+// k_lz77_resolve_exact: own-lane copies up to 32 bytes in two steps of two 8-byte words, byte-permute expansion of short periodic matches,
+// the exact readiness rule (kExact above; LDS per wave: window + 256 bytes of match ranges).  Compiled for 8 waves per SIMD (64 VGPRs; the
+// attribute is worth 0.4 ms).  (Round 3's k_lz77_resolve_o32 -- the frontier rule -- was the A/B partner until round 6; profiles/round5.)
 template <uint32_t kHist, uint32_t kSpanMax>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz77_resolve_exact(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpanMax, true, true, 0, true>(SBX_LZ77_PASS);
+    lz77_resolve_body<kHist, kSpanMax, true, true>(SBX_LZ77_PASS);
 }
 
 }  // namespace
@@ -1351,20 +1258,10 @@ void launch_k1a(const InflateArgs& a, hipStream_t stream) {
         dim3 grid((a.n_blocks + kInfThreads - 1) / kInfThreads), block(kInfThreads);
         const size_t lds = (size_t)kInfThreads * kLaneLds + kLenTabBytes + kDistTabBytes;
         const uint32_t only_flagged = k1a != 1 ? 1u : 0u;
-        // 16-byte groups per token-store burst: 1 (default) is the fastest -- no register FIFO to shift -- and writes partial
-        // sectors (WRITE_SIZE 2.7 x the token bytes); 2 and 4 trade instructions for write traffic (1.5 x, 1.2 x): DESIGN.md K1a
-        static const int burst = [] { const char* e = getenv("SBX_K1A_BURST"); return e ? atoi(e) : 1; }();
-#define SBX_K1A_LAUNCH(DEPTH, STREAM)                                                                                                      \
-    hipLaunchKernelGGL((k_huffman_decode<DEPTH, STREAM>), grid, block, lds, stream, a.comp, a.comp_off, a.comp_len, a.isize, a.out_off, \
-                       a.n_blocks, a.block0, a.lit, a.ent, a.nent, a.scratch, a.status, a.tok, only_flagged)
-        switch (burst) {
-            case 4: SBX_K1A_LAUNCH(4, false); break;
-            case 2: SBX_K1A_LAUNCH(2, false); break;
-            case 21: SBX_K1A_LAUNCH(1, true); break;
-            case 22: SBX_K1A_LAUNCH(2, true); break;
-            default: SBX_K1A_LAUNCH(1, false); break;
-        }
-#undef SBX_K1A_LAUNCH
+        // (one 16-byte group per token store: the kernel is a template over the burst depth and the cache policy of its stores --
+        // rounds 3 / 4 measured 2 and 4 groups per burst and nontemporal stores, profiles/round3, profiles/round4; only this form is built)
+        hipLaunchKernelGGL((k_huffman_decode<1, false>), grid, block, lds, stream, a.comp, a.comp_off, a.comp_len, a.isize, a.out_off,
+                           a.n_blocks, a.block0, a.lit, a.ent, a.nent, a.scratch, a.status, a.tok, only_flagged);
         SBX_HIP(hipGetLastError());
     }
     if (k1a != 1) {
@@ -1378,13 +1275,8 @@ void launch_k1b(const InflateArgs& a, hipStream_t stream) {
     const uint32_t per = kResThreads / 64;
     dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
     const size_t lds = (size_t)(kResThreads / 64) * (kHistDefault + 1024u + kSpanDefault + 16u);
-    static const int variant = [] { const char* e = getenv("SBX_K1B_VARIANT"); return e ? atoi(e) : 3; }();
-    if (variant == 1)
-        hipLaunchKernelGGL((k_lz77_resolve_o32<kHistDefault, kSpanDefault>), grid, block, lds + 128, stream, a.lit, a.ent, a.nent, a.out_off,
-                           a.isize, a.n_blocks, a.block0, a.out, a.status);
-    else
-        hipLaunchKernelGGL((k_lz77_resolve_exact<kHistDefault, kSpanDefault>), grid, block, lds + 128 + (size_t)(kResThreads / 64) * 256, stream, a.lit,
-                           a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
+    hipLaunchKernelGGL((k_lz77_resolve_exact<kHistDefault, kSpanDefault>), grid, block, lds + 128 + (size_t)(kResThreads / 64) * 256, stream, a.lit,
+                       a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
     SBX_HIP(hipGetLastError());
 }
 

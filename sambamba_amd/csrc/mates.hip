@@ -59,11 +59,8 @@ __device__ bool same_name(const uint8_t* U, const RecDesc& a, const RecDesc& b) 
     return true;
 }
 
-// The scan of record i runs over the records that start inside its span -- a few hundred at 300x -- and nearly all of it
-// is "different hash, next": the workgroup therefore stages {pos, low half of the hash, reference id | not-admitted bit}
-// of the 1024 records from its first one on in LDS (coalesced, each record's descriptor read four times in all instead
-// of once per neighbour) and the lanes scan that; only a hash match touches global memory again, and a lane whose span
-// reaches beyond the window (coverage in the thousands) finishes in global memory.
+// A workgroup of find_mates / find_partners looks at the 1024 records from its first one on (a window staged in LDS); a lane whose
+// span reaches beyond the window (coverage in the thousands) finishes in global memory.
 constexpr uint32_t kFindWin = 1024;
 
 __device__ __forceinline__ void link_if_mates(const uint8_t* U, const RecDesc* desc, const uint64_t* hash, const RecDesc& a, uint64_t h,
@@ -77,67 +74,8 @@ __device__ __forceinline__ void link_if_mates(const uint8_t* U, const RecDesc* d
     }
 }
 
-__global__ __launch_bounds__(kMateThreads) void k_find_mates(const uint8_t* __restrict__ U, const RecDesc* __restrict__ desc,
-                                                              const uint64_t* __restrict__ hash, const int32_t* __restrict__ rec_ref,
-                                                              uint64_t n, uint32_t* mate, uint32_t* n_partners) {
-    __shared__ int32_t s_pos[kFindWin];
-    __shared__ uint32_t s_h[kFindWin], s_ref[kFindWin];
-    const uint64_t i0 = (uint64_t)blockIdx.x * kMateThreads;
-    for (uint32_t k = threadIdx.x; k < kFindWin; k += kMateThreads) {
-        const uint64_t j = i0 + k;
-        if (j < n) {
-            const RecDesc d = desc[j];
-            s_pos[k] = d.pos;
-            s_h[k] = (uint32_t)hash[j];
-            s_ref[k] = ((uint32_t)rec_ref[j] & 0x7FFFFFFFu) | (d.kind == 0 ? 0x80000000u : 0u);
-        } else {
-            s_pos[k] = 0x7FFFFFFF;
-            s_h[k] = 0;
-            s_ref[k] = 0x7FFFFFFEu;      // no reference has this id: the scan stops here
-        }
-    }
-    __syncthreads();
-    const uint64_t i = i0 + threadIdx.x;
-    if (i >= n) return;
-    const RecDesc a = desc[i];
-    if (a.kind == 0) return;
-    const uint64_t h = hash[i];
-    const int32_t ref = rec_ref[i];
-    const uint32_t ref_tag = (uint32_t)ref & 0x7FFFFFFFu, h32 = (uint32_t)h;
-    bool done = false;
-    uint32_t k = threadIdx.x + 1;
-    // four window entries per step: twelve LDS reads in flight and one wait instead of three dependent round trips per entry (the
-    // scan is a few hundred entries long at 300x and nearly all of it is "different hash, next"); the entries are still taken in
-    // order -- `nv` of the four lie before the first one that ends the scan, only those can link
-    for (; !done && k + 4 <= kFindWin; k += 4) {
-        uint32_t rj[4], hj[4];
-        int32_t pj[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { rj[q] = s_ref[k + q]; pj[q] = s_pos[k + q]; hj[q] = s_h[k + q]; }
-        uint32_t nv = 4, hits = 0;
-#pragma unroll
-        for (int q = 3; q >= 0; --q) {
-            if ((rj[q] & 0x7FFFFFFFu) != ref_tag || pj[q] >= a.end) nv = (uint32_t)q;      // coordinate sorted: nothing further can overlap A
-            if (hj[q] == h32 && !(rj[q] >> 31)) hits |= 1u << q;
-        }
-        hits &= (1u << nv) - 1u;
-        for (; hits; hits &= hits - 1u) link_if_mates(U, desc, hash, a, h, i, i0 + k + (uint32_t)__builtin_ctz(hits), mate, n_partners);
-        if (nv < 4u) done = true;
-    }
-    for (; !done && k < kFindWin; ++k) {
-        const uint32_t rj = s_ref[k];
-        if ((rj & 0x7FFFFFFFu) != ref_tag || s_pos[k] >= a.end) { done = true; break; }
-        if (s_h[k] == h32 && !(rj >> 31)) link_if_mates(U, desc, hash, a, h, i, i0 + k, mate, n_partners);
-    }
-    if (!done)
-        for (uint64_t j = i0 + kFindWin; j < n; ++j) {
-            const RecDesc b = desc[j];
-            if (rec_ref[j] != ref || b.pos >= a.end) break;
-            if (hash[j] == h) link_if_mates(U, desc, hash, a, h, i, j, mate, n_partners);
-        }
-}
 
-// The same links through a hash JOIN (round 4): the scan above reads a few hundred window entries per record at
+// The links through a hash JOIN (round 4; round 3's kernel scanned the window entries that start inside a record's span -- it read a few hundred window entries per record at
 // 300x to find the one or two with its hash.  Here the workgroup puts the admitted records of its window into an open-addressing
 // table in LDS keyed by the half hash (2,048 slots for <= 1,024 entries: mates share a key and sit in neighbouring slots), and a
 // record probes for its own key: two or three slots instead of three hundred entries.  A candidate links under the scan's conditions
@@ -708,13 +646,7 @@ __global__ __launch_bounds__(kMateThreads) void k_mates_columns(
 void launch_find_mates(const uint8_t* d_U, const RecDesc* d_desc, const uint64_t* d_hash, const int32_t* d_rec_ref, uint64_t n_records,
                        uint32_t* d_mate, uint32_t* d_n_partners, hipStream_t stream) {
     if (!n_records) return;
-    // SBX_K7_FIND=0: round 3's window scan; default: the hash join
-    static const int find = [] { const char* e = getenv("SBX_K7_FIND"); return e ? atoi(e) : 1; }();
-    if (find == 0)
-        hipLaunchKernelGGL(k_find_mates, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
-                           d_U, d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
-    else
-        hipLaunchKernelGGL(k_find_mates_join, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
+    hipLaunchKernelGGL(k_find_mates_join, dim3((uint32_t)((n_records + kMateThreads - 1) / kMateThreads)), dim3(kMateThreads), 0, stream,
                            d_U, d_desc, d_hash, d_rec_ref, n_records, d_mate, d_n_partners);
     SBX_HIP(hipGetLastError());
 }

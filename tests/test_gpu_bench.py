@@ -48,6 +48,15 @@ def test_bench_line(tmp_path, extra):
     assert d["kernels"]["huffman_decode"]["intermediate_bytes"] > 0
     assert d["kernels"]["huffman_decode"]["algorithmic_bytes"] < d["kernels"]["lz77_resolve"]["algorithmic_bytes"]
     assert 0 < d["roofline"]["path_frac"] < 1
+    # round 6: the older definition beside the redefined one; the pass including its text (configs 2, 5); config 4 timed with the work-list
+    # cache off, the cached re-run beside it
+    assert d["roofline"]["path_frac_incl_counters"] >= d["roofline"]["path_frac"] and "traffic_total" in d["roofline"]
+    if cfg in (2, 5):
+        dt = d["device_text"]
+        assert "error" not in dt, dt
+        assert dt["text_equals_host_copy_path"] and dt["text_bytes"] > 100000 and dt["ms_per_step"] >= d["ms_per_step"] * 0.8
+    if cfg == 4:
+        assert d["rerun_cached"]["ms_per_step"] > 0
     # counters are joined only from a pass stamped with these very kernel sources: a development-scale line has none
     assert d["roofline"]["traffic"] is None
 

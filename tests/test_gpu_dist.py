@@ -46,14 +46,18 @@ def one_contig(tmp_path_factory):
                    extra=["--insert-mean", "250", "--insert-sd", "40", "--tie-free-overlaps"])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("args", [
+ONE_CONTIG_ARGS = [
     ["base"],
     ["base", "-m", "-q", "20"],
     ["base", "-c", "0", "-a", "-C", "45"],
     ["base", "-L", "chrOne:30000-150000", "-m"],
     ["window", "-w", "1000", "-m", "-T", "20"],
-])
+]
+
+
+# (round 6: every option set at two ranks, two of them at three -- a torch.distributed job takes seconds to come up; the one-process
+# form of the same sharding, `sbx-depth --gpus N`, runs the full matrix in tests/test_gpu_cli_sharded.py)
+@pytest.mark.parametrize("args,world", [(a, 2) for a in ONE_CONTIG_ARGS] + [(ONE_CONTIG_ARGS[1], 3), (ONE_CONTIG_ARGS[4], 3)])
 def test_position_sharded_single_contig_equals_single_gpu_cli(one_contig, args, world):
     want = run_cli(args + [one_contig])
     assert len(want) > 1000
@@ -70,13 +74,15 @@ def test_position_sharded_base_on_a_genome(genome):
         assert got == want, args
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("args", [
+GENOME_ARGS = [
     ["region", "-L", "BED", "-T", "5", "-T", "20"],
     ["region", "-L", "BED", "-m", "-q", "20", "-T", "3"],
     ["window", "-w", "1000", "-T", "10"],
     ["window", "-w", "700", "-m", "-q", "13", "--combined"],
-])
+]
+
+
+@pytest.mark.parametrize("args,world", [(a, 2) for a in GENOME_ARGS] + [(GENOME_ARGS[1], 3), (GENOME_ARGS[2], 3)])
 def test_sharded_equals_single_gpu_cli(genome, args, world):
     bam, bed = genome
     if "--combined" in args and "-m" in args:
@@ -150,8 +156,7 @@ def run_dist_to_file(args, world, port, out_path, env_extra=None):
     return open(out_path, "rb").read()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("args", [["base"], ["base", "-c", "0"], ["base", "-m", "-q", "20", "-a"]])
+@pytest.mark.parametrize("args,world", [(["base"], 2), (["base", "-c", "0"], 3), (["base", "-m", "-q", "20", "-a"], 2)])
 def test_every_rank_writes_its_own_byte_range(genome, one_contig, tmp_path, args, world):
     """`base -o`: no text funnel -- each rank pwrites at the offset the exclusive scan of the measured sizes gives it, in pieces
     (SBX_STREAM_PIECE makes the pieces small enough that every rank writes several)."""
@@ -162,7 +167,7 @@ def test_every_rank_writes_its_own_byte_range(genome, one_contig, tmp_path, args
         assert got == want, (args, k)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [3])
 def test_allreduce_form_prints_the_same_text(genome, one_contig, tmp_path, world):
     """`base --reduce allreduce`: reads partitioned by start position, per-position counters summed by an all-reduce."""
     for k, bam in enumerate((one_contig, genome[0])):

@@ -31,8 +31,11 @@ def bam(tmp_path_factory):
                    extra=["--samples", "2", "--insert-mean", "260", "--insert-sd", "40", "--tie-free-overlaps"])
 
 
-@pytest.mark.parametrize("slice_positions", [1024, 40000, 100000, 10**9])
-@pytest.mark.parametrize("args", [["base"], ["base", "-c", "3", "-C", "40", "-a"], ["base", "-m", "-q", "20"], ["base", "--combined", "-F", "mapping_quality > 10"]])
+PIPE_ARGS = [["base"], ["base", "-c", "3", "-C", "40", "-a"], ["base", "-m", "-q", "20"], ["base", "--combined", "-F", "mapping_quality > 10"]]
+
+
+# (slices of one tile -- 1,024 positions, hundreds of slices -- with two of the option sets only: they cost 10 s each)
+@pytest.mark.parametrize("args,slice_positions", [(a, sp) for a in PIPE_ARGS for sp in (40000, 100000, 10**9)] + [(PIPE_ARGS[0], 1024), (PIPE_ARGS[2], 1024)])
 def test_pipelined_base_equals_one_pass_and_oracle(bam, args, slice_positions):
     want = run_oracle(args + [bam])
     env_off = dict(os.environ, SBX_NO_PIPELINE="1")

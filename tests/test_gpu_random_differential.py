@@ -177,15 +177,18 @@ def _one(seed):
 
 
 def test_cli_equals_oracle_on_random_bams():
-    fails = []          # every differing example is reported, not only the first (no shrinking: an example is a GPU process)
+    from concurrent.futures import ThreadPoolExecutor
+    seeds = []          # hypothesis draws the (derandomized) seeds; the examples -- a CLI process and an oracle process each -- run side by side
 
     @settings(max_examples=300, deadline=None, derandomize=True, database=None, phases=[Phase.generate],
               suppress_health_check=list(HealthCheck))
     @given(seed=st.integers(0, 2 ** 31 - 1))
     def body(seed):
-        r = _one(seed)
-        if r is not None:
-            fails.append(r)
+        seeds.append(seed)
 
     body()
+    assert len(seeds) >= 250
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        # every differing example is reported, not only the first (no shrinking: an example is a GPU process)
+        fails = [r for r in ex.map(_one, seeds) if r is not None]
     assert not fails, "%d of the random examples differ:\n%s" % (len(fails), "\n".join(map(str, fails[:8])))

@@ -1,7 +1,9 @@
 // k1_lab -- development tool (not part of the product library): times the inflate kernels of csrc/inflate.hip on the BGZF blocks
 // of a BAM, kernel by kernel with HIP events, and K1b with parts of its batch loop compiled out (lz77_resolve_body's kAblate bits:
-// results of those launches are INVALID by construction; the point is what each part of the loop costs the kernel).  The default
-// kernels run first and their output is compared with zlib's on the host, so a lab build that broke the real path says so.
+// results of those launches are INVALID by construction; the point is what each part of the loop costs the kernel -- `ablate`) or
+// with other window geometries (`geo`).  The default kernels run first and their output is compared with zlib's on the host, so a
+// lab build that broke the real path says so.  (Round 6's A/Bs -- the copy primitive, 8-byte cooperative copies, one-step 32-byte
+// copies -- were run from earlier versions of this file: profiles/round6/call_[a-f]_*.jsonl.)
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o k1_lab k1_lab.hip -lz && ./k1_lab file.bam [repeats]
 //
@@ -17,21 +19,15 @@
 namespace sbx {
 void require_device(int) {}
 
-template <uint32_t kAblate, bool kWide = false, uint32_t kOpt = 0>
+template <uint32_t kAblate>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lab_k1b(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHistDefault, kSpanDefault, true, true, kAblate, kWide, kOpt>(SBX_LZ77_PASS);
-}
-
-// the same body with the register budget of 6 waves per SIMD (80 VGPRs) instead of 8 (64)
-template <uint32_t kAblate, bool kWide, uint32_t kOpt>
-__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_lab_k1b_r(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHistDefault, kSpanDefault, true, true, kAblate, kWide, kOpt>(SBX_LZ77_PASS);
+    lz77_resolve_body<kHistDefault, kSpanDefault, true, true, kAblate>(SBX_LZ77_PASS);
 }
 
 // window geometry variants of the product body
 template <uint32_t kHist, uint32_t kSpan>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lab_k1b_geo(SBX_LZ77_ARGS) {
-    lz77_resolve_body<kHist, kSpan, true, true, 0, true, 0>(SBX_LZ77_PASS);
+    lz77_resolve_body<kHist, kSpan, true, true, 0>(SBX_LZ77_PASS);
 }
 
 struct Lab {
@@ -57,18 +53,6 @@ struct Lab {
     }
     double last_mean = 0;
     std::function<void()> check;
-    template <uint32_t kAblate, bool kWide, uint32_t kOpt>
-    void k1b_r(const char* what, bool verify = false) {
-        const uint32_t per = kResThreads / 64;
-        dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
-        const size_t lds = (size_t)per * (kHistDefault + 1024u + kSpanDefault + 16u) + 128 + (size_t)per * 256;
-        const double ms = time([&] {
-            hipLaunchKernelGGL((k_lab_k1b_r<kAblate, kWide, kOpt>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
-        });
-        printf("{\"kernel\": \"k1b\", \"ablate\": %u, \"wide\": %d, \"opt\": %u, \"waves_per_eu\": \"6..8\", \"what\": \"%s\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", kAblate, (int)kWide, kOpt, what, ms, last_mean);
-        if (verify) check();
-        fflush(stdout);
-    }
     template <uint32_t kHist, uint32_t kSpan>
     void k1b_geo(bool verify = false) {
         const uint32_t per = kResThreads / 64;
@@ -81,15 +65,15 @@ struct Lab {
         if (verify) check();
         fflush(stdout);
     }
-    template <uint32_t kAblate, bool kWide = false, uint32_t kOpt = 0>
+    template <uint32_t kAblate>
     void k1b(const char* what, bool verify = false) {
         const uint32_t per = kResThreads / 64;
         dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
         const size_t lds = (size_t)per * (kHistDefault + 1024u + kSpanDefault + 16u) + 128 + (size_t)per * 256;
         const double ms = time([&] {
-            hipLaunchKernelGGL((k_lab_k1b<kAblate, kWide, kOpt>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
+            hipLaunchKernelGGL((k_lab_k1b<kAblate>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
         });
-        printf("{\"kernel\": \"k1b\", \"ablate\": %u, \"wide\": %d, \"opt\": %u, \"what\": \"%s\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", kAblate, (int)kWide, kOpt, what, ms, last_mean);
+        printf("{\"kernel\": \"k1b\", \"ablate\": %u, \"what\": \"%s\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", kAblate, what, ms, last_mean);
         if (verify) check();
         fflush(stdout);
     }
@@ -150,8 +134,7 @@ int main(int argc, char** argv) {
         const double k1b = lab.time([&] { launch_k1b(lab.a, lab.stream); });
         printf("{\"kernel\": \"k1b_product\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", k1b, lab.last_mean);
         lab.check();
-        lab.k1b<0, false>("round 5's body (four collapsing dwords)");
-        lab.k1b<0, true>("wide own-lane copies: the product body", true);
+        lab.k1b<0>("the product body", true);
         if (argc > 3 && std::string(argv[3]) == "geo") {
             lab.k1b_geo<1024, 1024>(true);
             lab.k1b_geo<1024, 1536>();
@@ -159,10 +142,8 @@ int main(int argc, char** argv) {
             lab.k1b_geo<2048, 1024>();
             lab.k1b_geo<2048, 1536>();
             lab.k1b_geo<2048, 2048>(true);
-            lab.k1b_geo<3072, 1024>();
             lab.k1b_geo<3072, 1536>();
             lab.k1b_geo<4096, 1536>();
-            lab.k1b_geo<6144, 1536>(true);
         }
         if (argc > 3 && std::string(argv[3]) == "ablate") {
             lab.k1b<1>("no literal copies (own + coop)");
@@ -175,11 +156,6 @@ int main(int argc, char** argv) {
             lab.k1b<3 | 4>("no phase A, no phase B");
             lab.k1b<3 | 4 | 8>("scan and loop only");
             lab.k1b<3 | 8>("phase B only");
-            lab.k1b<3, true>("wide: no phase A");
-            lab.k1b<4, true>("wide: no phase B");
-            lab.k1b<8, true>("wide: no phase C");
-            lab.k1b<3 | 4, true>("wide: no phase A, no phase B");
-            lab.k1b<3 | 4 | 8, true>("wide: scan and loop only");
         }
         return 0;
     } catch (const std::exception& e) {
