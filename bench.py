@@ -358,7 +358,7 @@ def parity_full_regions(d, bam, regs, got_rows, share_of_host=1):
             "oracle_processes": n_sl, "seconds": round(time.time() - t0, 1)}
 
 
-def cli_e2e(bam, mode_args, reads):
+def cli_e2e(bam, mode_args, reads, pause=3.0):
     """The product CLI end to end: file (page cache) -> device -> text on /dev/null, wall clock of the command as ONE process,
     teardown of the device context included (`seconds`: the like-for-like figure next to cpu_baseline).  Three runs, the best is
     reported, all are listed, with the CLI's own phase clock of the best one.  Two more runs with SBX_DETACH=1 -- the work in a
@@ -379,12 +379,12 @@ def cli_e2e(bam, mode_args, reads):
         runs, det = [], []
         for k in range(3):
             if k:
-                time.sleep(3.0)      # (a process started right behind another one's teardown waits for the driver to scrub the freed memory)
+                time.sleep(pause)    # (a process started right behind another one's teardown waits for the driver to scrub the freed memory)
             runs.append(once(dict(os.environ, SBX_TIMING="1")))
         for k in range(2):
-            time.sleep(3.0)
+            time.sleep(pause)
             det.append(once(dict(os.environ, SBX_TIMING="1", SBX_DETACH="1")))
-        time.sleep(2.0)
+        time.sleep(min(pause, 2.0))
     except RuntimeError as e:
         return {"error": str(e)}
     best = min(runs, key=lambda x: x[0])
@@ -686,6 +686,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=int(os.environ.get("SBX_BENCH_CPU_READS", 10_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-pause", type=float, default=3.0, help="seconds between the end-to-end CLI runs (the tests use a short one)")
     ap.add_argument("--no-side-runs", action="store_true", help="N > 1: skip the strong-scaling / all-reduce side measurements")
     ap.add_argument("--parity-windows", type=int, default=8)
     ap.add_argument("--no-full-parity", dest="full_parity", action="store_false",
@@ -951,7 +952,7 @@ def main():
         e2e = None
         log("cpu baseline done; e2e CLI")
         if not args.no_e2e and world == 1:
-            e2e = cli_e2e(path, mode_args, int(info["reads"]))
+            e2e = cli_e2e(path, mode_args, int(info["reads"]), pause=args.e2e_pause)
             if cpu and e2e.get("Mreads_per_s"):
                 e2e["vs_cpu_baseline"] = round(e2e["Mreads_per_s"] / cpu["value"], 1)
         what = {2: "depth base", 3: "depth window -w 1000", 4: "depth region -L exome.bed", 5: "depth base --fix-mate-overlaps -q20"}[args.config]

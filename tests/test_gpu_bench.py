@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 ])
 def test_bench_line(tmp_path, extra):
     env = dict(os.environ, PYTHONPATH=ROOT)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000", "--parity-windows", "4"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000", "--parity-windows", "4", "--e2e-pause", "0.3"] + extra
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
