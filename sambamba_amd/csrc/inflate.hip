@@ -41,6 +41,7 @@
 
 #include "common.hpp"
 #include "inflate2_core.hpp"
+#include "lz77_copy.hpp"
 #include "kernels.hpp"
 
 namespace sbx {
@@ -883,40 +884,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-// One short copy task (n <= 16) of a lane, loads and stores separated so that a caller can put the loads of several tasks in flight
-// before the first store.  gfx950 takes 8-byte LDS and global accesses at any byte address (hipcc emits ds_read_b64 / ds_write_b64 for
-// them), so 8 .. 16 bytes are two 8-byte words at offsets 0 and n - 8, 4 .. 7 bytes two dwords at 0 and n - 4 -- the words overlap in
-// the middle, nothing is computed per dword; below 4 bytes one dword is read (the over-read stays inside the padded buffers) and 1 .. 3
-// bytes of it are written.  (Rounds 1-5 copied four dwords at offsets min(4 k, n - 4): 21.5 ms against 18.5 ms for config 2's K1b,
-// profiles/round6/call_d_k1b_wide_config2.jsonl.)
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x2 ldu64(const uint8_t* p) { u32x2 v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ void stu64(uint8_t* p, u32x2 v) { __builtin_memcpy(p, &v, 8); }
-struct Short16 {
-    uint32_t w[4];
-    __device__ __forceinline__ void load(const uint8_t* s, uint32_t n) {
-        if (n >= 8) {
-            const u32x2 a = ldu64(s), b = ldu64(s + n - 8);
-            w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
-        } else if (n >= 4) {
-            w[0] = ldu32(s); w[1] = ldu32(s + n - 4);
-        } else if (n) {
-            w[0] = ldu32(s);
-        }
-    }
-    __device__ __forceinline__ void store(uint8_t* d, uint32_t n) const {
-        if (n >= 8) {
-            u32x2 a, b;
-            a.x = w[0]; a.y = w[1]; b.x = w[2]; b.y = w[3];
-            stu64(d, a); stu64(d + n - 8, b);
-        } else if (n >= 4) {
-            stu32(d, w[0]); stu32(d + n - 4, w[1]);
-        } else if (n) {
-            if (n & 2u) { const uint16_t h = (uint16_t)w[0]; __builtin_memcpy(d, &h, 2); }
-            if (n & 1u) d[n & 2u] = (uint8_t)(w[0] >> (8u * (n & 2u)));
-        }
-    }
-};
+// (the short copy of a lane -- Short16 -- and the expansion of short periodic matches live in lz77_copy.hpp: the CPU harness runs them too)
+using lz::Short16;
 
 // Long copy tasks (16 < n <= 512) of a wave, done by all 64 lanes, 8 bytes per lane, four tasks in
 // flight (loads of all four before the first store).  Lane r of `m` owns a task: n bytes from
@@ -979,7 +948,8 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // round 5: correct, and 37 % SLOWER than this kernel (30.6 against 22.4 ms on config 2; more instructions of every kind, not fewer:
 // profiles/round5/README.md).  It is gone; what it left is the lesson that the rounds of phase B are cheap -- see kExact below.)
 // (kAblate: tools/k1_lab compiles parts of the batch loop out to time them; 0 in the product)
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0>
+// (kTail16, lab A/B: the second 16 bytes of a 17 .. 32-byte own-lane copy as ONE 16-byte word at offset n - 16 instead of a second Short16 step)
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0, bool kTail16 = false>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
@@ -995,9 +965,7 @@ __device__ __forceinline__ void lz77_resolve_body(
         uint32_t* tab = (uint32_t*)(smem + (kResThreads / 64) * (kHist + 1024u + kSpanMax + 16u));
         if (threadIdx.x < 32u) {
             const uint32_t d = (threadIdx.x >> 2) + 1u, j = threadIdx.x & 3u;
-            uint32_t v = 0;
-            for (uint32_t i = 0; i < 4; ++i) v |= ((4u * j + i) % d) << (8u * i);
-            tab[threadIdx.x] = v;
+            tab[threadIdx.x] = lz::period_selector(d, j);
         }
         __syncthreads();
     }
@@ -1051,7 +1019,7 @@ __device__ __forceinline__ void lz77_resolve_body(
             // and registers for both steps -- what matters is that the kernel keeps its 8 waves per SIMD)
             const uint32_t own_l = (kAblate & 1u) ? 0u : lr <= kOwn ? lr : 0u, own_f = (kAblate & 2u) ? 0u : far && len <= kOwn ? len : 0u;
             const uint32_t steps = (kAblate & 16u) ? 1u : kOwn32 && __any((own_l | own_f) > 16u) ? 2u : 1u;
-            for (uint32_t h = 0; h < steps; ++h) {
+            for (uint32_t h = 0; h < (kTail16 ? 1u : steps); ++h) {
                 const uint32_t n_l = own_l > 16u * h ? (own_l - 16u * h < 16u ? own_l - 16u * h : 16u) : 0u;
                 const uint32_t n_f = own_f > 16u * h ? (own_f - 16u * h < 16u ? own_f - 16u * h : 16u) : 0u;
                 Short16 rl, rf;
@@ -1059,6 +1027,18 @@ __device__ __forceinline__ void lz77_resolve_body(
                 rf.load(o + src + 16u * h, n_f);
                 rl.store(buf + (eo - base) + 16u * h, n_l);
                 rf.store(buf + (dst - base) + 16u * h, n_f);
+            }
+            if (kTail16 && steps > 1u) {
+                // 17 .. 32 bytes: the last 16 of them as one word (it overlaps what the first step copied)
+                // (a lane has a long literal run or a long far match, rarely both: ONE word per lane, the literal run first)
+                const bool tl = own_l > 16u, tf = !tl && own_f > 16u;
+                const uint8_t* ts = tl ? lit + el + own_l - 16u : o + src + own_f - 16u;
+                const uint32_t td = tl ? (eo - base) + own_l - 16u : (dst - base) + own_f - 16u;
+                u32x4 tv;
+                if (tl || tf) { __builtin_memcpy(&tv, ts, 16); __builtin_memcpy(buf + td, &tv, 16); }
+                if (__any(tl && own_f > 16u)) {
+                    if (tl && own_f > 16u) { __builtin_memcpy(&tv, o + src + own_f - 16u, 16); __builtin_memcpy(buf + (dst - base) + own_f - 16u, &tv, 16); }
+                }
             }
             if (!(kAblate & (1u | 64u))) coop_copy(__ballot(lr > kOwn), lit, el, buf, eo - base, lr, lane);
             if (!(kAblate & (2u | 64u))) coop_copy(__ballot(far && len > kOwn), o, src, buf, dst - base, len, lane);
@@ -1115,11 +1095,16 @@ __device__ __forceinline__ void lz77_resolve_body(
                 constexpr uint32_t kOwn = kOwn32 ? 32u : 16u;
                 const uint32_t own_s = plain && len <= kOwn ? len : 0u;       // (source and destination of a plain match do not overlap)
                 const uint32_t steps = kOwn32 && __any(own_s > 16u) ? 2u : 1u;
-                for (uint32_t h = 0; h < steps; ++h) {
+                for (uint32_t h = 0; h < (kTail16 ? 1u : steps); ++h) {
                     const uint32_t n_s = own_s > 16u * h ? (own_s - 16u * h < 16u ? own_s - 16u * h : 16u) : 0u;
                     Short16 rs;
                     rs.load(buf + srco + 16u * h, n_s);
                     rs.store(buf + dsto + 16u * h, n_s);
+                }
+                if (kTail16 && steps > 1u && own_s > 16u) {
+                    u32x4 ts;
+                    __builtin_memcpy(&ts, buf + srco + own_s - 16u, 16);
+                    __builtin_memcpy(buf + dsto + own_s - 16u, &ts, 16);
                 }
                 coop_copy(__ballot(plain && len > kOwn), buf, srco, buf, dsto, len, lane);
             }
@@ -1134,25 +1119,10 @@ __device__ __forceinline__ void lz77_resolve_body(
                 Short16 ws;
                 uint32_t n_p = 0;
                 if (per_perm) {
-                    const u32x2 xx = ldu64(buf + srco);
-                    const uint32_t x0 = xx.x, x1 = xx.y;
+                    const lz::W2 xx = lz::ld64(buf + srco);
                     const u32x4 sel = *(const u32x4*)(per_sel + 4u * (dist - 1u));
-                    const uint32_t y0 = __builtin_amdgcn_perm(x1, x0, sel.x), y1 = __builtin_amdgcn_perm(x1, x0, sel.y);
-                    const uint32_t y2 = __builtin_amdgcn_perm(x1, x0, sel.z), y3 = __builtin_amdgcn_perm(x1, x0, sel.w);
                     n_p = len;
-                    // (Short16::store: 8 .. 16 bytes are the words at offsets 0 and len - 8, 4 .. 7 bytes the dwords at 0 and len - 4)
-                    ws.w[0] = y0;
-                    if (len >= 8u) {
-                        const uint32_t to = len - 8u, tj = to >> 2, tsh = to & 3u;          // (tj == 2 only with tsh == 0)
-                        const uint32_t ta = tj == 0u ? y0 : tj == 1u ? y1 : y2;
-                        const uint32_t tb = tj == 0u ? y1 : tj == 1u ? y2 : y3;
-                        const uint32_t tc = tj == 0u ? y2 : y3;
-                        ws.w[1] = y1;
-                        ws.w[2] = __builtin_amdgcn_alignbyte(tb, ta, tsh);
-                        ws.w[3] = __builtin_amdgcn_alignbyte(tc, tb, tsh);
-                    } else {
-                        ws.w[1] = __builtin_amdgcn_alignbyte(y1, y0, len >= 4u ? len - 4u : 0u);
-                    }
+                    lz::periodic16(xx.x, xx.y, len, sel.x, sel.y, sel.z, sel.w, &ws);
                 }
                 ws.store(buf + dsto, n_p);
             }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../sambamba_amd/csrc/inflate2_core.hpp"
+#include "../../sambamba_amd/csrc/lz77_copy.hpp"
 
 using namespace sbx::inf2;
 
@@ -27,6 +28,35 @@ static std::vector<uint8_t> read_file(const char* path) {
     return v;
 }
 
+// The copy primitives of K1b (lz77_copy.hpp; round 6: two overlapping 8-byte words instead of four collapsing dwords) on the CPU: every
+// length at every source / destination alignment against memcpy -- nothing outside [0, n) of the destination may change --, and the
+// byte-permute expansion of a short periodic match for every (length, period) against the byte loop.
+static bool copy_primitives_ok() {
+    uint8_t src[96], dst[96], ref[96];
+    for (uint32_t n = 0; n <= 16; ++n)
+        for (uint32_t sa = 0; sa < 9; ++sa)
+            for (uint32_t da = 0; da < 9; ++da) {
+                for (int i = 0; i < 96; ++i) { src[i] = (uint8_t)(i * 37 + 11); dst[i] = ref[i] = (uint8_t)(200 - i); }
+                sbx::lz::Short16 c;
+                c.load(src + 16 + sa, n);
+                c.store(dst + 32 + da, n);
+                memcpy(ref + 32 + da, src + 16 + sa, n);
+                if (memcmp(dst, ref, 96)) { fprintf(stderr, "Short16: n=%u src+%u dst+%u differs from memcpy\n", n, sa, da); return false; }
+            }
+    for (uint32_t len = 2; len <= 16; ++len)
+        for (uint32_t dist = 1; dist <= 8 && dist < len; ++dist) {
+            for (int i = 0; i < 96; ++i) { src[i] = (uint8_t)(i * 29 + 5); dst[i] = ref[i] = 0xEE; }
+            const sbx::lz::W2 xx = sbx::lz::ld64(src + 3);
+            sbx::lz::Short16 ws;
+            sbx::lz::periodic16(xx.x, xx.y, len, sbx::lz::period_selector(dist, 0), sbx::lz::period_selector(dist, 1),
+                                sbx::lz::period_selector(dist, 2), sbx::lz::period_selector(dist, 3), &ws);
+            ws.store(dst + 40, len);
+            for (uint32_t k = 0; k < len; ++k) ref[40 + k] = src[3 + k % dist];
+            if (memcmp(dst, ref, 96)) { fprintf(stderr, "periodic16: len=%u dist=%u differs from the byte loop\n", len, dist); return false; }
+        }
+    return true;
+}
+
 // K1b's near-match resolution with the EXACT readiness rule (inflate.hip, kExact: the default kernel since round 5) step by step on the
 // CPU -- the algorithm, not the HIP code: batches of <= 64 entries and <= kSpan bytes; literal runs and far matches (source below the
 // window base) put in place first (phase A); then rounds: a pending match is READY when no pending match writes into its source range
@@ -36,7 +66,7 @@ static std::vector<uint8_t> read_file(const char* path) {
 static bool resolve_exact(const uint32_t* ent, uint32_t n_ent, const uint8_t* lit, uint32_t isize, std::vector<uint8_t>& out,
                           long* n_batches, long* n_rounds) {
     constexpr uint32_t kHist = 2048, kSpan = 1536, kCap = kHist + 1024 + kSpan;
-    out.assign(isize, 0);
+    out.assign((size_t)isize + 64, 0);        // (the primitives may read a dword / write nothing beyond a copy: 64 bytes of slack as on the device)
     uint32_t opos = 0, lpos = 0, base = 0;
     for (uint32_t e0 = 0; e0 < n_ent;) {
         uint32_t take = 0, span = 0, lspan = 0;
@@ -57,11 +87,30 @@ static bool resolve_exact(const uint32_t* ent, uint32_t n_ent, const uint8_t* li
         uint32_t start[64], end[64];
         for (uint32_t j = 0; j < 64; ++j) {
             if (j < take) {
-                for (uint32_t k = 0; k < lr[j]; ++k) out[dst[j] - lr[j] + k] = lit[lp++];
+                if (lr[j] <= 32) {             // own-lane copy: two steps of Short16 (the kernel's phase A)
+                    for (uint32_t h = 0; h < 2; ++h) {
+                        const uint32_t nn = lr[j] > 16 * h ? (lr[j] - 16 * h < 16 ? lr[j] - 16 * h : 16) : 0;
+                        sbx::lz::Short16 c;
+                        c.load(lit + lp + 16 * h, nn);
+                        c.store(out.data() + dst[j] - lr[j] + 16 * h, nn);
+                    }
+                    lp += lr[j];
+                } else
+                    for (uint32_t k = 0; k < lr[j]; ++k) out[dst[j] - lr[j] + k] = lit[lp++];
                 if (len[j]) {
                     if (dist[j] > dst[j]) return false;
                     const uint32_t src = dst[j] - dist[j];
-                    if (src < base) { for (uint32_t k = 0; k < len[j]; ++k) out[dst[j] + k] = out[src + k]; }
+                    if (src < base) {
+                        if (len[j] <= 32 && dist[j] >= len[j]) {
+                            for (uint32_t h = 0; h < 2; ++h) {
+                                const uint32_t nn = len[j] > 16 * h ? (len[j] - 16 * h < 16 ? len[j] - 16 * h : 16) : 0;
+                                sbx::lz::Short16 c;
+                                c.load(out.data() + src + 16 * h, nn);
+                                c.store(out.data() + dst[j] + 16 * h, nn);
+                            }
+                        } else
+                            for (uint32_t k = 0; k < len[j]; ++k) out[dst[j] + k] = out[src + k];
+                    }
                     else pending |= 1ull << j;
                 }
                 start[j] = dst[j] - base; end[j] = dst[j] + len[j] - base;
@@ -90,9 +139,32 @@ static bool resolve_exact(const uint32_t* ent, uint32_t n_ent, const uint8_t* li
             for (uint32_t i = 0; i < 64; ++i) if ((pending >> i & 1) && !(dep[i] & pending)) ready |= 1ull << i;
             if (!ready) return false;
             std::vector<std::pair<uint32_t, uint8_t>> writes;
+            // the kernel's paths: plain matches of up to 32 bytes in two Short16 steps (all lanes load, then all lanes store, step by
+            // step), periodic ones of up to 16 bytes with a period of up to 8 through the byte permutes; everything else byte by byte
+            sbx::lz::Short16 cp[64];
+            for (uint32_t h = 0; h < 2; ++h) {
+                for (uint32_t i = 0; i < 64; ++i)
+                    if ((ready >> i & 1) && dist[i] >= len[i] && len[i] <= 32) {
+                        const uint32_t nn = len[i] > 16 * h ? (len[i] - 16 * h < 16 ? len[i] - 16 * h : 16) : 0;
+                        cp[i].load(out.data() + dst[i] - dist[i] + 16 * h, nn);
+                    }
+                for (uint32_t i = 0; i < 64; ++i)
+                    if ((ready >> i & 1) && dist[i] >= len[i] && len[i] <= 32) {
+                        const uint32_t nn = len[i] > 16 * h ? (len[i] - 16 * h < 16 ? len[i] - 16 * h : 16) : 0;
+                        cp[i].store(out.data() + dst[i] + 16 * h, nn);
+                    }
+            }
             for (uint32_t i = 0; i < 64; ++i) {
-                if (!(ready >> i & 1)) continue;
+                if (!(ready >> i & 1) || (dist[i] >= len[i] && len[i] <= 32)) continue;
                 const uint32_t src = dst[i] - dist[i];
+                if (dist[i] < len[i] && len[i] <= 16 && dist[i] <= 8) {
+                    const sbx::lz::W2 xx = sbx::lz::ld64(out.data() + src);
+                    sbx::lz::Short16 ws;
+                    sbx::lz::periodic16(xx.x, xx.y, len[i], sbx::lz::period_selector(dist[i], 0), sbx::lz::period_selector(dist[i], 1),
+                                        sbx::lz::period_selector(dist[i], 2), sbx::lz::period_selector(dist[i], 3), &ws);
+                    ws.store(out.data() + dst[i], len[i]);
+                    continue;
+                }
                 for (uint32_t k = 0; k < len[i]; ++k) writes.push_back({dst[i] + k, out[src + k % dist[i]]});      // reads [src, dst) only
             }
             for (auto& w : writes) out[w.first] = w.second;
@@ -100,6 +172,7 @@ static bool resolve_exact(const uint32_t* ent, uint32_t n_ent, const uint8_t* li
         }
         opos += span; lpos += lspan; e0 += take;
     }
+    out.resize(isize);
     return opos == isize;
 }
 
@@ -107,6 +180,7 @@ int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s FILE [lane] [--exact]\n", argv[0]); return 2; }
     const uint32_t lane = argc > 2 ? (uint32_t)atoi(argv[2]) : 0u;
     const bool exact = argc > 3 && !strcmp(argv[3], "--exact");
+    if (!copy_primitives_ok()) return 1;
     long n_batches = 0, n_rounds = 0;
     std::vector<uint8_t> file = read_file(argv[1]);
     std::vector<uint8_t> lds(kWaveLds + kLenTabBytes + kDistTabBytes, 0xA5);

@@ -24,6 +24,12 @@ __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 
     lz77_resolve_body<kHistDefault, kSpanDefault, true, true, kAblate>(SBX_LZ77_PASS);
 }
 
+// the second 16 bytes of a 17 .. 32-byte copy as one word
+template <uint32_t kAblate>
+__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lab_k1b_t16(SBX_LZ77_ARGS) {
+    lz77_resolve_body<kHistDefault, kSpanDefault, true, true, kAblate, true>(SBX_LZ77_PASS);
+}
+
 // window geometry variants of the product body
 template <uint32_t kHist, uint32_t kSpan>
 __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lab_k1b_geo(SBX_LZ77_ARGS) {
@@ -62,6 +68,17 @@ struct Lab {
             hipLaunchKernelGGL((k_lab_k1b_geo<kHist, kSpan>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
         });
         printf("{\"kernel\": \"k1b\", \"hist\": %u, \"span\": %u, \"lds_per_wave\": %u, \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", kHist, kSpan, kHist + 1024u + kSpan + 16u + 256u, ms, last_mean);
+        if (verify) check();
+        fflush(stdout);
+    }
+    void k1b_t16(bool verify = false) {
+        const uint32_t per = kResThreads / 64;
+        dim3 grid((a.n_blocks + per - 1) / per), block(kResThreads);
+        const size_t lds = (size_t)per * (kHistDefault + 1024u + kSpanDefault + 16u) + 128 + (size_t)per * 256;
+        const double ms = time([&] {
+            hipLaunchKernelGGL((k_lab_k1b_t16<0>), grid, block, lds, stream, a.lit, a.ent, a.nent, a.out_off, a.isize, a.n_blocks, a.block0, a.out, a.status);
+        });
+        printf("{\"kernel\": \"k1b\", \"variant\": \"tail16\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", ms, last_mean);
         if (verify) check();
         fflush(stdout);
     }
@@ -135,6 +152,9 @@ int main(int argc, char** argv) {
         printf("{\"kernel\": \"k1b_product\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", k1b, lab.last_mean);
         lab.check();
         lab.k1b<0>("the product body", true);
+        lab.k1b_t16(true);
+        lab.k1b<0>("the product body, again");
+        lab.k1b_t16();
         if (argc > 3 && std::string(argv[3]) == "geo") {
             lab.k1b_geo<1024, 1024>(true);
             lab.k1b_geo<1024, 1536>();
