@@ -503,8 +503,8 @@ struct Described {
     bool admit, bad, urg;
 };
 
-// p: the record's block_size field.  kStaged: p points into the wave's piece in LDS, which holds the whole record, and `tail_end`
-// behind its last byte there;
+// p: the record's block_size field.  kStaged: p is the lane's staging slot in LDS -- the first kStageHead bytes of the record (fixed
+// part, name and CIGAR fit) -- and `tail_end` points behind the staged copy of the record's last kStageTail bytes (the tags fit);
 // otherwise p is the record in global memory.  The rg table comes as the view the kernel prepared (LDS copy or the global arrays).
 template <bool kStaged>
 __device__ __forceinline__ Described describe_record(const uint8_t* p, const uint8_t* tail_end, uint64_t o, const IndexArgs& a, const RgTable& rgv) {
@@ -870,43 +870,29 @@ __global__ __launch_bounds__(kScanThreads) void k_check_scan_mw(IndexArgs a, uns
 // ---- 3. describe: one wave per block, one lane per record ---------------------------------------------------
 constexpr int kDescThreads = 256;
 
-// Staging.  Round 4's lanes followed their records through global memory field by field (about twenty dependent round trips per batch of
-// 64 records); round 5 gave every lane the head and the tail of its record with seven independent 16-byte loads and parsed from an LDS
-// slot -- and found the kernel no faster: `describe` does not wait for its chain of loads, it runs at the rate of SCATTERED 128-byte lines
-// a CU sustains (about 12 ns per line and CU; the walk, at a quarter of the occupancy, runs at the same rate per line), and head and tail
-// of a 2.2-line record are practically every line of the stream.  Round 6: the lines are not scattered any more.  A wave takes the
-// records of its block in pieces -- the longest run of records from the current one on that fits kPiece bytes -- and all 64 lanes copy the
-// piece to LDS with coalesced 16-byte loads (1 KB per instruction, the whole stream once); every lane then parses its record from the
-// piece: fixed part, name, CIGAR, tags, and -- for the filters that read them -- bases and qualities all lie there.  A record that does
-// not fit a piece on its own (a long read), or whose size contradicts the chain, takes the path through global memory.  The read-group
-// table is copied to LDS once per workgroup.
-constexpr uint32_t kPiece = 8192;            // bytes per wave: 32 KB per workgroup, four workgroups per CU
+// (Round 6 measured the alternative to the per-lane slots below -- the wave copies the longest run of whole records that fits 8 KB to LDS
+// with coalesced 16-byte loads (global_load_lds_dwordx4: no registers, every load of the piece in flight at once) and every lane parses its
+// record from the piece: the whole stream once, coalesced, instead of head and tail of every record as scattered lines.  Correct (138 GPU
+// tests, whole-share parity at config 2's size) and SLOWER: record_index 6.9 -> 8.2 ms on config 2 (8.9 with two 16-byte loads in flight
+// through registers).  A piece holds 28 records, not 64: the parser's dependent LDS reads (name, CIGAR, the tag scan for RG:Z) cost a turn
+// the same whatever number of lanes is busy, and there are 2.3 x the turns.  profiles/round6/call_k_describe_streamed_*.json.)
+// Staging (round 5).  A lane used to follow its record through global memory field by field -- block_size, the fixed part, the CIGAR
+// operations one by one, then the tag bytes one by one up to RG:Z and the read-group table byte by byte: about twenty DEPENDENT
+// round trips per batch of 64 records; the kernel waits 79 % of its wave cycles (profiles/round4/pmc_sq_config2_full.csv), and the
+// hypothesis was that it waits for that chain.  (It does not: see the note at the kernels below.)  Now the record offsets of the batch give every lane the start of its record AND of the
+// next one, so the head (kStageHead bytes from the record's start) and the tail (the kStageTail bytes in front of the next record: the
+// tags of a record without a long tag list) are fetched with seven independent 16-byte loads, copied to the lane's slot in LDS, and
+// everything is parsed from there -- two round trips to global memory per batch: the offsets, the bytes.  The read-group table
+// is copied to LDS once per workgroup.  A record that does not fit (long name or CIGAR, more than kStageTail bytes of tags, a
+// filter that reads bases or qualities, a size that contradicts the chain) takes the old path through global memory.
+constexpr uint32_t kStageHead = 64, kStageTail = 48, kStageSlot = kStageHead + kStageTail;
 constexpr uint32_t kRgLdsIds = 256, kRgLdsMax = 16;
 static_assert(kRgLdsIds <= (uint32_t)kDescThreads, "the read-group ids are copied to LDS one byte per thread");
-
-// nbytes of the stream into the wave's piece: 64 lanes x 16 bytes per instruction, four instructions in flight (kept out of line so
-// that its sixteen registers are not live across the record parser, whose filter interpreter already fills the budget of 4 waves per SIMD)
-__device__ __noinline__ void stage_piece(const uint8_t* __restrict__ src, uint8_t* __restrict__ piece, uint32_t nbytes, uint32_t lane) {
-    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-    for (uint32_t k0 = 0; k0 < nbytes; k0 += 4096u) {
-        u32x4s v[4];
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            const uint32_t k = k0 + 1024u * q + 16u * lane;
-            if (k < nbytes) v[q] = *(const u32x4s*)(src + k);
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            const uint32_t k = k0 + 1024u * q + 16u * lane;
-            if (k < nbytes) *(u32x4s*)(piece + k) = v[q];
-        }
-    }
-}
 
 template <bool kStage>
 __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     __shared__ uint32_t tot[7];          // records, admitted, malformed, unknown read group of this workgroup's blocks; bytes K3 reads; longest span
-    __shared__ __attribute__((aligned(16))) uint8_t stage[(kDescThreads / 64) * (kPiece + 16)];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kDescThreads * kStageSlot];
     __shared__ __attribute__((aligned(4))) char rg_ids[kRgLdsIds];
     __shared__ uint32_t rg_off[kRgLdsMax];
     __shared__ uint16_t rg_sample[kRgLdsMax];
@@ -918,10 +904,15 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
         if (threadIdx.x < (uint32_t)a.rg.n_rg) { rg_off[threadIdx.x] = a.rg.id_off[threadIdx.x]; rg_sample[threadIdx.x] = a.rg.sample_of[threadIdx.x]; }
         rgv.ids = rg_ids; rgv.id_off = rg_off; rgv.sample_of = rg_sample;
     }
+    // a filter that reads bases or qualities needs the body of the record: no staging
+    bool filt_body = false;
+    for (int k = 0; k < a.filt->n_ops; ++k) {
+        const sbx_filter_op& op = a.filt->ops[k];
+        filt_body = filt_body || op.kind == 13 || (op.kind == 15 && op.field == 1) || (op.kind == 2 && op.field == 7);
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
-    const uint32_t b = blockIdx.x * (kDescThreads / 64) + wv;
+    const uint32_t b = blockIdx.x * (kDescThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
     // (descriptor array too small: nothing is written, the host enlarges it and launches again)
     const uint32_t count = (b < a.n_blocks && !a.flags[2]) ? a.count[b] : 0u;
     uint32_t n_adm = 0, n_bad = 0, n_urg = 0, b_seq = 0, b_qual = 0, m_span = 0;
@@ -930,49 +921,39 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
         const uint64_t base = (a.state[b] & kStateMask) - count;
         const uint16_t* list = rec_list(a.scratch, beg, b);
         const uint64_t chain_exit = a.exit_[b];        // where the record chain leaves the block: the end of its last record
-        uint8_t* const piece = stage + wv * (kPiece + 16);
+        uint8_t* const slot = stage + threadIdx.x * kStageSlot;
         typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-        for (uint32_t i0 = 0; i0 < count;) {
+        for (uint32_t i0 = 0; i0 < count; i0 += 64) {
             const uint32_t i = i0 + lane;
             const bool live = i < count;
-            uint64_t o = 0, o_next = 0;
-            if (live) {
-                o = beg + list[i];
-                o_next = i + 1 < count ? beg + list[i + 1] : chain_exit;
-            }
-            // the piece: from the first record of this turn (16-byte aligned down) over as many whole records as fit -- a prefix of the lanes
-            const uint64_t o_first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)o);
-            const uint64_t p0 = o_first & ~15ull;
-            const uint64_t limit = p0 + kPiece < a.u_alloc ? p0 + kPiece : a.u_alloc;
-            const bool fits = kStage && live && o_next > o && o_next <= limit;
-            const uint64_t fm = __ballot(fits);
-            const uint32_t n_fit = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
-            const uint32_t n_take = n_fit ? n_fit : 1u;       // (a record longer than a piece goes alone, through global memory)
-            if (n_fit) {
-                const uint32_t e_hi = __builtin_amdgcn_readlane((uint32_t)(o_next >> 32), n_fit - 1u), e_lo = __builtin_amdgcn_readlane((uint32_t)o_next, n_fit - 1u);
-                const uint32_t nbytes = (uint32_t)((((uint64_t)e_hi << 32) | e_lo) - p0);       // <= kPiece; the loads may run 15 bytes past it: u_alloc + 64
-                const uint8_t* src = a.U + p0;
-                stage_piece(src, piece, nbytes, lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            const bool mine = live && lane < n_take;
             Described R;
             R.admit = false; R.bad = false; R.urg = false; R.t0 = R.t1 = 0;
             const uint64_t idx = base + i;
-            if (mine) {
-                bool staged = lane < n_fit;
-                const uint8_t* const rp = piece + (uint32_t)(o - p0);
+            if (live) {
+                const uint64_t o = beg + list[i];
+                const uint64_t o_next = i + 1 < count ? beg + list[i + 1] : chain_exit;
+                // (the head may reach up to 64 bytes past the stream: the allocation has that slack, IndexArgs::u_alloc)
+                bool staged = kStage && !filt_body && o_next >= o + 36 && o_next >= kStageTail && o_next <= a.u_alloc;
                 if (staged) {
-                    // does the record's size agree with the chain?  (a record that contradicts it is described -- and reported -- from global memory)
-                    const int64_t bs = (int32_t)ld32(rp);
-                    const uint32_t bmn = ld32(rp + 12), fnc = ld32(rp + 16);
-                    const int32_t l_seq = (int32_t)ld32(rp + 20);
+                    u32x4s h[4], t[3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __builtin_memcpy(&h[k], a.U + o + 16 * k, 16);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) __builtin_memcpy(&t[k], a.U + o_next - kStageTail + 16 * k, 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *(u32x4s*)(slot + 16 * k) = h[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) *(u32x4s*)(slot + kStageHead + 16 * k) = t[k];
+                    // does the record fit the slot, and does its size agree with the chain?
+                    const int64_t bs = (int32_t)h[0].x;
+                    const uint32_t bmn = h[0].w, fnc = h[1].x;
+                    const int32_t l_seq = (int32_t)h[1].y;
                     const int64_t ln = bmn & 0xFFu, nc = fnc & 0xFFFFu;
                     const int64_t fixed = 32 + ln + 4 * nc + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
-                    staged = o_next >= o + 36 && l_seq >= 0 && bs >= fixed && o + 4 + (uint64_t)bs == o_next;
+                    staged = l_seq >= 0 && bs >= fixed && o + 4 + (uint64_t)bs == o_next && 36 + ln + 4 * nc <= (int64_t)kStageHead &&
+                             bs - fixed <= (int64_t)kStageTail;
                 }
-                if (staged) R = describe_record<true>(rp, rp + (uint32_t)(o_next - o), o, a, rgv);
+                if (staged) R = describe_record<true>(slot, slot + kStageSlot, o, a, rgv);
                 else R = describe_record<false>(a.U + o, nullptr, o, a, rgv);
                 a.desc[idx] = R.d;
                 a.rec_ref[idx] = R.ref;
@@ -988,7 +969,7 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
             }
             // records of a wave have consecutive indices, so the lowest index of a tile is held by the first lane of a run
             // of equal tiles and the highest by the last one
-            const bool adm = mine && R.admit;
+            const bool adm = live && R.admit;
             const uint32_t t0 = adm ? R.t0 : 0xFFFFFFFFu;
             const uint32_t t0_prev = __shfl_up(t0, 1, 64), t0_next = __shfl_down(t0, 1, 64);
             if (adm) {
@@ -999,8 +980,6 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
                     atomicMax(&a.tile_hi[t], (uint32_t)idx + 1);
                 }
             }
-            __builtin_amdgcn_wave_barrier();       // the piece is overwritten by the next turn
-            i0 += n_take;
         }
         for (int d = 32; d >= 1; d >>= 1) {
             n_adm += __shfl_xor(n_adm, d, 64);
@@ -1035,7 +1014,11 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     }
 }
 
-// (4 waves per SIMD: the register budget of the filter interpreter; 32 KB of pieces per workgroup -- four workgroups per CU)
+// the staged form at 4 waves per SIMD (124 VGPRs; at 5 waves -- 96 VGPRs and a dozen spills -- it is 0.2 ms slower), and the unstaged
+// body (SBX_K2_DESCRIBE=0).  What staging is worth, measured (profiles/round5/README.md section 2): against the unstaged body of THIS
+// build 1.07 ms of config 2's record_index -- but against round 4's kernel under the profiler 4.52 -> 4.38 ms, 3 %: the unstaged body
+// compiled into this template is slower than round 4's kernel was.  `describe` does not wait for its chain of dependent loads; it runs
+// at the rate of scattered 128-byte lines a CU sustains (the walk, with a quarter of the occupancy, runs at the same rate per line).
 __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_blocks(IndexArgs a) { describe_blocks_body<true>(a); }
 
 // ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
