@@ -948,8 +948,9 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t
 // round 5: correct, and 37 % SLOWER than this kernel (30.6 against 22.4 ms on config 2; more instructions of every kind, not fewer:
 // profiles/round5/README.md).  It is gone; what it left is the lesson that the rounds of phase B are cheap -- see kExact below.)
 // (kAblate: tools/k1_lab compiles parts of the batch loop out to time them; 0 in the product)
-// (kTail16, lab A/B: the second 16 bytes of a 17 .. 32-byte own-lane copy as ONE 16-byte word at offset n - 16 instead of a second Short16 step)
-template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0, bool kTail16 = false>
+// (kTail16: the second 16 bytes of a 17 .. 32-byte own-lane copy as ONE 16-byte word at offset n - 16 -- it overlaps what the first step
+// copied -- instead of a second Short16 step: 3.16 -> 3.05 ms at 40 Mbp, profiles/round6/call_j_k1b_tail16_40Mbp.jsonl; false: the A/B partner)
+template <uint32_t kHist, uint32_t kSpanMax, bool kOwn32, bool kExact, uint32_t kAblate = 0, bool kTail16 = true>
 __device__ __forceinline__ void lz77_resolve_body(
     const uint8_t* __restrict__ lit_stream, const uint32_t* __restrict__ ent_stream, const uint32_t* __restrict__ n_entries,
     const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ isize, uint32_t n_blocks, uint32_t block0,
