@@ -1006,14 +1006,14 @@ def main():
 
 
 PMC_KERNELS = {"huffman_decode": ["k_huffman_decode", "k_huffman_decode2", "k_translate_literals"],
-               "lz77_resolve": ["k_lz77_resolve", "k_lz77_resolve_o32", "k_lz77_resolve_o32_w8", "k_lz77_resolve_o32_u", "k_lz77_resolve_o32_f",
-                                "k_lz77_resolve_exact"],
-               "record_index": ["k_walk_blocks", "k_check_scan", "k_check_scan_mw", "k_describe_blocks", "k_describe_blocks_r4", "k_tile_compact", "k_tile_compact_mw", "k_chain_repair", "k_rewalk_mismatched"],
-               "decode_accumulate": ["k_accumulate16", "k_accumulate16b", "k_accumulate16c", "k_accumulate", "k_accumulate_mates", "k_find_mates",
-                                     "k_find_partners", "k_mates_columns", "k_max_u32"]}
+               "lz77_resolve": ["k_lz77_resolve_exact"],
+               "record_index": ["k_walk_blocks", "k_check_scan", "k_check_scan_mw", "k_describe_blocks", "k_tile_compact", "k_tile_compact_mw", "k_chain_repair",
+                                "k_rewalk_mismatched"],
+               "decode_accumulate": ["k_accumulate16", "k_accumulate16c", "k_accumulate", "k_accumulate_mates", "k_find_mates_join", "k_find_partners",
+                                     "k_mates_columns", "k_max_u32"]}
 
 
-KERNEL_SOURCES = ["inflate.hip", "inflate2_core.hpp", "index.hip", "depth.hip", "mates.hip", "reduce.hip", "common.hpp", "kernels.hpp"]
+KERNEL_SOURCES = ["inflate.hip", "inflate2_core.hpp", "lz77_copy.hpp", "index.hip", "depth.hip", "mates.hip", "reduce.hip", "common.hpp", "kernels.hpp"]
 CLOCK_GHZ = 2.4          # what the SIMDs run at under these kernels (GRBM_GUI_ACTIVE / duration: 2.35-2.43, profiles/round4/README.md)
 N_SIMD = 1024
 
