@@ -16,12 +16,12 @@ mkdir -p $RAW
 export TMPDIR=/tmp
 STAMP=$(python -c "import bench; print(bench.kernel_sources_hash())")
 cd /tmp
-B="python $REPO/bench.py --config $CFG $EXTRA --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --parity-windows 0 --no-full-parity"
+B="python $REPO/bench.py --config $CFG $EXTRA --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --parity-windows 0 --no-full-parity --no-side-runs"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/fetch -o p -- $B > /dev/null 2> $RAW/fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $RAW/write -o p -- $B > /dev/null 2> $RAW/write.err
 timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d $RAW/sq1 -o p -- $B > /dev/null 2> $RAW/sq1.err
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $RAW/sq2 -o p -- $B > /dev/null 2> $RAW/sq2.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- python $REPO/bench.py --config $CFG $EXTRA --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --parity-windows 0 --no-full-parity > $OUT/bench_config${CFG}_under_rocprofv3.json 2> $RAW/kt.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- python $REPO/bench.py --config $CFG $EXTRA --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --parity-windows 0 --no-full-parity --no-side-runs > $OUT/bench_config${CFG}_under_rocprofv3.json 2> $RAW/kt.err
 cd $REPO
 python - "$RAW" "$OUT" "$CFG" "$STAMP" <<'PY'
 import csv, glob, collections, re, sys, subprocess
