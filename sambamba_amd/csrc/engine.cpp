@@ -240,6 +240,10 @@ struct sbx_ctx {
     // spare position tiles behind the last position of every contig, for alignments hanging over its end; enlarged (and kept) when a
     // pass meets an alignment that reaches beyond them (run_impl); spare_of_run: what the last pass was laid out with
     uint32_t spare_tiles = 1, spare_of_run = 0;
+    // > 0 while sbx_stream_base_rows is handing text out.  The one call allowed on another thread meanwhile is
+    // sbx_prefetch_interval: it touches the work list, the compressed bytes and the block tables (make_resident) -- nothing the text path
+    // reads (counters, slot_of, tile_base, span, the format buffers).  A RUN replaces exactly those: it refuses while text is streaming.
+    std::atomic<int> text_streaming{0};
     bool span_valid = false;
     std::vector<uint32_t> h_tile_base, h_slot_of;
     sbx_run_stats stats{};
@@ -1482,6 +1486,8 @@ static void merge_members(sbx_ctx* c) {
 }
 
 static void run_files(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restricted) {
+    if (c->text_streaming.load() > 0)
+        throw Error(SBX_EINVAL, "a run was started while sbx_stream_base_rows is handing out text of this context (only sbx_prefetch_interval may run next to it)");
     const auto files = files_of(c);
     for (sbx_ctx* m : files) run_impl(m, sel, restricted);
     // several files share one tile grid: a file that had to enlarge its spare tiles (run_impl) makes the others follow
@@ -2479,7 +2485,11 @@ int sbx_stream_base_rows(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32_t end
         if (!c || !write) throw Error(SBX_EINVAL, "null argument");
         check_base_run(c, ref_id, beg, end, "sbx_stream_base_rows");
         if (beg == end) return;
-        SBX_HIP(hipSetDevice(c->device));
+        struct Streaming {
+            std::atomic<int>& n;
+            explicit Streaming(std::atomic<int>& x) : n(x) { n.fetch_add(1); }
+            ~Streaming() { n.fetch_sub(1); }
+        } streaming_guard(c->text_streaming);
         hipStream_t s = c->stream;
         FormatArgs a = format_args(c, ref_id, min_cov, max_cov, annotate, s);
         uint64_t piece = 2u << 20;                // positions per piece (~55 MB of text at one sample, 30x: the two pinned buffers

@@ -127,10 +127,16 @@ def test_d_glue_covers_or_refuses_every_stateful_corner_of_the_compiled_host():
     d = open(os.path.join(ROOT, "d", "sbx_depth.d")).read()
     cli = open(os.path.join(ROOT, "sambamba_amd", "csrc", "cli.cpp")).read()
     body = d[d.index("bool sbxDepthRun("):]
-    # refusals
-    assert "o.mode == SBX_MODE_BASE && o.merged_bed.length && o.min_cov <= 0) return false" in body      # base -L with -c 0
+    # the one refusal left (round 6: the two base-mode corners are printed on the host from the device's counters, as cli.cpp does)
     assert "o.mode == SBX_MODE_WINDOW && o.overlap != 0) return false" in body                            # window --overlap
-    assert "if (ob != ulong.max) return false;" in body                                                   # base -c 0 with over-hanging alignments
+    assert body[:body.index("sbx_ctx* sbxOpen(")].count("return false") == 1
+    # base -L with -c 0, and base -c 0 with over-hanging alignments: PerBasePrinter's rules, member for member of cli.cpp's BasePrinter
+    for cli_name, d_name in (("void write_empty(", "void writeEmpty("), ("void write_column(", "void writeColumn("), ("void push(", "void push("),
+                             ("void close()", "void close()"), ("bool output_required(", "bool outputRequired("), ("void init_tails()", "void initTails()")):
+        assert cli_name in cli and d_name in d, (cli_name, d_name)
+    assert "const bool base_host = o.mode == SBX_MODE_BASE && o.merged_bed.length && o.min_cov <= 0;" in body
+    assert "if (base_host) { hp.runRefs(r0, r1); continue; }" in body and "if (base_host) hp.close();" in body
+    assert "hp.writeColumn(cast(int) r, cast(long)(ob + x)" in body                                      # columns behind a contig's end
     # rules carried over (each named after the cli.cpp member that implements it)
     for cli_name, d_name in (("first_column(", "firstColumn("), ("last_column(", "lastColumn("), ("pending_empty_", "base_pending_empty"),
                              ("pending_empty", "win_pending_empty"), ("stale_st", "stale_st"), ("zero_windows(", "zeroWindows("),
