@@ -107,7 +107,6 @@ struct sbx_ctx {
     bool compact_counters = false;
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr, text_stream = nullptr;     // compute; file bytes host -> device; text device -> host
-    InflateOverlap k1_overlap;        // the side stream of K1's overlapped schedule (launch_bgzf_inflate)
     FileMap file;
     BlockTable blocks;
     BamHeaderInfo hdr;
@@ -544,7 +543,7 @@ void inflate_worklist(sbx_ctx* c, hipEvent_t ev_mid) {
     c->d_tok.ensure(64);
     SBX_HIP(hipMemsetAsync(c->d_tok.p, 0, 64 * 8, c->stream));
     launch_bgzf_inflate(c->d_comp.p, c->d_comp_off.p, c->d_comp_len.p, c->d_isize.p, c->d_out_off.p, c->d_U.p, n, 0, c->d_scratch.p,
-                        c->d_lit.p, c->d_ent.p, c->d_nent.p, c->d_status.p, c->stream, ev_mid, c->d_tok.p, &c->k1_overlap);
+                        c->d_lit.p, c->d_ent.p, c->d_nent.p, c->d_status.p, c->stream, ev_mid, c->d_tok.p);
 }
 
 // inflates the first k BGZF blocks of the file into host memory (BAM header at open)
@@ -725,7 +724,6 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
         SBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SBX_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         SBX_HIP(hipStreamCreateWithFlags(&c->text_stream, hipStreamNonBlocking));
-        inflate_overlap_create(&c->k1_overlap, c->device);
         const double t1 = now();
         host.join();
         host_joined = true;
@@ -794,7 +792,6 @@ sbx_ctx* sbx_open(const char* const* bam_paths, int n_bams, int device, char* er
         if (c && c->stream) (void)hipStreamDestroy(c->stream);
         if (c && c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         if (c && c->text_stream) (void)hipStreamDestroy(c->text_stream);
-        if (c) inflate_overlap_destroy(&c->k1_overlap);
         return nullptr;
     }
 }
@@ -805,7 +802,6 @@ void sbx_close(sbx_ctx* c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->text_stream) { (void)hipStreamSynchronize(c->text_stream); (void)hipStreamDestroy(c->text_stream); }
-    inflate_overlap_destroy(&c->k1_overlap);
     delete c;
 }
 
@@ -1183,20 +1179,13 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
             c->desc_cap = want_cap;
         }
         if (c->fix_mate) c->d_name_hash.ensure((size_t)c->desc_cap + 64);
-        // LAB (SBX_LAB_CORUN, not for production): from the second pass on K2 is enqueued on another stream behind K1a only -- it runs NEXT TO
-        // K1b on the bytes the previous pass left in U (the same file: the same bytes) -- to measure what hiding K2 behind K1b could be worth
-        static const bool lab_corun = getenv("SBX_LAB_CORUN") != nullptr;
-        static int lab_runs = 0;
-        const bool corun = lab_corun && attempt == 0 && lab_runs++ >= 1;
-        hipStream_t sk2 = corun ? c->text_stream : s;
-        if (corun) SBX_HIP(hipStreamWaitEvent(sk2, t1m.b, 0));
-        SBX_HIP(hipMemsetAsync(c->d_tile_lo.p, 0xFF, (size_t)nt * 4, sk2));
-        SBX_HIP(hipMemsetAsync(c->d_tile_hi.p, 0, (size_t)nt * 4, sk2));
-        SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats) * kIndexStatSlots, sk2));
-        SBX_HIP(hipMemsetAsync(c->d_state.p, 0, ((size_t)nb + 1) * 8, sk2));
-        SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 8, sk2));           // [0] first inconsistent block, [1] first failed inflate
-        SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 24, sk2));         // [2] overflow, [3] ticket, [4] rewalked, [5] max partners, [6] K3 -m overflow
-        SBX_HIP(hipMemsetAsync(c->d_flag.p + 8, 0xFF, 8, sk2));       // [8..9] start of the record behind an open-ended run (64 bits)
+        SBX_HIP(hipMemsetAsync(c->d_tile_lo.p, 0xFF, (size_t)nt * 4, s));
+        SBX_HIP(hipMemsetAsync(c->d_tile_hi.p, 0, (size_t)nt * 4, s));
+        SBX_HIP(hipMemsetAsync(c->d_stats.p, 0, sizeof(IndexStats) * kIndexStatSlots, s));
+        SBX_HIP(hipMemsetAsync(c->d_state.p, 0, ((size_t)nb + 1) * 8, s));
+        SBX_HIP(hipMemsetAsync(c->d_flag.p, 0xFF, 8, s));           // [0] first inconsistent block, [1] first failed inflate
+        SBX_HIP(hipMemsetAsync(c->d_flag.p + 2, 0, 24, s));         // [2] overflow, [3] ticket, [4] rewalked, [5] max partners, [6] K3 -m overflow
+        SBX_HIP(hipMemsetAsync(c->d_flag.p + 8, 0xFF, 8, s));       // [8..9] start of the record behind an open-ended run (64 bits)
         IndexArgs a{};
         a.U = c->d_U.p;
         a.u_alloc = (w.u_bytes + 15) & ~15ull;
@@ -1206,24 +1195,15 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         a.entry_in = entries_given ? c->d_entry.p : nullptr;
         a.entry = c->d_entry.p; a.exit_ = c->d_exit.p; a.count = c->d_count.p;
         a.state = c->d_state.p; a.scratch = c->d_lit.p;
-        if (lab_corun) {        // (the record lists must not land in the literal stream K1b is reading)
-            static DevBuf<uint8_t> lab_lists;
-            lab_lists.ensure(inflate_lit_bytes(w.u_bytes, nb));
-            a.scratch = lab_lists.p;
-        }
         a.refs = refs; a.filt = c->d_filter.p; a.rg = rg; a.tile_pos = T;
         a.desc = c->d_desc.p; a.rec_ref = c->d_rec_ref.p; a.name_hash = c->fix_mate ? c->d_name_hash.p : nullptr;
         a.desc_cap = c->desc_cap;
         a.tile_lo = c->d_tile_lo.p; a.tile_hi = c->d_tile_hi.p; a.stats = c->d_stats.p; a.flags = c->d_flag.p;
         a.scan_part = c->d_scan_part.p;
         a.own_ref = c->own_ref; a.own_beg = c->own_beg; a.own_end = c->own_end;
-        launch_index_blocks(a, sk2);
-        launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, deep_thr, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, sk2,
+        launch_index_blocks(a, s);
+        launch_tile_compact(c->d_tile_lo.p, c->d_tile_hi.p, (uint32_t)nt, deep_thr, c->d_active.p, c->d_slot_of.p, c->d_n_active.p, s,
                             c->d_scan_part.p);
-        if (corun) {
-            SBX_HIP(hipEventRecord(c->k1_overlap.ev_main, sk2));
-            SBX_HIP(hipStreamWaitEvent(s, c->k1_overlap.ev_main, 0));
-        }
         if (attempt == 0) t2.stop(s);
         R.last_state = 0;
         SBX_HIP(hipMemcpyAsync(R.flags, c->d_flag.p, 16, hipMemcpyDeviceToHost, s));

@@ -769,25 +769,19 @@ __global__ __launch_bounds__(kInfThreads) void k_huffman_decode(
 // kernel: 7) and the 3,379 wavefronts of a chromosome-sized file are resident at once.  Blocks it does not decode are flagged
 // kNeedsGeneral and decoded by k_huffman_decode in a second launch.
 constexpr int kInf2Threads = 64;
-// kWaves wavefronts per workgroup: 1 in the ordinary launch; 4 in the balanced launch of launch_bgzf_inflate's overlapped schedule -- the
-// four wavefronts of a workgroup go to the four SIMDs of its CU, so that N workgroups per CU are N wavefronts on EVERY SIMD (single
-// wavefronts are not spread evenly: 12 of them on a CU left some SIMDs with 4, profiles/round6/call_n_*).
-template <int kWaves>
-__global__ __launch_bounds__(kInf2Threads * kWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_huffman_decode2(
+__global__ __launch_bounds__(kInf2Threads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_huffman_decode2(
     const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
     const uint32_t* __restrict__ isize, const uint64_t* __restrict__ out_off, uint32_t n_blocks, uint32_t block0,
     uint8_t* __restrict__ lit_stream, uint32_t* __restrict__ ent_stream, uint32_t* __restrict__ n_entries,
-    uint8_t* __restrict__ scratch, uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes, uint32_t raise_prio) {
+    uint8_t* __restrict__ scratch, uint32_t* __restrict__ status, unsigned long long* __restrict__ tok_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // (the tail launch of launch_bgzf_inflate's overlapped schedule runs next to K1b's wavefronts: its few long serial chains go first)
-    if (raise_prio) __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t b_raw = blockIdx.x * (kInf2Threads * kWaves) + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b_raw = blockIdx.x * kInf2Threads + lane;
     const bool live = b_raw < n_blocks;
     const uint32_t b = live ? b_raw : n_blocks - 1;
-    uint16_t* const len_tab = (uint16_t*)(smem + kWaves * inf2::kWaveLds);
-    uint32_t* const dist_tab = (uint32_t*)(smem + kWaves * inf2::kWaveLds + inf2::kLenTabBytes);
-    if (threadIdx.x < 32u) inf2::rfc_tables_entry(threadIdx.x, &len_tab[threadIdx.x], &dist_tab[threadIdx.x]);
+    uint16_t* const len_tab = (uint16_t*)(smem + inf2::kWaveLds);
+    uint32_t* const dist_tab = (uint32_t*)(smem + inf2::kWaveLds + inf2::kLenTabBytes);
+    if (lane < 32u) inf2::rfc_tables_entry(lane, &len_tab[lane], &dist_tab[lane]);
     __syncthreads();
     const uint64_t oo = out_off[b];
     inf2::LaneIo io;
@@ -799,7 +793,7 @@ __global__ __launch_bounds__(kInf2Threads * kWaves) __attribute__((amdgpu_waves_
     io.scratch = scratch + (size_t)b * kScratchStride;
     io.live = live;
     inf2::Lane L;
-    const inf2::LaneResult R = L.run(io, smem + wv * inf2::kWaveLds, lane, len_tab, dist_tab);
+    const inf2::LaneResult R = L.run(io, smem, lane, len_tab, dist_tab);
     if (live) {
         status[b] = R.status;
         n_entries[b] = R.n_ent;
@@ -807,7 +801,7 @@ __global__ __launch_bounds__(kInf2Threads * kWaves) __attribute__((amdgpu_waves_
     if (tok_bytes) {
         unsigned long long t = live && R.status == 0u ? (unsigned long long)R.n_lit + 4ull * R.n_ent : 0ull;
         for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
-        if (lane == 0) atomicAdd(tok_bytes + ((blockIdx.x * kWaves + wv) & 63u), t);
+        if (lane == 0) atomicAdd(tok_bytes + (blockIdx.x & 63u), t);
     }
 }
 
@@ -1217,23 +1211,18 @@ struct InflateArgs {
 };
 
 // K1a of a range of blocks: the fast kernel, the general one for the blocks that one flagged, the literal translation
-void launch_k1a(const InflateArgs& a, hipStream_t stream, int waves_per_wg = 1, uint32_t raise_prio = 0, size_t lds_min = 0) {
+void launch_k1a(const InflateArgs& a, hipStream_t stream) {
     if (a.n_blocks == 0) return;
     // SBX_K1A=1: round 3's kernel alone (the general kernel: every kind of block); default: the fast kernel, then the general one for
     // the blocks the fast one flagged (a wavefront without a flagged block ends at once), then the literal translation
     static const int k1a = [] { const char* e = getenv("SBX_K1A"); return e ? atoi(e) : 2; }();
     if (k1a != 1) {
+        dim3 grid((a.n_blocks + kInf2Threads - 1) / kInf2Threads), block(kInf2Threads);
         // (SBX_K1A_LDS_PAD: extra LDS per workgroup -- an occupancy experiment)
         static const size_t pad = [] { const char* e = getenv("SBX_K1A_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-        const size_t lds = std::max((size_t)waves_per_wg * inf2::kWaveLds + inf2::kLenTabBytes + inf2::kDistTabBytes + pad, lds_min);
-        const uint32_t per = (uint32_t)(kInf2Threads * waves_per_wg);
-        dim3 grid((a.n_blocks + per - 1) / per), block(per);
-        if (waves_per_wg == 4)
-            hipLaunchKernelGGL(k_huffman_decode2<4>, grid, block, lds, stream, a.comp, a.comp_off, a.comp_len, a.isize, a.out_off, a.n_blocks, a.block0,
-                               a.lit, a.ent, a.nent, a.scratch, a.status, a.tok, raise_prio);
-        else
-            hipLaunchKernelGGL(k_huffman_decode2<1>, grid, block, lds, stream, a.comp, a.comp_off, a.comp_len, a.isize, a.out_off, a.n_blocks, a.block0,
-                               a.lit, a.ent, a.nent, a.scratch, a.status, a.tok, raise_prio);
+        const size_t lds = (size_t)inf2::kWaveLds + inf2::kLenTabBytes + inf2::kDistTabBytes + pad;
+        hipLaunchKernelGGL(k_huffman_decode2, grid, block, lds, stream, a.comp, a.comp_off, a.comp_len, a.isize, a.out_off, a.n_blocks, a.block0,
+                           a.lit, a.ent, a.nent, a.scratch, a.status, a.tok);
         SBX_HIP(hipGetLastError());
     }
     {
@@ -1264,74 +1253,17 @@ void launch_k1b(const InflateArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-void inflate_overlap_create(InflateOverlap* ov, int device) {
-    hipDeviceProp_t prop;
-    SBX_HIP(hipGetDeviceProperties(&prop, device));
-    ov->n_cu = (uint32_t)prop.multiProcessorCount;
-    ov->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
-    int least = 0, greatest = 0;
-    SBX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    SBX_HIP(hipStreamCreateWithPriority(&ov->side, hipStreamNonBlocking, greatest));
-    SBX_HIP(hipEventCreateWithFlags(&ov->ev_main, hipEventDisableTiming));
-    SBX_HIP(hipEventCreateWithFlags(&ov->ev_tail, hipEventDisableTiming));
-    if (const char* e = getenv("SBX_K1_WAVES_PER_CU")) ov->waves_per_cu = atoi(e);       // 0: the one-launch schedule
-    if (const char* e = getenv("SBX_K1_TAIL_PRIO")) ov->raise_prio = atoi(e) != 0;
-    if (const char* e = getenv("SBX_K1_SPLIT_BLOCKS")) ov->split_blocks = (uint32_t)atol(e);     // test hook: the main part in blocks
-}
-
-void inflate_overlap_destroy(InflateOverlap* ov) {
-    if (ov->side) { (void)hipStreamSynchronize(ov->side); (void)hipStreamDestroy(ov->side); ov->side = nullptr; }
-    if (ov->ev_main) { (void)hipEventDestroy(ov->ev_main); ov->ev_main = nullptr; }
-    if (ov->ev_tail) { (void)hipEventDestroy(ov->ev_tail); ov->ev_tail = nullptr; }
-}
-
-// The schedule.  K1a is one lane per BGZF block and a lane's chain through its block is serial, so a launch is as slow as the SIMD
-// that holds the most wavefronts: the 3,379 wavefronts of a chromosome are 3 on 717 SIMDs and 4 on 307 of an MI355X, and the launch
-// takes what FOUR cost (the occupancy sweep of profiles/round4: a balanced 3 per SIMD finishes in 3/4 of the time, the 307 left over
-// need a lone wavefront's ~10 ms however idle the device is).  With an InflateOverlap the blocks are therefore cut in two:
-//   main   whole multiples of waves_per_cu x CUs wavefronts -- the LDS request is padded so that exactly waves_per_cu fit a CU: every
-//          SIMD holds the same number;
-//   tail   the rest, on the side stream (highest stream priority, s_setprio inside the kernel) NEXT TO K1b of the main part: K1b is
-//          issue-bound and has 26 rounds of wavefronts to go, the tail's few long chains hide behind it, and so does the tail's own K1b.
-// Without one (or when the blocks fit the balanced launch, or SBX_K1_WAVES_PER_CU=0): K1a, then K1b.
 void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_len,
                          const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
                          uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
-                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid, unsigned long long* d_tok_bytes, const InflateOverlap* ov) {
+                         uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid, unsigned long long* d_tok_bytes) {
     if (n_blocks == 0) { if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream)); return; }
     const InflateArgs all{d_comp, d_comp_off, d_comp_len, d_isize, d_out_off, d_out, n_blocks, block0, d_scratch, d_lit, d_ent, d_nent, d_status, d_tok_bytes};
-    uint32_t n_main = 0;
-    size_t lds_bal = 0;
-    int wpw = 1;
-    if (ov && ov->side && ov->waves_per_cu > 0 && ov->n_cu > 0) {
-        // waves_per_cu a multiple of 4: workgroups of four wavefronts, one per SIMD.  The LDS request is the largest of which exactly
-        // waves_per_cu / wpw workgroups fit a CU (gfx950 hands out LDS in pieces of 1,280 bytes; 65,280 is the most a launch may ask for)
-        wpw = ov->waves_per_cu % 4 == 0 ? 4 : 1;
-        const uint32_t wgs = (uint32_t)ov->waves_per_cu / (uint32_t)wpw;
-        constexpr size_t kLdsGranule = 1280;
-        const size_t lds_base = (size_t)wpw * inf2::kWaveLds + inf2::kLenTabBytes + inf2::kDistTabBytes;
-        lds_bal = std::min<size_t>((size_t)ov->lds_per_cu / wgs / kLdsGranule * kLdsGranule, 65280);
-        const uint32_t cap = (uint32_t)ov->waves_per_cu * ov->n_cu * (uint32_t)kInf2Threads;
-        if (lds_bal >= lds_base && (size_t)(wgs + 1) * lds_bal > ov->lds_per_cu && n_blocks > cap) n_main = n_blocks / cap * cap;
-        // (tests/test_gpu_inflate.py: the two-stream schedule on inputs of a few hundred blocks)
-        if (ov->split_blocks) { lds_bal = 0; n_main = n_blocks > ov->split_blocks ? n_blocks / ov->split_blocks * ov->split_blocks : 0; }
-    }
-    if (n_main == 0 || n_main == n_blocks) {
-        launch_k1a(all, stream);
-        if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream));
-        launch_k1b(all, stream);
-        return;
-    }
-    const InflateArgs mainp = all.slice(0, n_main), tail = all.slice(n_main, n_blocks - n_main);
-    launch_k1a(mainp, stream, wpw, 0, lds_bal);
+    // (measured and dropped, profiles/round4/README.md: K1a of the second half of the blocks on a second stream next to K1b of the first half --
+    // the two kernels do not fill each other's issue slots, the inflate takes 51-54 ms instead of 48)
+    launch_k1a(all, stream);
     if (ev_mid) SBX_HIP(hipEventRecord(ev_mid, stream));
-    SBX_HIP(hipEventRecord(ov->ev_main, stream));
-    SBX_HIP(hipStreamWaitEvent(ov->side, ov->ev_main, 0));
-    launch_k1a(tail, ov->side, 1, ov->raise_prio ? 1u : 0u);
-    launch_k1b(tail, ov->side);
-    SBX_HIP(hipEventRecord(ov->ev_tail, ov->side));
-    launch_k1b(mainp, stream);
-    SBX_HIP(hipStreamWaitEvent(stream, ov->ev_tail, 0));
+    launch_k1b(all, stream);
 }
 
 const char* inflate_status_string(uint32_t s) {

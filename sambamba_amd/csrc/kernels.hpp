@@ -94,19 +94,7 @@ void launch_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
                          const uint32_t* d_isize, const uint64_t* d_out_off, uint8_t* d_out, uint32_t n_blocks,
                          uint32_t block0, uint8_t* d_scratch, uint8_t* d_lit, uint32_t* d_ent, uint32_t* d_nent,
                          uint32_t* d_status, hipStream_t stream, hipEvent_t ev_mid = nullptr,
-                         unsigned long long* d_tok_bytes = nullptr,      // [64] += literal bytes + 4 x match entries (accounting; may be null)
-                         const struct InflateOverlap* ov = nullptr);     // the overlapped schedule (inflate.hip), or K1a then K1b on `stream`
-// A second stream and the events that tie it to the caller's: what the overlapped schedule of launch_bgzf_inflate needs.  Owned by
-// the caller (one per context); waves_per_cu = K1a wavefronts per compute unit of the balanced launch (0: the one-launch schedule).
-struct InflateOverlap {
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_tail = nullptr;
-    uint32_t n_cu = 0, lds_per_cu = 0, split_blocks = 0;
-    int waves_per_cu = 12;
-    bool raise_prio = true;
-};
-void inflate_overlap_create(InflateOverlap* ov, int device);
-void inflate_overlap_destroy(InflateOverlap* ov);
+                         unsigned long long* d_tok_bytes = nullptr);     // [64] += literal bytes + 4 x match entries (accounting; may be null)
 const char* inflate_status_string(uint32_t s);
 
 // ---- K2: record index (index.hip) ---------------------------------------------------------

@@ -134,29 +134,3 @@ def test_inflate_bench_like_bam_bit_exact(tmp_path):
     got = sambamba_amd.inflate_blocks(data, co, cl, isz, oo, total)
     want = oracle_inflate_all(path)
     assert got.shape == want.shape and np.array_equal(got, want)
-
-
-@pytest.mark.parametrize("split_blocks", [7, 64])
-def test_overlapped_schedule_inflates_the_same_bytes(tmp_path, monkeypatch, split_blocks):
-    """K1's two-stream schedule (launch_bgzf_inflate with an InflateOverlap: a balanced K1a launch, its tail on a side stream next to K1b
-    of the main part) only happens above ~200 k BGZF blocks; SBX_K1_SPLIT_BLOCKS cuts a small input the same way.  The counters of the
-    whole pass -- every block inflated, indexed and accumulated -- must equal the oracle's, and the run must report the same records."""
-    import sambamba_amd
-    from tests.util import gen_bam, oracle_base_counters
-    path = gen_bam(str(tmp_path / "o.bam"), "chrO:260000", coverage=30, seed=78)
-    _, _, cl, _, _, _ = scan_bgzf(path)
-    assert len(cl) > 2 * split_blocks + 3          # main part of several pieces and a tail
-    results = []
-    for env in (None, str(split_blocks)):
-        if env is None:
-            monkeypatch.delenv("SBX_K1_SPLIT_BLOCKS", raising=False)
-        else:
-            monkeypatch.setenv("SBX_K1_SPLIT_BLOCKS", env)
-        with sambamba_amd.Depth(path) as d:
-            d.set_params()
-            st = d.run()
-            results.append((st["n_records"], st["n_admitted"], d.base_counters(0, 0, d.ref_lengths[0])))
-    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
-    assert np.array_equal(results[0][2], results[1][2])
-    want = oracle_base_counters(path, 0, 0, results[1][2].shape[0], n_samples=results[1][2].shape[1])
-    assert np.array_equal(results[1][2], want)

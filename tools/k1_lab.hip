@@ -165,52 +165,6 @@ int main(int argc, char** argv) {
             lab.k1b_geo<3072, 1536>();
             lab.k1b_geo<4096, 1536>();
         }
-        if (argc > 3 && std::string(argv[3]) == "split") {
-            // the overlapped schedule of launch_bgzf_inflate (balanced K1a launch; its tail on a side stream next to K1b) against K1a, then K1b
-            const InflateArgs& a = lab.a;
-            auto whole = [&](const InflateOverlap* ov) {
-                launch_bgzf_inflate(a.comp, a.comp_off, a.comp_len, a.isize, a.out_off, a.out, a.n_blocks, a.block0, a.scratch, a.lit, a.ent, a.nent, a.status,
-                                    lab.stream, nullptr, a.tok, ov);
-            };
-            int dev = 0;
-            SBX_HIP(hipGetDevice(&dev));
-            InflateOverlap ov;
-            inflate_overlap_create(&ov, dev);
-            fprintf(stderr, "CUs %u, LDS per CU %u\n", ov.n_cu, ov.lds_per_cu);
-            for (int rep = 0; rep < 2; ++rep) {
-                double ms = lab.time([&] { whole(nullptr); });
-                printf("{\"schedule\": \"K1a, then K1b\", \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", ms, lab.last_mean);
-                if (rep == 0) lab.check();
-                for (int wpc : {12, 8, 13, 10}) {
-                    for (int prio = 1; prio >= 0; --prio) {
-                        if (rep == 1 && (prio == 0 || wpc != 12)) continue;
-                        ov.waves_per_cu = wpc;
-                        ov.raise_prio = prio != 0;
-                        ms = lab.time([&] { whole(&ov); });
-                        printf("{\"schedule\": \"overlapped\", \"waves_per_cu\": %d, \"tail_prio\": %d, \"ms_best\": %.4f, \"ms_mean\": %.4f}\n", wpc, prio, ms, lab.last_mean);
-                        if (rep == 0 && prio == 1) lab.check();
-                        fflush(stdout);
-                    }
-                }
-            }
-            // the balanced launch alone, and the tail alone (what the two parts of K1a cost when nothing runs next to them)
-            for (int wpc : {12, 8}) {
-                const uint32_t cap = (uint32_t)wpc * ov.n_cu * 64u;
-                if (a.n_blocks <= cap) continue;
-                const size_t lds_bal = std::min<size_t>((size_t)ov.lds_per_cu / (wpc / 4) / 1280 * 1280, 65280);
-                double ms = lab.time([&] { launch_k1a(a.slice(0, cap), lab.stream, 4, 0, lds_bal); });
-                printf("{\"kernel\": \"k1a main alone, workgroups of 4 wavefronts\", \"waves_per_cu\": %d, \"blocks\": %u, \"ms_best\": %.4f}\n", wpc, cap, ms);
-                ms = lab.time([&] { launch_k1a(a.slice(cap, a.n_blocks - cap), lab.stream, 1, 1); });
-                printf("{\"kernel\": \"k1a tail alone\", \"waves_per_cu\": %d, \"blocks\": %u, \"ms_best\": %.4f}\n", wpc, a.n_blocks - cap, ms);
-                fflush(stdout);
-            }
-            {   // every block in workgroups of four wavefronts (three per CU resident, the rest in a second round)
-                double ms = lab.time([&] { launch_k1a(a, lab.stream, 4); });
-                printf("{\"kernel\": \"k1a, all blocks, workgroups of 4 wavefronts\", \"ms_best\": %.4f}\n", ms);
-            }
-            inflate_overlap_destroy(&ov);
-            return 0;
-        }
         if (argc > 3 && std::string(argv[3]) == "ablate") {
             lab.k1b<1>("no literal copies (own + coop)");
             lab.k1b<2>("no far-match copies (own + coop)");
