@@ -12,9 +12,11 @@
 //
 // Two passes over the counter tiles with the same emitter: pass 1 only adds up the bytes of every
 // 256-position chunk, a scan turns them into offsets, pass 2 builds each chunk's text in LDS (one
-// position per lane) and streams it to HBM 16 bytes per lane, contiguous.  HBM-bound: 28 B of counters
-// read twice + ~35 B of text written per position and sample.
+// position per lane; rows assembled in registers and stored eight bytes at a time, format_core.hpp)
+// and streams it to HBM 16 bytes per lane, contiguous.  HBM-bound: 28 B of counters read twice +
+// ~35 B of text written per position and sample.
 #include "common.hpp"
+#include "format_core.hpp"
 #include "kernels.hpp"
 
 namespace sbx {
@@ -22,46 +24,12 @@ namespace sbx {
 namespace {
 
 constexpr int kFmtThreads = 256;
-constexpr uint32_t kFmtLds = 48 * 1024;     // text of one chunk; chunks that do not fit are written byte-wise to HBM
+constexpr uint32_t kFmtLds = 24 * 1024;     // text of one chunk (rows of up to 96 bytes on average); chunks that do not fit go straight to HBM
 
-__device__ __forceinline__ uint32_t n_digits(uint64_t v) {
-    uint32_t n = 1;
-    if (v >= 10000000000ull) { v /= 10000000000ull; n += 10; }
-    const uint32_t w = (uint32_t)v;
-    n += (w >= 10u) + (w >= 100u) + (w >= 1000u) + (w >= 10000u) + (w >= 100000u) + (w >= 1000000u) + (w >= 10000000u) +
-         (w >= 100000000u) + (w >= 1000000000u);
-    return n;
-}
-
-// byte sink: kWrite == false only counts
+// One position: its rows (one per sample) appended to `dst` when kWrite, their length either way.  The emitter is format_core.hpp's
+// RowSink -- rows assembled in a 64-bit register, eight bytes per store, four digits per dword of arithmetic.
 template <bool kWrite>
-struct Sink {
-    uint8_t* p;
-    uint32_t n;
-    __device__ __forceinline__ void ch(char c) {
-        if (kWrite) p[n] = (uint8_t)c;
-        ++n;
-    }
-    __device__ __forceinline__ void str(const char* s, uint32_t len) {
-        if (kWrite) for (uint32_t i = 0; i < len; ++i) p[n + i] = (uint8_t)s[i];
-        n += len;
-    }
-    __device__ __forceinline__ void num(uint64_t v) {
-        const uint32_t nd = n_digits(v);
-        if (kWrite) {
-            if (v <= 0xFFFFFFFFull) {
-                uint32_t w = (uint32_t)v;
-                for (uint32_t i = nd; i-- > 0;) { p[n + i] = (uint8_t)('0' + w % 10u); w /= 10u; }
-            } else {
-                for (uint32_t i = nd; i-- > 0;) { p[n + i] = (uint8_t)('0' + v % 10u); v /= 10u; }
-            }
-        }
-        n += nd;
-    }
-};
-
-template <bool kWrite>
-__device__ uint32_t emit_position(const FormatArgs& a, uint32_t pos, uint8_t* dst) {
+__device__ __forceinline__ uint32_t emit_position(const FormatArgs& a, uint32_t pos, uint8_t* dst) {
     const uint32_t tile = a.tile_first + pos / a.T;
     const uint32_t slot = tile < a.tile_end ? a.slot_of[tile] : 0xFFFFFFFFu;
     const uint32_t in_tile = pos & (a.T - 1u);
@@ -76,32 +44,42 @@ __device__ uint32_t emit_position(const FormatArgs& a, uint32_t pos, uint8_t* ds
         }
     }
     if (!column && !a.zero_fill) return 0;
-    Sink<kWrite> o{dst, 0};
+    fmt::RowSink o;
+    o.init(dst);
+    uint32_t n = 0;
+    const uint32_t nd_pos = fmt::n_digits32(pos);
     for (uint32_t s = 0; s < a.S; ++s) {
-        uint32_t v[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) v[k] = column ? c[s * 7u + k] : 0u;
+        uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (column) __builtin_memcpy(v, c + s * 7u, 28);
         const uint64_t total = (uint64_t)v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6];
         const bool ok = total >= a.lo && total <= a.hi;
         if (!ok && !a.annotate) break;                       // return, not continue (depth.d:540-541)
-        o.str(a.names, a.ref_name_len);
-        o.ch('\t'); o.num(pos);
-        o.ch('\t'); o.num(total);
-        o.ch('\t'); o.num(v[0]);
-        o.ch('\t'); o.num(v[1]);
-        o.ch('\t'); o.num(v[2]);
-        o.ch('\t'); o.num(v[3]);
-        o.ch('\t'); o.num(v[5]);
-        o.ch('\t'); o.num(v[6]);
-        if (!a.combined) {
-            const uint32_t so = a.sample_off[s], sl = a.sample_off[s + 1] - so;
-            o.ch('\t');
-            o.str(a.names + so, sl);
+        // REF \t POS \t COV \t A \t C \t G \t T \t DEL \t REFSKIP [\t SAMPLE] [\t y|n] \n   (v[4], the other bases, is counted in COV only)
+        const bool small = total < 10000ull;                  // then every counter has at most four digits
+        uint32_t nd[6];
+        const uint32_t w[6] = {v[0], v[1], v[2], v[3], v[5], v[6]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nd[k] = small ? fmt::n_digits4(w[k]) : fmt::n_digits32(w[k]);
+        const uint32_t nd_tot = small ? fmt::n_digits4((uint32_t)total) : fmt::n_digits64(total);
+        const uint32_t sl = a.combined ? 0u : a.sample_off[s + 1] - a.sample_off[s];
+        n += a.ref_name_len + 1u + nd_pos + 1u + nd_tot + 6u + nd[0] + nd[1] + nd[2] + nd[3] + nd[4] + nd[5] + (a.combined ? 0u : 1u + sl) +
+             (a.annotate ? 2u : 0u) + 1u;
+        if (kWrite) {
+            o.str(a.names, a.ref_name_len);
+            o.sep_num32('\t', pos, nd_pos);
+            if (small) o.sep_num32('\t', (uint32_t)total, nd_tot); else o.sep_num64('\t', total);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o.sep_num32('\t', w[k], nd[k]);
+            if (!a.combined) {
+                o.put((uint64_t)'\t', 1u);
+                o.str(a.names + a.sample_off[s], sl);
+            }
+            if (a.annotate) o.put((uint64_t)'\t' | (uint64_t)(ok ? 'y' : 'n') << 8 | (uint64_t)'\n' << 16, 3u);
+            else o.put((uint64_t)'\n', 1u);
         }
-        if (a.annotate) { o.ch('\t'); o.ch(ok ? 'y' : 'n'); }
-        o.ch('\n');
     }
-    return o.n;
+    if (kWrite) o.finish();
+    return n;
 }
 
 __device__ __forceinline__ uint32_t wave_incl(uint32_t v, uint32_t lane) {
