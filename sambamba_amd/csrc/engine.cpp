@@ -2402,6 +2402,8 @@ static FormatArgs format_args(sbx_ctx* c, uint32_t ref_id, double min_cov, doubl
     a.names = c->d_fmt_names.p;
     a.ref_name_len = (uint32_t)c->hdr.refs[ref_id].name.size();
     a.sample_off = c->d_fmt_soff.p;
+    a.max_sample_len = 0;
+    for (size_t i = 0; i + 1 < c->h_fmt_soff.size(); ++i) a.max_sample_len = std::max(a.max_sample_len, c->h_fmt_soff[i + 1] - c->h_fmt_soff[i]);
     return a;
 }
 

@@ -24,7 +24,6 @@ namespace sbx {
 namespace {
 
 constexpr int kFmtThreads = 256;
-constexpr uint32_t kFmtLds = 24 * 1024;     // text of one chunk (rows of up to 96 bytes on average); chunks that do not fit go straight to HBM
 
 // One position: its rows (one per sample) appended to `dst` when kWrite, their length either way.  The emitter is format_core.hpp's
 // RowSink -- rows assembled in a 64-bit register, eight bytes per store, four digits per dword of arithmetic.
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(kFmtThreads) void k_format_measure(FormatArgs a, ui
 
 // pass 2: the text
 __global__ __launch_bounds__(kFmtThreads) void k_format_write(FormatArgs a, const uint64_t* __restrict__ chunk_off,
-                                                             uint8_t* __restrict__ text) {
+                                                             uint8_t* __restrict__ text, uint32_t lds_cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_text[];
     __shared__ uint32_t wsum[kFmtThreads / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(kFmtThreads) void k_format_write(FormatArgs a, cons
     uint32_t my = inc - n;
     for (uint32_t w = 0; w < wv; ++w) my += wsum[w];
     uint8_t* out = text + off;
-    if (total > kFmtLds) {            // very long names: straight to HBM
+    if (total > lds_cap) {            // very long rows: straight to HBM
         if (n) emit_position<true>(a, (uint32_t)pos, out + my);
         return;
     }
@@ -148,7 +147,13 @@ void launch_format_measure(const FormatArgs& a, uint32_t n_chunks, uint32_t* d_c
 
 void launch_format_write(const FormatArgs& a, uint32_t n_chunks, const uint64_t* d_chunk_off, uint8_t* d_text, hipStream_t stream) {
     if (!n_chunks) return;
-    hipLaunchKernelGGL(k_format_write, dim3(n_chunks), dim3(kFmtThreads), kFmtLds, stream, a, d_chunk_off, d_text);
+    // LDS for the text of a chunk: what rows with three-digit counters need -- 13 KB for one sample and a short contig name, eight
+    // workgroups per CU -- instead of the 48 KB a chunk may use; a chunk that does not fit writes its rows straight to HBM
+    const uint32_t row = a.ref_name_len + 44u + (a.combined ? 0u : a.max_sample_len + 1u) + (a.annotate ? 2u : 0u);
+    uint64_t want = (uint64_t)kFmtThreads * a.S * row;
+    want = (want + 1023u) & ~1023ull;
+    const uint32_t lds = (uint32_t)(want < 8192u ? 8192u : want > 48u * 1024u ? 48u * 1024u : want);
+    hipLaunchKernelGGL(k_format_write, dim3(n_chunks), dim3(kFmtThreads), lds, stream, a, d_chunk_off, d_text, lds);
     SBX_HIP(hipGetLastError());
 }
 

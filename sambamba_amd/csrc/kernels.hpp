@@ -267,6 +267,7 @@ struct FormatArgs {
     const char* names;            // device blob: contig name, then the sample names
     uint32_t ref_name_len;
     const uint32_t* sample_off;   // [S + 1] offsets of the sample names inside `names`
+    uint32_t max_sample_len;      // longest sample name (sizes the LDS of a chunk)
 };
 uint32_t format_chunk_positions();
 void launch_format_measure(const FormatArgs& a, uint32_t n_chunks, uint32_t* d_chunk_len, hipStream_t stream);
