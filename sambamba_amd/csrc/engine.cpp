@@ -141,6 +141,7 @@ struct sbx_ctx {
     size_t text_host_cap[2] = {0, 0};
     hipEvent_t text_ev_fmt[2] = {nullptr, nullptr}, text_ev_copy[2] = {nullptr, nullptr};
     std::string h_fmt_blob;
+    bool fmt_blob_on_device = false;      // d_fmt_names / d_fmt_soff hold h_fmt_blob / h_fmt_soff
     std::vector<uint32_t> h_fmt_soff;
     uint8_t* stage[kStages] = {};
     hipEvent_t stage_ev[kStages] = {};
@@ -2370,18 +2371,26 @@ int sbx_depth_base_tile_device(sbx_ctx* c, uint32_t ref_id, uint32_t beg, uint32
 static FormatArgs format_args(sbx_ctx* c, uint32_t ref_id, double min_cov, double max_cov, int annotate, hipStream_t s) {
     const uint32_t S = c->n_samples_eff;
     // names blob: contig name, then the sample names ("*" when the header has no read groups, as the CLI prints)
-    c->h_fmt_blob = c->hdr.refs[ref_id].name;
-    c->h_fmt_soff.clear();
+    // (the blob on the device is kept while the next call asks for the same contig and sample names: a caller that formats a contig
+    //  piece by piece does not pay two copies and a synchronisation per piece)
+    std::string blob = c->hdr.refs[ref_id].name;
+    std::vector<uint32_t> soff;
     for (uint32_t i = 0; i < S; ++i) {
-        c->h_fmt_soff.push_back((uint32_t)c->h_fmt_blob.size());
-        if (!c->combined && i < c->hdr.sample_names.size()) c->h_fmt_blob += c->hdr.sample_names[i];
+        soff.push_back((uint32_t)blob.size());
+        if (!c->combined && i < c->hdr.sample_names.size()) blob += c->hdr.sample_names[i];
     }
-    c->h_fmt_soff.push_back((uint32_t)c->h_fmt_blob.size());
-    c->d_fmt_names.ensure(c->h_fmt_blob.size() + 1);
-    c->d_fmt_soff.ensure(c->h_fmt_soff.size());
-    SBX_HIP(hipMemcpyAsync(c->d_fmt_names.p, c->h_fmt_blob.data(), c->h_fmt_blob.size(), hipMemcpyHostToDevice, s));
-    SBX_HIP(hipMemcpyAsync(c->d_fmt_soff.p, c->h_fmt_soff.data(), c->h_fmt_soff.size() * 4, hipMemcpyHostToDevice, s));
-    SBX_HIP(hipStreamSynchronize(s));         // (the host copies may be reused by the next call)
+    soff.push_back((uint32_t)blob.size());
+    if (!c->fmt_blob_on_device || blob != c->h_fmt_blob || soff != c->h_fmt_soff) {
+        c->fmt_blob_on_device = false;
+        c->h_fmt_blob = blob;
+        c->h_fmt_soff = soff;
+        c->d_fmt_names.ensure(c->h_fmt_blob.size() + 1);
+        c->d_fmt_soff.ensure(c->h_fmt_soff.size());
+        SBX_HIP(hipMemcpyAsync(c->d_fmt_names.p, c->h_fmt_blob.data(), c->h_fmt_blob.size(), hipMemcpyHostToDevice, s));
+        SBX_HIP(hipMemcpyAsync(c->d_fmt_soff.p, c->h_fmt_soff.data(), c->h_fmt_soff.size() * 4, hipMemcpyHostToDevice, s));
+        SBX_HIP(hipStreamSynchronize(s));         // (the host copies may be changed by the next call)
+        c->fmt_blob_on_device = true;
+    }
     FormatArgs a{};
     a.counters = c->d_counters.p;
     a.span = c->span_valid ? c->d_span.p : nullptr;

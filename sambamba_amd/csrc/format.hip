@@ -25,57 +25,86 @@ namespace {
 
 constexpr int kFmtThreads = 256;
 
-// One position: its rows (one per sample) appended to `dst` when kWrite, their length either way.  The emitter is format_core.hpp's
-// RowSink -- rows assembled in a 64-bit register, eight bytes per store, four digits per dword of arithmetic.
-template <bool kWrite>
-__device__ __forceinline__ uint32_t emit_position(const FormatArgs& a, uint32_t pos, uint8_t* dst) {
+// The counters of a position: where they are and whether a pileup column exists there (>= 1 admitted read spans it).
+struct PosInfo {
+    const uint32_t* c;
+    bool column, prints;          // prints: the position has rows at all (a column, or all-zero rows when min_cov == 0)
+};
+__device__ __forceinline__ PosInfo pos_lookup(const FormatArgs& a, uint32_t pos) {
     const uint32_t tile = a.tile_first + pos / a.T;
     const uint32_t slot = tile < a.tile_end ? a.slot_of[tile] : 0xFFFFFFFFu;
     const uint32_t in_tile = pos & (a.T - 1u);
-    const uint32_t* c = slot != 0xFFFFFFFFu ? a.counters + ((size_t)slot * a.T + in_tile) * a.S * 7u : nullptr;
-    bool column = false;      // does a pileup column exist here?
-    if (c) {
-        if (a.span) column = a.span[(size_t)slot * a.T + in_tile] != 0;
+    PosInfo pi;
+    pi.c = slot != 0xFFFFFFFFu ? a.counters + ((size_t)slot * a.T + in_tile) * a.S * 7u : nullptr;
+    pi.column = false;
+    if (pi.c) {
+        if (a.span) pi.column = a.span[(size_t)slot * a.T + in_tile] != 0;
         else {
             uint32_t any = 0;
-            for (uint32_t k = 0; k < a.S * 7u; ++k) any |= c[k];
-            column = any != 0;
+            for (uint32_t k = 0; k < a.S * 7u; ++k) any |= pi.c[k];
+            pi.column = any != 0;
         }
     }
-    if (!column && !a.zero_fill) return 0;
+    pi.prints = pi.column || a.zero_fill;
+    return pi;
+}
+
+// One row -- REF \t POS \t COV \t A \t C \t G \t T \t DEL \t REFSKIP [\t SAMPLE] [\t y|n] \n  (the other bases are counted in COV only) --
+// in two steps, so that the writing kernel, which needs the length of every row of a chunk before it can place the first one, does not
+// read and count a position twice: row_prepare loads the counters of sample s and counts the digits; row_emit appends the row to a
+// RowSink (format_core.hpp: rows assembled in a 64-bit register, eight bytes per store, four digits per dword of arithmetic).
+struct RowPrep {
+    uint32_t w[6], nd[6];
+    uint64_t total;
+    uint32_t nd_tot, len;
+    bool ok, small;
+};
+// false: the loop over the samples of the position ends here (coverage out of range and rows are not annotated: depth.d:540-541 returns)
+__device__ __forceinline__ bool row_prepare(const FormatArgs& a, const PosInfo& pi, uint32_t s, uint32_t nd_pos, RowPrep& r) {
+    uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (pi.column) __builtin_memcpy(v, pi.c + s * 7u, 28);
+    r.total = (uint64_t)v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6];
+    r.ok = r.total >= a.lo && r.total <= a.hi;
+    r.len = 0;
+    if (!r.ok && !a.annotate) return false;
+    r.small = r.total < 10000ull;                  // then every counter has at most four digits
+    r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3]; r.w[4] = v[5]; r.w[5] = v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.nd[k] = r.small ? fmt::n_digits4(r.w[k]) : fmt::n_digits32(r.w[k]);
+    r.nd_tot = r.small ? fmt::n_digits4((uint32_t)r.total) : fmt::n_digits64(r.total);
+    const uint32_t sl = a.combined ? 0u : a.sample_off[s + 1] - a.sample_off[s];
+    r.len = a.ref_name_len + 1u + nd_pos + 1u + r.nd_tot + 6u + r.nd[0] + r.nd[1] + r.nd[2] + r.nd[3] + r.nd[4] + r.nd[5] +
+            (a.combined ? 0u : 1u + sl) + (a.annotate ? 2u : 0u) + 1u;
+    return true;
+}
+__device__ __forceinline__ void row_emit(const FormatArgs& a, uint32_t pos, uint32_t nd_pos, uint32_t s, const RowPrep& r, fmt::RowSink& o) {
+    o.str(a.names, a.ref_name_len);
+    o.sep_num32('\t', pos, nd_pos);
+    if (r.small) o.sep_num32('\t', (uint32_t)r.total, r.nd_tot); else o.sep_num64('\t', r.total);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.sep_num32('\t', r.w[k], r.nd[k]);
+    if (!a.combined) {
+        o.put((uint64_t)'\t', 1u);
+        o.str(a.names + a.sample_off[s], a.sample_off[s + 1] - a.sample_off[s]);
+    }
+    if (a.annotate) o.put((uint64_t)'\t' | (uint64_t)(r.ok ? 'y' : 'n') << 8 | (uint64_t)'\n' << 16, 3u);
+    else o.put((uint64_t)'\n', 1u);
+}
+
+// One position: its rows (one per sample) appended to `dst` when kWrite, their length either way.
+template <bool kWrite>
+__device__ __forceinline__ uint32_t emit_position(const FormatArgs& a, uint32_t pos, uint8_t* dst) {
+    const PosInfo pi = pos_lookup(a, pos);
+    if (!pi.prints) return 0;
     fmt::RowSink o;
     o.init(dst);
     uint32_t n = 0;
     const uint32_t nd_pos = fmt::n_digits32(pos);
     for (uint32_t s = 0; s < a.S; ++s) {
-        uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (column) __builtin_memcpy(v, c + s * 7u, 28);
-        const uint64_t total = (uint64_t)v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6];
-        const bool ok = total >= a.lo && total <= a.hi;
-        if (!ok && !a.annotate) break;                       // return, not continue (depth.d:540-541)
-        // REF \t POS \t COV \t A \t C \t G \t T \t DEL \t REFSKIP [\t SAMPLE] [\t y|n] \n   (v[4], the other bases, is counted in COV only)
-        const bool small = total < 10000ull;                  // then every counter has at most four digits
-        uint32_t nd[6];
-        const uint32_t w[6] = {v[0], v[1], v[2], v[3], v[5], v[6]};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) nd[k] = small ? fmt::n_digits4(w[k]) : fmt::n_digits32(w[k]);
-        const uint32_t nd_tot = small ? fmt::n_digits4((uint32_t)total) : fmt::n_digits64(total);
-        const uint32_t sl = a.combined ? 0u : a.sample_off[s + 1] - a.sample_off[s];
-        n += a.ref_name_len + 1u + nd_pos + 1u + nd_tot + 6u + nd[0] + nd[1] + nd[2] + nd[3] + nd[4] + nd[5] + (a.combined ? 0u : 1u + sl) +
-             (a.annotate ? 2u : 0u) + 1u;
-        if (kWrite) {
-            o.str(a.names, a.ref_name_len);
-            o.sep_num32('\t', pos, nd_pos);
-            if (small) o.sep_num32('\t', (uint32_t)total, nd_tot); else o.sep_num64('\t', total);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o.sep_num32('\t', w[k], nd[k]);
-            if (!a.combined) {
-                o.put((uint64_t)'\t', 1u);
-                o.str(a.names + a.sample_off[s], sl);
-            }
-            if (a.annotate) o.put((uint64_t)'\t' | (uint64_t)(ok ? 'y' : 'n') << 8 | (uint64_t)'\n' << 16, 3u);
-            else o.put((uint64_t)'\n', 1u);
-        }
+        RowPrep r;
+        if (!row_prepare(a, pi, s, nd_pos, r)) break;
+        n += r.len;
+        if (kWrite) row_emit(a, pos, nd_pos, s, r, o);
     }
     if (kWrite) o.finish();
     return n;
@@ -112,18 +141,38 @@ __global__ __launch_bounds__(kFmtThreads) void k_format_write(FormatArgs a, cons
     const uint64_t off = chunk_off[blockIdx.x];
     const uint32_t total = (uint32_t)(chunk_off[blockIdx.x + 1] - off);
     if (total == 0) return;
-    const uint32_t n = pos < a.end ? emit_position<false>(a, (uint32_t)pos, nullptr) : 0u;
+    // (one sample: the row is prepared once -- counters read, digits counted -- and written from the registers)
+    const bool one = a.S == 1u;
+    RowPrep r1;
+    r1.len = 0;
+    uint32_t nd_pos = 0;
+    uint32_t n = 0;
+    if (pos < a.end) {
+        if (one) {
+            const PosInfo pi = pos_lookup(a, (uint32_t)pos);
+            nd_pos = fmt::n_digits32((uint32_t)pos);
+            if (pi.prints && row_prepare(a, pi, 0, nd_pos, r1)) n = r1.len;
+        } else n = emit_position<false>(a, (uint32_t)pos, nullptr);
+    }
     const uint32_t inc = wave_incl(n, lane);
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     uint32_t my = inc - n;
     for (uint32_t w = 0; w < wv; ++w) my += wsum[w];
     uint8_t* out = text + off;
-    if (total > lds_cap) {            // very long rows: straight to HBM
-        if (n) emit_position<true>(a, (uint32_t)pos, out + my);
-        return;
-    }
-    if (n) emit_position<true>(a, (uint32_t)pos, lds_text + my);
+    const bool in_lds = total <= lds_cap;         // (else very long rows: straight to HBM)
+    // (two calls: the stores into LDS stay LDS instructions)
+    auto rows_to = [&](uint8_t* dst) {
+        if (one) {
+            fmt::RowSink o;
+            o.init(dst);
+            row_emit(a, (uint32_t)pos, nd_pos, 0, r1, o);
+            o.finish();
+        } else emit_position<true>(a, (uint32_t)pos, dst);
+    };
+    if (n && in_lds) rows_to(lds_text + my);
+    if (n && !in_lds) rows_to(out + my);
+    if (!in_lds) return;
     __syncthreads();
     for (uint32_t i = 16 * t; i < total; i += 16 * kFmtThreads) {
         if (i + 16 <= total) {

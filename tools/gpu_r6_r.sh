@@ -6,9 +6,9 @@ OUT=$(pwd)/gpurun_out/r6_r
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests/test_gpu_format.py tests/test_gpu_depth.py tests/test_gpu_pipeline.py tests/test_gpu_cli_sharded.py tests/test_gpu_multibam.py tests/test_gpu_batches.py -m gpu -x -q 2>&1 | tail -4
-timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --parity-windows 4 > $OUT/bench_config2_k6_fast_scan.json 2> $OUT/bench_config2_k6_fast_scan.err
+timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --parity-windows 4 > $OUT/bench_config2_k6_prepared_rows.json 2> $OUT/bench_config2_k6_prepared_rows.err
 echo "bench rc=$?"
-python - $OUT/bench_config2_k6_fast_scan.json <<'PY'
+python - $OUT/bench_config2_k6_prepared_rows.json <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
