@@ -189,6 +189,7 @@ struct sbx_ctx {
     std::vector<uint8_t> h_ref_sets;
     std::string h_rg_ids;
     DeviceFilter h_df;
+    bool filter_is_simple = false;     // the -F program of the last upload_static: only operations eval_filter_simple knows
 
     // region / window statistics: buffers and the preprocessed range list survive between calls (a caller that asks for the
     // same BED after every run -- bench.py config 4, the CLI per batch -- pays for sorting, chunking and uploading it once)
@@ -1064,6 +1065,9 @@ static void upload_static(sbx_ctx* c, const std::vector<sbx_region>& sel, bool r
     c->d_ref_sets.ensure(c->h_ref_sets.size() + 1);
     if (!c->h_ref_sets.empty()) SBX_HIP(hipMemcpyAsync(c->d_ref_sets.p, c->h_ref_sets.data(), c->h_ref_sets.size(), hipMemcpyHostToDevice, s));
     df.ref_sets = c->d_ref_sets.p;
+    c->filter_is_simple = true;
+    for (int i = 0; i < df.n_ops; ++i) c->filter_is_simple = c->filter_is_simple && filter_op_is_simple(df.ops[i].kind, df.ops[i].field);
+    if (const char* e = getenv("SBX_K2_SIMPLE_FILTER")) c->filter_is_simple = c->filter_is_simple && atoi(e) != 0;      // (A/B: 0 = the interpreter always)
     SBX_HIP(hipMemcpyAsync(c->d_filter.p, &df, sizeof df, hipMemcpyHostToDevice, s));
     // read groups
     *rg_out = RgTable{nullptr, nullptr, nullptr, 0, 0, 0};
@@ -1197,6 +1201,7 @@ static void run_impl(sbx_ctx* c, const std::vector<sbx_region>& sel, bool restri
         a.entry = c->d_entry.p; a.exit_ = c->d_exit.p; a.count = c->d_count.p;
         a.state = c->d_state.p; a.scratch = c->d_lit.p;
         a.refs = refs; a.filt = c->d_filter.p; a.rg = rg; a.tile_pos = T;
+        a.simple_filter = c->filter_is_simple ? 1u : 0u;
         a.desc = c->d_desc.p; a.rec_ref = c->d_rec_ref.p; a.name_hash = c->fix_mate ? c->d_name_hash.p : nullptr;
         a.desc_cap = c->desc_cap;
         a.tile_lo = c->d_tile_lo.p; a.tile_hi = c->d_tile_hi.p; a.stats = c->d_stats.p; a.flags = c->d_flag.p;

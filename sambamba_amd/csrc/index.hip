@@ -60,32 +60,49 @@ __device__ bool plausible_record(const uint8_t* U, uint64_t limit, uint64_t o, c
                                  uint32_t* sort_key_ref, int32_t* sort_key_pos) {
     if (o + 36 > limit) return false;
     const uint8_t* p = U + o;
-    int64_t bs = (int32_t)ld32(p);
+    // (the fixed part in one go -- three loads in flight -- instead of a load per test: the candidates of a wavefront are 64 consecutive
+    //  offsets, their 36-byte windows share one or two lines, and a chain of nine dependent round trips per candidate was what
+    //  k_guess_entries spent its time on)
+    uint32_t f[9];
+    __builtin_memcpy(f, p, 36);
+    int64_t bs = (int32_t)f[0];
     if (bs < 32 || bs > (int64_t)(1 << 29)) return false;
-    int32_t ref = (int32_t)ld32(p + 4);
+    int32_t ref = (int32_t)f[1];
     if (ref < -1 || ref >= refs.n_ref_own) return false;
-    int32_t pos = (int32_t)ld32(p + 8);
+    int32_t pos = (int32_t)f[2];
     if (pos < -1) return false;
     if (ref >= 0 && pos > refs.ref_len[refs.own_to_merged ? refs.own_to_merged[ref] : ref]) return false;
-    uint32_t bmn = ld32(p + 12);
+    uint32_t bmn = f[3];
     uint32_t l_name = bmn & 0xFFu;
     if (l_name < 1) return false;
-    uint32_t fnc = ld32(p + 16);
+    uint32_t fnc = f[4];
     uint32_t n_cigar = fnc & 0xFFFFu;
-    int32_t l_seq = (int32_t)ld32(p + 20);
+    int32_t l_seq = (int32_t)f[5];
     if (l_seq < 0) return false;
-    int32_t nref = (int32_t)ld32(p + 24);
+    int32_t nref = (int32_t)f[6];
     if (nref < -1 || nref >= refs.n_ref_own) return false;
-    int32_t npos = (int32_t)ld32(p + 28);
+    int32_t npos = (int32_t)f[7];
     if (npos < -1) return false;
     int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 + (int64_t)l_seq;
     if (bs < fixed) return false;
     if (o + 4 + (uint64_t)bs > limit) return false;
     // read name: printable, NUL only at the end
+    // (eight characters per load, tested in registers: the true start's three records used to pay a round trip per character)
     const uint8_t* name = p + 36;
-    if (name[l_name - 1] != 0) return false;
-    for (uint32_t k = 0; k + 1 < l_name; ++k)
-        if (name[k] < 33 || name[k] > 126) return false;
+    const uint8_t last = name[l_name - 1];
+    bool printable = true;
+    for (uint32_t k = 0; k + 1 < l_name; k += 8) {
+        uint64_t x;
+        __builtin_memcpy(&x, name + k, 8);       // (may read a few bytes past the name: inside the record, or the slack behind the stream)
+        const uint32_t n = l_name - 1 - k < 8u ? l_name - 1 - k : 8u;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t ch = (uint32_t)(x >> (8 * i)) & 0xFFu;
+            if (i < n && (ch < 33u || ch > 126u)) printable = false;
+        }
+        if (!printable) break;
+    }
+    if (last != 0 || !printable) return false;
     // CIGAR: known operations whose query-consuming lengths add up to l_seq (SAM 1.4; what every aligner and htslib
     // write).  A window that starts a byte or two off a true record passes every test above for a few percent of the
     // positions (the shifted fields stay in range) and, one time in a record length, chains into the true records
@@ -297,6 +314,47 @@ __device__ bool cmp_str(uint32_t op, const uint8_t* a, uint32_t na, const char* 
     for (uint32_t i = 0; i < n && c == 0; ++i) c = (int)a[i] - (int)(uint8_t)b[i];
     if (c == 0) c = na < nb ? -1 : na > nb ? 1 : 0;
     return cmp_op<int>(op, c, 0);
+}
+
+// A -F program of flag tests, integer fields and and / or / not only -- the default filter of `depth` (mapping_quality > 0 and not
+// duplicate and not failed_quality_control, depth.d:1159) and most filters people write -- evaluated without the interpreter's string,
+// tag and regular-expression machinery: the describe kernel built around it needs half the registers and runs at twice the occupancy
+// (k_describe_blocks_simple below).  kernels.hpp: filter_op_is_simple says which operations it knows.
+__device__ __forceinline__ bool eval_filter_simple(const DeviceFilter* f, const uint8_t* p /* at refID */, int32_t ref, int32_t pos, uint32_t bmn,
+                                                   uint32_t fnc, int32_t l_seq) {
+    uint64_t stack = 0;
+    int sp = 0;
+    const uint32_t flag = fnc >> 16, mapq = (bmn >> 8) & 0xFF;
+    for (int i = 0; i < f->n_ops; ++i) {
+        const sbx_filter_op& op = f->ops[i];
+        bool v = true;
+        switch (op.kind) {
+            case 0: v = (flag & op.mask) != 0; break;
+            case 1: v = (flag & 1) && !(flag & 4) && !(flag & 8) && ref != (int32_t)ld32(p + 20); break;
+            case 2: {
+                int64_t x = 0;
+                switch (op.field) {
+                    case 0: x = ref; break;
+                    case 1: x = pos; break;
+                    case 2: x = mapq; break;
+                    case 3: x = l_seq; break;
+                    case 4: x = (int32_t)ld32(p + 20); break;
+                    case 5: x = (int32_t)ld32(p + 24); break;
+                    default: x = (int32_t)ld32(p + 28); break;
+                }
+                v = cmp_op<int64_t>(op.cmp, x, op.value);
+                break;
+            }
+            case 12: v = false; break;
+            case 3: { bool b2 = stack & 1; stack >>= 1; bool a2 = stack & 1; stack >>= 1; sp -= 2; v = a2 && b2; break; }
+            case 4: { bool b2 = stack & 1; stack >>= 1; bool a2 = stack & 1; stack >>= 1; sp -= 2; v = a2 || b2; break; }
+            case 5: { bool a2 = stack & 1; stack >>= 1; sp -= 1; v = !a2; break; }
+            default: v = true; break;
+        }
+        stack = (stack << 1) | (v ? 1u : 0u);
+        ++sp;
+    }
+    return sp > 0 ? (stack & 1) : true;
 }
 
 __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID */, int32_t ref, int32_t pos, uint32_t bmn,
@@ -527,7 +585,7 @@ struct Described {
 // p: the record's block_size field.  kStaged: p is the lane's staging slot in LDS -- the first kStageHead bytes of the record (fixed
 // part, name and CIGAR fit) -- and `tail_end` points behind the staged copy of the record's last kStageTail bytes (the tags fit);
 // otherwise p is the record in global memory.  The rg table comes as the view the kernel prepared (LDS copy or the global arrays).
-template <bool kStaged>
+template <bool kStaged, bool kSimpleFilter = false>
 __device__ __forceinline__ Described describe_record(const uint8_t* p, const uint8_t* tail_end, uint64_t o, const IndexArgs& a, const RgTable& rgv) {
     Described R;
     const int64_t bs = (int32_t)ld32(p);
@@ -562,7 +620,8 @@ __device__ __forceinline__ Described describe_record(const uint8_t* p, const uin
     bool admit = sane && !(flag & 0x4) && ref >= 0;                       // read.d:256, unmapped reads cover nothing
     const uint8_t* const tags_end = kStaged ? tail_end : r + bs;
     const uint8_t* const tags = kStaged ? tail_end - (bs - fixed) : r + fixed;
-    if (admit) admit = eval_filter(a.filt, r, ref, pos, bmn, fnc, l_seq, tags, tags_end);      // filtering.d:36-38
+    if (admit) admit = kSimpleFilter ? eval_filter_simple(a.filt, r, ref, pos, bmn, fnc, l_seq)
+                                     : eval_filter(a.filt, r, ref, pos, bmn, fnc, l_seq, tags, tags_end);      // filtering.d:36-38
     if (admit) {
         // basesCovered + shape of the CIGAR
         const uint8_t* cg = r + 32 + l_name;
@@ -703,8 +762,15 @@ __device__ void walk_block_from(const IndexArgs& a, uint32_t b, uint64_t E) {
     if (bad_block) atomicMin(a.flags + 0, b);
 }
 
-__global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
-    const uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+// The guess: the first offset of the block at which a chain of three plausible records starts.  ONE WAVE per block, one candidate offset
+// per lane -- 64 consecutive bytes are one or two 128-byte lines for the whole wavefront, and nearly every candidate is rejected by its
+// first load.  (Until round 6 the lane that walks the block scanned the candidates itself, one dependent load after the other, 64 lanes
+// in 64 different blocks: ~45 M extra requests per chromosome -- as many as the walk itself makes -- and the walk took 2.4 ms where
+// tools/calib5 says its 50 M scattered lines cost 1.0.)  Writes entry[b]; k_walk_blocks takes it from there.
+constexpr int kGuessThreads = 256;
+__global__ __launch_bounds__(kGuessThreads) void k_guess_entries(IndexArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * (kGuessThreads / 64) + (threadIdx.x >> 6);
     if (b >= a.n_blocks) return;
     const uint64_t beg = a.out_off[b], blk_end = beg + a.isize[b];
     const ChainRun run = a.runs[a.run_of[b]];
@@ -712,12 +778,23 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
     const uint64_t hi = hi0 > lo ? hi0 : lo;
     uint64_t E = kOffUnknown;
     if (b == run.blk_first) E = run.u_beg;
-    else if (a.entry_in) E = a.entry_in[b];
     else {
-        for (uint64_t o = lo; o < hi; ++o)
-            if (plausible_chain(a.U, run.u_end, o, a.refs)) { E = o; break; }
+        for (uint64_t base = lo; base < hi; base += 64) {
+            const uint64_t o = base + lane;
+            const bool ok = o < hi && plausible_chain(a.U, run.u_end, o, a.refs);
+            const uint64_t m = __ballot(ok);
+            if (m) { E = base + (uint64_t)__builtin_ctzll(m); break; }
+        }
     }
-    walk_block_from(a, b, E);
+    if (lane == 0) a.entry[b] = E;
+}
+
+__global__ __launch_bounds__(kWalkThreads) void k_walk_blocks(IndexArgs a) {
+    const uint32_t b = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (b >= a.n_blocks) return;
+    // (the entry: given by the caller after a repair, or guessed by k_guess_entries -- the first block of a run starts where the run does)
+    const ChainRun run = a.runs[a.run_of[b]];
+    walk_block_from(a, b, b == run.blk_first ? run.u_beg : a.entry_in[b]);
     if (a.inflate_status[b] != 0) atomicMin(a.flags + 1, b);
 }
 
@@ -910,7 +987,7 @@ constexpr uint32_t kStageHead = 64, kStageTail = 48, kStageSlot = kStageHead + k
 constexpr uint32_t kRgLdsIds = 256, kRgLdsMax = 16;
 static_assert(kRgLdsIds <= (uint32_t)kDescThreads, "the read-group ids are copied to LDS one byte per thread");
 
-template <bool kStage>
+template <bool kStage, bool kSimpleFilter = false>
 __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     __shared__ uint32_t tot[7];          // records, admitted, malformed, unknown read group of this workgroup's blocks; bytes K3 reads; longest span
     __shared__ __attribute__((aligned(16))) uint8_t stage[kDescThreads * kStageSlot];
@@ -974,8 +1051,8 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
                     staged = l_seq >= 0 && bs >= fixed && o + 4 + (uint64_t)bs == o_next && 36 + ln + 4 * nc <= (int64_t)kStageHead &&
                              bs - fixed <= (int64_t)kStageTail;
                 }
-                if (staged) R = describe_record<true>(slot, slot + kStageSlot, o, a, rgv);
-                else R = describe_record<false>(a.U + o, nullptr, o, a, rgv);
+                if (staged) R = describe_record<true, kSimpleFilter>(slot, slot + kStageSlot, o, a, rgv);
+                else R = describe_record<false, kSimpleFilter>(a.U + o, nullptr, o, a, rgv);
                 a.desc[idx] = R.d;
                 a.rec_ref[idx] = R.ref;
                 if (a.name_hash) a.name_hash[idx] = R.hash;
@@ -1041,6 +1118,8 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
 // compiled into this template is slower than round 4's kernel was.  `describe` does not wait for its chain of dependent loads; it runs
 // at the rate of scattered 128-byte lines a CU sustains (the walk, with a quarter of the occupancy, runs at the same rate per line).
 __global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_blocks(IndexArgs a) { describe_blocks_body<true>(a); }
+// the same with the simple filter evaluator (IndexArgs::simple_filter: the host looked at the program)
+__global__ __launch_bounds__(kDescThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_describe_blocks_simple(IndexArgs a) { describe_blocks_body<true, true>(a); }
 
 // ---- active tile compaction (single workgroup ballot scan; n_tiles ~ 1e3..2e6) ---------------------
 __global__ __launch_bounds__(kScanThreads) void k_tile_compact(const uint32_t* __restrict__ tile_lo,
@@ -1183,7 +1262,14 @@ void launch_max_u32(const uint32_t* d_in, uint64_t n, uint32_t* d_out, hipStream
 
 void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
     if (!a.n_blocks) return;
-    hipLaunchKernelGGL(k_walk_blocks, dim3((a.n_blocks + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, stream, a);
+    IndexArgs w = a;
+    if (!a.entry_in) {       // no entries given: guess them (into entry[], which the walk rewrites with the same values)
+        const uint32_t per_g = kGuessThreads / 64;
+        hipLaunchKernelGGL(k_guess_entries, dim3((a.n_blocks + per_g - 1) / per_g), dim3(kGuessThreads), 0, stream, a);
+        SBX_HIP(hipGetLastError());
+        w.entry_in = a.entry;
+    }
+    hipLaunchKernelGGL(k_walk_blocks, dim3((a.n_blocks + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, stream, w);
     SBX_HIP(hipGetLastError());
     // (scan_part: kScanMaxWgs words the launcher owns -- IndexArgs::scan_part; SBX_K2_SCAN=0 keeps the single workgroup)
     static const bool mw = [] { const char* e = getenv("SBX_K2_SCAN"); return !e || atoi(e) != 0; }();
@@ -1196,7 +1282,8 @@ void launch_index_blocks(const IndexArgs& a, hipStream_t stream) {
     SBX_HIP(hipGetLastError());
     const uint32_t per = kDescThreads / 64;
     const dim3 dgrid((a.n_blocks + per - 1) / per), dblock(kDescThreads);
-    hipLaunchKernelGGL(k_describe_blocks, dgrid, dblock, 0, stream, a);
+    if (a.simple_filter) hipLaunchKernelGGL(k_describe_blocks_simple, dgrid, dblock, 0, stream, a);
+    else hipLaunchKernelGGL(k_describe_blocks, dgrid, dblock, 0, stream, a);
     SBX_HIP(hipGetLastError());
 }
 

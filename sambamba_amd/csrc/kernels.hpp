@@ -55,6 +55,12 @@ struct DeviceFilter {       // compiled -F program (sbx_filter), evaluated per r
     int32_t n_ref;
 };
 
+// operations eval_filter_simple (index.hip) knows: flag tests, mate_is_on_another_chromosome-style flag logic, integer fields (not the
+// average base quality: it reads the qualities), and / or / not, the constants
+inline bool filter_op_is_simple(uint32_t kind, uint32_t field) {
+    return kind == 0 || kind == 1 || (kind == 2 && field != 7) || kind == 3 || kind == 4 || kind == 5 || kind == 6 || kind == 12;
+}
+
 struct RefTable {           // per-reference device arrays
     const int32_t* ref_len;        // [n_ref]
     const uint32_t* tile_base;     // [n_ref + 1] index of the contig's first tile
@@ -128,6 +134,7 @@ struct IndexArgs {
     uint32_t n_blocks;
     const uint32_t* inflate_status; // [n_blocks] K1 status
     const uint64_t* entry_in;       // nullptr: guess the first record start of every block; else the repaired chain
+    uint32_t simple_filter;         // the -F program holds flag tests, integer fields and and / or / not only (index.hip: eval_filter_simple)
     uint64_t* entry;                // [n_blocks] out: first record start at or after the block's first byte (may lie beyond it)
     uint64_t* exit_;                // [n_blocks] out: where the chain leaves the block
     uint32_t* count;                // [n_blocks] out: records starting inside the block

@@ -50,6 +50,15 @@ def synth_ms(tmp_path_factory):
     return gen_bam(str(d / "ms.bam"), "c1:150000,cEmpty:3000,c2:40000", coverage=12, seed=21, extra=["--samples", "3"])
 
 
+@pytest.mark.parametrize("extra", [["-c", "0"], ["-c", "2", "-a"]])
+def test_rows_of_many_samples_go_past_the_lds(tmp_path, extra):
+    """Eight samples: the rows of a 256-position chunk (8 x ~40 bytes per position: > 80 KB) exceed the 48 KB of LDS a chunk may use,
+    so the write kernel stores them straight to HBM -- RowSink with 8-byte global stores at any byte address (format_core.hpp)."""
+    bam = gen_bam(str(tmp_path / "s8.bam"), "cL:70000,cS:9000", coverage=16, seed=31, extra=["--samples", "8"])
+    args = ["base"] + extra + [bam]
+    assert run_cli(args) == run_oracle(args)
+
+
 @pytest.mark.parametrize("extra", [[], ["-c", "0"], ["-c", "5", "-C", "14"], ["-c", "4", "-a"], ["-q", "24", "-c", "0"],
                                    ["--combined", "-c", "0"], ["-q", "38", "-c", "2", "-a"]])
 def test_multisample_rows(synth_ms, extra):
