@@ -50,6 +50,28 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t* p) {
     return v;
 }
 
+// A read-only table behind a generic pointer, read at a wave-uniform index: through the constant address space the compiler makes it a
+// SCALAR load (its own counter; nothing to do with the vector memory queue).  As a generic pointer the -F program was read with
+// vector loads -- a dependent round trip to L2 per operation and record turn, queued behind whatever the wave had prefetched: that, not
+// the record bytes, was what `describe` waited for (round 6).
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* as_constant(const T* p) {
+    return (const __attribute__((address_space(4))) T*)(uintptr_t)p;
+}
+
+// operation i of a -F program, through the scalar unit (i is the same in every lane)
+__device__ __forceinline__ sbx_filter_op filter_op(const DeviceFilter* f, int i) {
+    // (four dwords: the scalar unit has no byte loads, and a byte field read on its own would be a vector load again)
+    static_assert(sizeof(sbx_filter_op) == 16 && offsetof(sbx_filter_op, mask) == 4 && offsetof(sbx_filter_op, value) == 8, "layout of sbx_filter_op");
+    const auto* w = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)&f->ops[i];
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    sbx_filter_op op;
+    op.kind = (uint8_t)w0; op.field = (uint8_t)(w0 >> 8); op.cmp = (uint8_t)(w0 >> 16); op.pad = 0;
+    op.mask = w1;
+    op.value = (int64_t)(((uint64_t)w3 << 32) | w2);
+    return op;
+}
+
 // CIGAR_TYPE table of cigar.d:116 -- bit0: consumes query, bit1: consumes reference (MIDNSHP=X)
 constexpr uint32_t kCigarType = 0x3C1A7u;
 __device__ __forceinline__ uint32_t cig_type(uint32_t raw) { return (kCigarType >> ((raw & 15u) * 2u)) & 3u; }
@@ -325,8 +347,10 @@ __device__ __forceinline__ bool eval_filter_simple(const DeviceFilter* f, const 
     uint64_t stack = 0;
     int sp = 0;
     const uint32_t flag = fnc >> 16, mapq = (bmn >> 8) & 0xFF;
-    for (int i = 0; i < f->n_ops; ++i) {
-        const sbx_filter_op& op = f->ops[i];
+    const auto* fc = as_constant(f);
+    const int n_ops = fc->n_ops;
+    for (int i = 0; i < n_ops; ++i) {
+        const sbx_filter_op op = filter_op(f, i);
         bool v = true;
         switch (op.kind) {
             case 0: v = (flag & op.mask) != 0; break;
@@ -364,8 +388,9 @@ __device__ bool eval_filter(const DeviceFilter* f, const uint8_t* p /* at refID 
     uint64_t stack = 0;
     int sp = 0;
     uint32_t flag = fnc >> 16, mapq = (bmn >> 8) & 0xFF;
-    for (int i = 0; i < f->n_ops; ++i) {
-        const sbx_filter_op& op = f->ops[i];
+    const int n_ops = as_constant(f)->n_ops;
+    for (int i = 0; i < n_ops; ++i) {
+        const sbx_filter_op op = filter_op(f, i);
         bool v = true;
         switch (op.kind) {
             case 0: v = (flag & op.mask) != 0; break;
@@ -674,14 +699,19 @@ __device__ __forceinline__ Described describe_record(const uint8_t* p, const uin
         else d.sample = (uint16_t)s;
     }
     if (admit) {
-        const uint32_t tb = a.refs.tile_base[ref];
+        // (the records of a wavefront lie on one contig but for a handful of blocks: its tile base comes through the scalar unit -- a
+        //  vector load here would queue behind the next turn's prefetched bytes and stall the parse for their whole latency)
+        const int32_t ref_u = __builtin_amdgcn_readfirstlane(ref);
+        const uint32_t tb_u = as_constant(a.refs.tile_base)[ref_u], tbn_u = as_constant(a.refs.tile_base)[ref_u + 1];
+        uint32_t tb = tb_u, tbn = tbn_u;
+        if (ref != ref_u) { tb = a.refs.tile_base[ref]; tbn = a.refs.tile_base[ref + 1]; }
         uint32_t t0 = tb + (uint32_t)pos / a.tile_pos;
         uint32_t t1 = tb + (uint32_t)(d.end - 1) / a.tile_pos;
         // An alignment may hang over the end of its contig -- the reference's pileup has no notion of a contig's length and makes a
         // column of every position a read covers (pileup.d:345-397) -- so a contig has spare tiles behind its last position
         // (RefTable::tile_base).  One that reaches beyond them is reported (IndexStats::over_tiles): the host enlarges the spare
         // region and repeats the pass; what this pass computes for the clipped record is never used.
-        const uint32_t last_tile = a.refs.tile_base[ref + 1] - 1;
+        const uint32_t last_tile = tbn - 1;
         if (t1 > last_tile) {
             atomicMax(&a.stats->over_tiles, t1 - last_tile);
             t1 = last_tile;
@@ -1004,8 +1034,8 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     }
     // a filter that reads bases or qualities needs the body of the record: no staging
     bool filt_body = false;
-    for (int k = 0; k < a.filt->n_ops; ++k) {
-        const sbx_filter_op& op = a.filt->ops[k];
+    for (int k = 0; k < as_constant(a.filt)->n_ops; ++k) {
+        const sbx_filter_op op = filter_op(a.filt, k);
         filt_body = filt_body || op.kind == 13 || (op.kind == 15 && op.field == 1) || (op.kind == 2 && op.field == 7);
     }
     __syncthreads();
@@ -1021,36 +1051,73 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
         const uint64_t chain_exit = a.exit_[b];        // where the record chain leaves the block: the end of its last record
         uint8_t* const slot = stage + threadIdx.x * kStageSlot;
         typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-        for (uint32_t i0 = 0; i0 < count; i0 += 64) {
+        // The kernel around the simple evaluator keeps three turns in flight: the record offsets of turn k + 2, the head and tail bytes of
+        // turn k + 1 (seven 16-byte loads per lane, issued right after turn k's bytes have gone to LDS) and the parse of turn k -- a turn
+        // costs two dependent round trips to HBM otherwise (the offsets, then the bytes), and five waves per SIMD do not hide them.  The
+        // kernel around the interpreter has no registers to hold a turn: it fetches, waits and parses turn after turn.
+        struct Offs { uint32_t lo, hi; };        // block-relative start of the lane's record and of the one behind it
+        struct Fetch { u32x4s h[4], t[3]; uint64_t o, o_next; bool live, can; };
+        auto load_offs = [&](uint32_t i0) {
+            Offs f{0u, 0u};
             const uint32_t i = i0 + lane;
-            const bool live = i < count;
+            if (i < count) { f.lo = list[i]; f.hi = i + 1 < count ? (uint32_t)list[i + 1] : 0xFFFFFFFFu; }
+            return f;
+        };
+        auto issue = [&](uint32_t i0, const Offs& f) {
+            Fetch x;
+            x.live = i0 + lane < count;
+            x.o = beg + f.lo;
+            x.o_next = f.hi != 0xFFFFFFFFu ? beg + f.hi : chain_exit;
+            // (the head may reach up to 64 bytes past the stream: the allocation has that slack, IndexArgs::u_alloc)
+            x.can = x.live && kStage && !filt_body && x.o_next >= x.o + 36 && x.o_next >= kStageTail && x.o_next <= a.u_alloc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x.h[k] = u32x4s{0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x.t[k] = u32x4s{0, 0, 0, 0};
+            if (x.can) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_memcpy(&x.h[k], a.U + x.o + 16 * k, 16);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) __builtin_memcpy(&x.t[k], a.U + x.o_next - kStageTail + 16 * k, 16);
+            }
+            return x;
+        };
+        Offs offs{0u, 0u};
+        Fetch cur;
+        if (kSimpleFilter) {
+            offs = load_offs(0);
+            cur = issue(0, offs);
+            offs = load_offs(64);
+        }
+        for (uint32_t i0 = 0; i0 < count; i0 += 64) {
+            if (!kSimpleFilter) cur = issue(i0, load_offs(i0));
+            const uint32_t i = i0 + lane;
+            const bool live = cur.live;
             Described R;
             R.admit = false; R.bad = false; R.urg = false; R.t0 = R.t1 = 0;
             const uint64_t idx = base + i;
+            const uint64_t o = cur.o, o_next = cur.o_next;
+            bool staged = cur.can;
+            if (staged) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *(u32x4s*)(slot + 16 * k) = cur.h[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *(u32x4s*)(slot + kStageHead + 16 * k) = cur.t[k];
+                // does the record fit the slot, and does its size agree with the chain?
+                const int64_t bs = (int32_t)cur.h[0].x;
+                const uint32_t bmn = cur.h[0].w, fnc = cur.h[1].x;
+                const int32_t l_seq = (int32_t)cur.h[1].y;
+                const int64_t ln = bmn & 0xFFu, nc = fnc & 0xFFFFu;
+                const int64_t fixed = 32 + ln + 4 * nc + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
+                staged = l_seq >= 0 && bs >= fixed && o + 4 + (uint64_t)bs == o_next && 36 + ln + 4 * nc <= (int64_t)kStageHead &&
+                         bs - fixed <= (int64_t)kStageTail;
+            }
+            // the next turn's bytes leave now and arrive while this turn is parsed; the offsets of the turn behind it follow them
+            if (kSimpleFilter && i0 + 64 < count) {
+                cur = issue(i0 + 64, offs);
+                offs = load_offs(i0 + 128);
+            }
             if (live) {
-                const uint64_t o = beg + list[i];
-                const uint64_t o_next = i + 1 < count ? beg + list[i + 1] : chain_exit;
-                // (the head may reach up to 64 bytes past the stream: the allocation has that slack, IndexArgs::u_alloc)
-                bool staged = kStage && !filt_body && o_next >= o + 36 && o_next >= kStageTail && o_next <= a.u_alloc;
-                if (staged) {
-                    u32x4s h[4], t[3];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) __builtin_memcpy(&h[k], a.U + o + 16 * k, 16);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) __builtin_memcpy(&t[k], a.U + o_next - kStageTail + 16 * k, 16);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) *(u32x4s*)(slot + 16 * k) = h[k];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) *(u32x4s*)(slot + kStageHead + 16 * k) = t[k];
-                    // does the record fit the slot, and does its size agree with the chain?
-                    const int64_t bs = (int32_t)h[0].x;
-                    const uint32_t bmn = h[0].w, fnc = h[1].x;
-                    const int32_t l_seq = (int32_t)h[1].y;
-                    const int64_t ln = bmn & 0xFFu, nc = fnc & 0xFFFFu;
-                    const int64_t fixed = 32 + ln + 4 * nc + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
-                    staged = l_seq >= 0 && bs >= fixed && o + 4 + (uint64_t)bs == o_next && 36 + ln + 4 * nc <= (int64_t)kStageHead &&
-                             bs - fixed <= (int64_t)kStageTail;
-                }
                 if (staged) R = describe_record<true, kSimpleFilter>(slot, slot + kStageSlot, o, a, rgv);
                 else R = describe_record<false, kSimpleFilter>(a.U + o, nullptr, o, a, rgv);
                 a.desc[idx] = R.d;
