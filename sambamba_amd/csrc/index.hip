@@ -1042,13 +1042,14 @@ __device__ __forceinline__ void describe_blocks_body(const IndexArgs& a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = blockIdx.x * (kDescThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform for the compiler too)
     // (descriptor array too small: nothing is written, the host enlarges it and launches again)
-    const uint32_t count = (b < a.n_blocks && !a.flags[2]) ? a.count[b] : 0u;
+    // (b is wave-uniform and none of these tables is written by this kernel: scalar loads)
+    const uint32_t count = (b < a.n_blocks && !as_constant(a.flags)[2]) ? as_constant(a.count)[b] : 0u;
     uint32_t n_adm = 0, n_bad = 0, n_urg = 0, b_seq = 0, b_qual = 0, m_span = 0;
     if (count) {
-        const uint64_t beg = a.out_off[b];
-        const uint64_t base = (a.state[b] & kStateMask) - count;
+        const uint64_t beg = as_constant(a.out_off)[b];
+        const uint64_t base = (as_constant(a.state)[b] & kStateMask) - count;
         const uint16_t* list = rec_list(a.scratch, beg, b);
-        const uint64_t chain_exit = a.exit_[b];        // where the record chain leaves the block: the end of its last record
+        const uint64_t chain_exit = as_constant(a.exit_)[b];        // where the record chain leaves the block: the end of its last record
         uint8_t* const slot = stage + threadIdx.x * kStageSlot;
         typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
         // The kernel around the simple evaluator keeps three turns in flight: the record offsets of turn k + 2, the head and tail bytes of

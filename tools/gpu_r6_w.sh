@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 6, GPU call V (the final set, after the K2 changes): the measurement set of config 2 on the round's kernels: counter passes stamped with the kernel sources (bench.py joins
+# round 6, GPU call W (the final set of the round): the measurement set of config 2 on the round's kernels: counter passes stamped with the kernel sources (bench.py joins
 # them into the line), the driver's invocation, smoke, then the whole GPU test-suite with all durations
-OUT=$(pwd)/gpurun_out/r6_v
+OUT=$(pwd)/gpurun_out/r6_w
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 bash tools/pmc_pass.sh $OUT 2 2>&1 | tail -14
