@@ -101,3 +101,15 @@ def test_regex_filters_reference_fixture(flt):
 def test_unsupported_regex_is_reported(tagged):
     r = run_cli(["base", "-F", "read_name =~ /(r)\\1/", tagged], check=False)
     assert r.returncode != 0 and b"back-references" in r.stderr
+
+
+@pytest.mark.parametrize("flt", [None, "mapping_quality >= 30 and not duplicate", "proper_pair and not (secondary_alignment or supplementary)",
+                                 "first_of_pair or mate_is_reverse_strand", "template_length > 100 and position < 3500000"])
+def test_simple_evaluator_and_interpreter_agree(flt):
+    """-F programs of flag tests, integer fields and and / or / not run through `eval_filter_simple` in a describe kernel of their own
+    (index.hip: k_describe_blocks_simple); SBX_K2_SIMPLE_FILTER=0 sends the same program through the interpreter.  Same text either way,
+    and the oracle's."""
+    args = ["base"] + (["-F", flt] if flt else []) + ["mate_overlaps_1_3M_4M.bam"]
+    simple = run_cli(args, cwd=GOLDEN)
+    assert simple == run_cli(args, cwd=GOLDEN, env={"SBX_K2_SIMPLE_FILTER": "0"})
+    assert simple == run_oracle(args, cwd=GOLDEN)
