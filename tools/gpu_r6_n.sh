@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, GPU call N: K1's overlapped schedule (balanced K1a launch, its tail on a side stream next to K1b) -- the config-2 bench with it and
 # with the one-launch schedule, the lab's sweep of waves per CU at full size, the inflate / depth tests
+# (the two-stream schedule and the lab's `split` mode exist in commit 809ed8a only: the experiment was taken out again)
 set -u
 OUT=$(pwd)/gpurun_out/r6_n
 mkdir -p $OUT

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, GPU call O: K1's overlapped schedule with the balanced launch in workgroups of FOUR wavefronts (one per SIMD): the lab's sweep at full
 # size, the config-2 bench with it
+# (the two-stream schedule and the lab's `split` mode exist in commit 809ed8a only: the experiment was taken out again)
 set -u
 OUT=$(pwd)/gpurun_out/r6_o
 mkdir -p $OUT
