@@ -663,6 +663,9 @@ struct WindowPrinter {
         }
         std::vector<uint8_t> seen(reg.size());
         std::vector<uint32_t> cov1(reg.size() * s_n * cstride);
+        if (any_min && o.fix_mate)
+            throw Fail{"--fix-mate-overlaps with --overlap > 0: the first pileup column lies in the first ring of windows of the first contig "
+                       "(the reference counts only reads that start inside those windows, depth.d:1031-1032); not supported on the device path"};
         if (any_min) check(c, sbx_depth_region_stats_from(c, reg.data(), reg.size(), min_start.data(), st.data(), cov1.data(), seen.data()));
         else check(c, sbx_depth_region_stats(c, reg.data(), reg.size(), st.data(), cov1.data(), seen.data()));
         if (extended && n_thr) {
@@ -734,7 +737,12 @@ struct WindowPrinter {
         window_stats(r, nw, nw + ring(), stale_st, stale_cov);
     }
     void run_refs(int r0, int r1) {
-        if (o.overlap > 0 && o.fix_mate) throw Fail{"--fix-mate-overlaps with --overlap > 0 is not supported on the device path"};
+        // --fix-mate-overlaps with overlapping windows: a window is the region [k step, k step + w) of the closed form (reduce.hip) as
+        // long as (a) w is a multiple of the step -- otherwise a ring slot also collects per-COLUMN mate terms of the columns in front of
+        // its window, which the closed form of a region does not know -- and (b) no window of the run's first ring is printed (window_stats
+        // below: is_first_occurrence, depth.d:1031-1032, interacts with the mate status there).  Everything else is refused.
+        if (o.overlap > 0 && o.fix_mate && o.window % step() != 0)
+            throw Fail{"--fix-mate-overlaps with an --overlap whose step (window - overlap) does not divide the window is not supported on the device path"};
         if (!have_first) {
             if (!first_column_of_run(r0, r1)) return;   // no column yet: windows so far print nothing
             have_first = true;

@@ -179,6 +179,37 @@ def test_synthetic_window_fix_mate(overlapping, extra):
     assert run_cli(args) == run_oracle(args)
 
 
+@pytest.fixture(scope="module")
+def overlapping_behind_a_readless_contig(tmp_path_factory):
+    # (a first contig too short for a read pair: the first pileup column of the run lies on the SECOND contig, so no window of the
+    #  run's first ring -- where is_first_occurrence matters, depth.d:1031-1032 -- is printed; every real genome is like that: the first
+    #  reads of chr1 lie ten thousand positions in)
+    d = tmp_path_factory.mktemp("ovw")
+    return gen_bam(str(d / "ovw.bam"), "c0:250,chrA:90000,chrB:30000", coverage=40, seed=78,
+                   extra=["--insert-mean", "230", "--insert-sd", "45", "--tie-free-overlaps", "--samples", "2"])
+
+
+@pytest.mark.parametrize("extra", [["-w", "1000", "--overlap", "500"], ["-w", "300", "--overlap", "200", "-q", "20", "-T", "8"],
+                                   ["-w", "64", "--overlap", "48", "-T", "1", "-T", "40"], ["-w", "5000", "--overlap", "2500", "-q", "13"]])
+def test_window_fix_mate_with_overlapping_windows(overlapping_behind_a_readless_contig, extra):
+    """`window -m --overlap n` when the step divides the window and the first ring of the run prints nothing: a window is the region
+    [k step, k step + w) of the closed form (PerRegionPrinter with mate fixing, depth.d:717-845) -- against the oracle's literal
+    PerWindowPrinter."""
+    args = ["window", "-m"] + extra + [overlapping_behind_a_readless_contig]
+    assert run_cli(args) == run_oracle(args)
+
+
+def test_window_fix_mate_overlap_refusals(overlapping):
+    """What stays refused, loudly: a step that does not divide the window (a ring slot then collects per-column mate terms in front of
+    its window), and a run whose first pileup column lies in the first ring of windows of the first contig."""
+    bam, _ = overlapping
+    r = run_cli(["window", "-m", "-w", "300", "--overlap", "100", bam], check=False)
+    assert r.returncode != 0 and b"does not divide" in r.stderr
+    r = run_cli(["window", "-m", "-w", "300", "--overlap", "150", bam], check=False)
+    assert r.returncode != 0 and b"first ring" in r.stderr
+    assert r.stdout.count(b"\n") <= 1          # at most the header line
+
+
 def test_region_fix_mate_in_batches(overlapping):
     from tests.test_gpu_batches import cli_batched
     bam, bed = overlapping
